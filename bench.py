@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the SPH hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one solver.step() of the reference (neighbour search + density/EOS + non-pressure
+forces + pressure forces + symplectic integration + boundary) over the whole particle set.
+N=1 workload = BASELINE.json configs[1] (SURVEY 8d "C2"): 1,231,200-particle dam break, WCSPH,
+f32, synthetic lattice (no RNG).  Prints ONE JSON line on rank 0.
+
+Timing: W untimed warm-up steps, then exactly K steps enqueued on the library's HIP stream between
+two (barrier + device synchronise) fences; max over ranks.  `value` = fluid particles advanced per
+second by the whole job with all state resident in HBM (the scene upload is outside the region).
+Roofline leg: the dominant kernel (picked by a short all-kernel HIP-event pre-pass) is timed with
+HIP events on the library's own stream *inside* the timed region; achieved GB/s = algorithmic
+bytes per launch / average launch duration, against 8 TB/s HBM3E peak.
+CPU baseline leg (rank 0, N=1 only): the oracle (this repo's C restatement of the reference
+algorithm, OpenMP) timed on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy rate)
+
+# Algorithmic HBM bytes per particle per launch (DESIGN.md "Kernels").
+ALG_BYTES = {
+    "hash_count": 16, "scatter": 60, "density": 24, "non_pressure": 44, "pressure_integrate": 60,
+    "dfsph_density_alpha": 24, "dfsph_rho_adv": 36, "dfsph_correct": 48,
+    "pcisph_rho_star": 40, "pcisph_pressure_accel": 64,
+}
+
+
+def c2_scene(method="wcsph", scale_z=1):
+    """block identical to data/scenes/final_scene0.json:55-59 of the reference."""
+    dt = 4e-4 if method == "wcsph" else 6e-4
+    return {
+        "Configuration": {
+            "domainStart": [0.0, 0.0, 0.0], "domainEnd": [8.5, 8.0, 2.0 * scale_z], "addDomainBox": False,
+            "particleRadius": 0.01, "density0": 1000, "simulationMethod": method, "viscosityMethod": "standard",
+            "gravitation": [0.0, -9.81, 0.0], "timeStepSize": dt, "viscosity": 10.0,
+        },
+        "FluidBlocks": [{
+            "objectId": 0, "start": [0.09, 0.2, 0.2], "end": [1.7, 4.0, 1.8 + 2.0 * (scale_z - 1)],
+            "translation": [0.0, 0.0, 0.0], "scale": [1, 1, 1], "velocity": [0.0, -0.5, 0.0], "density": 1000.0,
+            "color": [50, 100, 200], "entryTime": -1.0,
+        }],
+    }
+
+
+def c1_scene(method="wcsph"):
+    from tests import helpers as H
+    return H.dam_break_scene(method=method)
+
+
+def cpu_baseline(cfg, steps, threads):
+    """Oracle (kind "port") timed on the host.  Test infrastructure used as the *measured baseline
+    only*; nothing of it is on the product path."""
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    from tests import helpers as H
+    sim = H.build_oracle(cfg, fixed_iterations=2 if cfg["Configuration"]["simulationMethod"] != "wcsph" else 0)
+    sim.prepare()
+    sim.step(1)  # warm-up (page faults, thread pool)
+    t0 = time.perf_counter()
+    sim.step(steps)
+    dt = time.perf_counter() - t0
+    n = sim.fluid_particle_num
+    pairs = sim.last_pairs
+    sim.close()
+    return n * steps / dt, pairs / (dt / steps), dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--strict-math", action="store_true", help="IEEE div/sqrt build instead of the fast build")
+    ap.add_argument("--no-deterministic", action="store_true")
+    ap.add_argument("--force-global", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--all-kernels", action="store_true", help="also print the per-kernel HIP-event table (stderr)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    method = "dfsph" if args.config == "c3" else "wcsph"
+    cfg = c1_scene(method) if args.config == "c1" else c2_scene(method)
+    from tests import helpers as H  # scene -> container/solver exactly like run_simulation.py
+    opts = dict(fast_math=0 if args.strict_math else 1, deterministic=0 if args.no_deterministic else 1,
+                force_global=int(args.force_global), device=local_rank if world > 1 else -1)
+    if method != "wcsph":
+        opts["fixed_iterations"] = 2
+    container, solver = H.build_product(cfg, **opts)
+    eng = container.engine
+    solver.prepare()
+    n_fluid = container.fluid_particle_num[None]
+    names = [eng.lib.sph_kernel_name(k).decode() for k in range(18)]
+
+    def fence():
+        eng.synchronize()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eng.step_async(args.warmup)
+    fence()
+
+    # pre-pass: which kernel dominates?  (all-kernel events perturb the stream slightly -> untimed)
+    eng.profile_enable(-1, True)
+    eng.profile_reset()
+    eng.step_async(5)
+    eng.synchronize()
+    table = {names[k]: eng.profile_read(k) for k in range(18)}
+    table = {k: v for k, v in table.items() if v[0] > 0}
+    dom = max((k for k in table if k in ALG_BYTES), key=lambda k: table[k][1])
+    if args.all_kernels and rank == 0:
+        for k, (n, ms) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+            print(f"  {k:24s} launches {n:5d}  avg {1e3 * ms / n:9.1f} us", file=sys.stderr)
+    eng.profile_enable(-1, False)
+    eng.profile_enable(names.index(dom), True)
+    eng.profile_reset()
+
+    fence()
+    t0 = time.perf_counter()
+    eng.step_async(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    launches, ms = eng.profile_read(names.index(dom))
+    stats = solver.stats()
+    n_total = n_fluid * world  # replicas: every rank advances its own copy
+    value = n_total * args.steps / elapsed
+    avg_s = (ms / max(launches, 1)) * 1e-3
+    achieved = ALG_BYTES[dom] * n_fluid / avg_s / 1e9 if launches else None
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(args.config, {}).get(dom)
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "particle-updates/sec", "value": value, "unit": "particle-updates/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": {"c1": "C1 8,000-particle cube dam break", "c2": "C2 1,231,200-particle dam break",
+                         "c3": "C3 1,231,200-particle dam break, 2+2 fixed DFSPH iterations"}[args.config],
+            "method": method, "particles": int(n_total), "grid_cells": int(container.grid_num.prod()),
+            "dt": cfg["Configuration"]["timeStepSize"], "math": "strict" if args.strict_math else "fast",
+            "deterministic_sort": not args.no_deterministic,
+            "parallelism": "single-gpu" if world == 1 else f"replicas x{world} (slab sharding not built yet)",
+            "pair_interactions_per_step": int(stats["pair_interactions"]),
+            "pair_interactions_per_s": stats["pair_interactions"] * world * args.steps / elapsed,
+            "lds_fallback_blocks_last_step": int(stats["lds_fallback_blocks"]),
+            "device": eng.device_info()["name"],
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+            "launches": int(launches), "avg_launch_us": 1e6 * avg_s,
+            "alg_bytes_per_launch": ALG_BYTES[dom] * n_fluid,
+            "step_achieved": (204 * n_fluid + 12 * int(container.grid_num.prod())) / (elapsed / args.steps) / 1e9,
+            "note": "neighbour passes are VALU/LDS-bound, not HBM-bound (DESIGN.md)",
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = os.cpu_count() or 1
+        v, pairs_s, secs = cpu_baseline(cfg, args.cpu_steps, threads)
+        out["cpu_baseline"] = {
+            "value": v, "unit": "particle-updates/s", "cores": threads, "kind": "port",
+            "sample": f"{args.cpu_steps} steps of the same workload ({secs:.1f} s), oracle/sph_ref.c "
+                      f"(this repo's C restatement of the reference algorithm, OpenMP), not Taichi",
+            "pair_interactions_per_s": pairs_s,
+        }
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

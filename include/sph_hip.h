@@ -1,0 +1,199 @@
+/*
+ * include/sph_hip.h -- C-ABI of libsph_hip.so, the MI355X (gfx950) SPH hot path.
+ *
+ * The reference (jason-huang03/SPH_Project) is 100 % Python + Taichi and has no FFI of its
+ * own; this header is the boundary a reference-side binding would target (ctypes stub in
+ * INTEGRATION.md).  Each entry point names the reference interface it replaces (paths
+ * relative to the reference root).  Conventions:
+ *   - plain pointers and sizes only; the caller owns every host buffer (C-contiguous
+ *     f32 / i32), the library owns all device memory behind the opaque handle;
+ *   - every call returns 0 or a negative SphStatus; text via sph_last_error();
+ *     HIP / RCCL failures are captured, never fatal, nothing throws across the ABI;
+ *   - one host thread per handle; one HIP compute stream (+ one comm stream) per handle;
+ *   - python-side quantities of the reference are doubles here and are rounded to f32
+ *     exactly where a reference Taichi kernel would consume them.
+ */
+#ifndef SPH_HIP_H
+#define SPH_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_MAX_OBJECTS 20 /* SPH/containers/base_container.py:52 max_num_object */
+#define SPH_MAT_FLUID 1    /* base_container.py:30 */
+#define SPH_MAT_RIGID 2    /* base_container.py:29 */
+
+typedef enum {
+    SPH_OK = 0,
+    SPH_ERR_INVALID = -1,   /* bad argument / bad state */
+    SPH_ERR_CAPACITY = -2,  /* particle_max_num exceeded */
+    SPH_ERR_HIP = -3,       /* HIP runtime error (text in sph_last_error) */
+    SPH_ERR_NO_DEVICE = -4, /* no gfx950 device visible */
+    SPH_ERR_COMM = -5,      /* RCCL error */
+    SPH_ERR_UNSUPPORTED = -6
+} SphStatus;
+
+typedef enum { SPH_METHOD_WCSPH = 0, SPH_METHOD_DFSPH = 1, SPH_METHOD_PCISPH = 2 } SphMethod;
+
+/* Scene / solver constants.  Mirrors what BaseContainer.__init__ (base_container.py:10-60)
+   and BaseSolver.__init__ (SPH/fluid_solvers/base_solver.py:9-54) derive from the JSON. */
+typedef struct {
+    double domain_size[3];   /* base_container.py:23 (domainStart must be 0, run_simulation.py:11) */
+    double particle_radius;  /* :33 dx */
+    double support_radius;   /* :37 dh = 4 dx (or "supportRadius") = grid cell size :55 */
+    double V0;               /* :49 0.8 * diameter^3 */
+    double padding;          /* :58 */
+    int32_t grid_num[3];     /* :56 ceil(domain_size / dh) */
+    double gravity[3];       /* base_solver.py:16 */
+    double g_upper;          /* :21-23 gravitationUpper (10000 if absent) */
+    double viscosity;        /* :26 */
+    double viscosity_b;      /* :27-29 */
+    double density_0;        /* :31 */
+    double surface_tension;  /* :32 (0.01) */
+    double dt;               /* :36 timeStepSize */
+    int32_t particle_max_num;/* base_container.py:116 */
+    int32_t viscosity_implicit; /* base_solver.py:40 viscosityMethod == "implicit" */
+    int32_t method;          /* SphMethod; run_simulation.py:46-63 */
+    int32_t fixed_iterations;/* 0: reference stopping rules; >0: exactly this many DFSPH/PCISPH/CG iterations */
+    int32_t fast_math;       /* 0: IEEE div/sqrt, no FMA contraction; 1: v_rcp/v_rsq + FMA */
+    int32_t device;          /* HIP device ordinal, -1: current */
+    int32_t force_global;    /* debug: bypass the LDS cell-tile path (neighbour loops read L2 directly) */
+    int32_t deterministic;   /* 1: stable within-cell order (bit-reproducible sums) */
+} SphParams;
+
+typedef struct SphHandle SphHandle;
+
+/* Per-particle fields addressable by sph_download / sph_upload.  Layouts are the reference's
+   (base_container.py:138-185; dfsph_container.py:13-17; pcisph_container.py:15-19), in the
+   current sorted order of the container (as BaseContainer.dump, base_container.py:599). */
+typedef enum {
+    SPH_F_POSITION = 0,      /* f32[n][3] particle_positions */
+    SPH_F_VELOCITY = 1,      /* f32[n][3] particle_velocities */
+    SPH_F_ACCELERATION = 2,  /* f32[n][3] particle_accelerations */
+    SPH_F_DENSITY = 3,       /* f32[n]    particle_densities */
+    SPH_F_PRESSURE = 4,      /* f32[n]    particle_pressures */
+    SPH_F_REST_VOLUME = 5,   /* f32[n]    particle_rest_volumes */
+    SPH_F_MASS = 6,          /* f32[n]    particle_masses */
+    SPH_F_MATERIAL = 7,      /* i32[n]    particle_materials */
+    SPH_F_OBJECT_ID = 8,     /* i32[n]    particle_object_ids */
+    SPH_F_IS_DYNAMIC = 9,    /* i32[n]    particle_is_dynamic */
+    SPH_F_COLOR = 10,        /* i32[n][3] particle_colors */
+    SPH_F_PARTICLE_ID = 11,  /* i32[n]    insertion index (not in the reference; lets tests match particles) */
+    SPH_F_GRID_ID = 12,      /* i32[n]    reference flat cell id (ix*ny+iy)*nz+iz, base_container.py:473 */
+    SPH_F_DFSPH_ALPHA = 13,  /* f32[n] */
+    SPH_F_DFSPH_KAPPA = 14,  /* f32[n] */
+    SPH_F_DFSPH_KAPPA_V = 15,/* f32[n] */
+    SPH_F_DENSITY_STAR = 16, /* f32[n] */
+    SPH_F_DENSITY_DERIV = 17,/* f32[n] */
+    SPH_F_PRESSURE_ACCEL = 18,   /* f32[n][3] pcisph particle_pressure_accelerations */
+    SPH_F_PREDICTED_VEL = 19,    /* f32[n][3] */
+    SPH_F_PREDICTED_POS = 20,    /* f32[n][3] */
+    SPH_F_CG_X = 21,             /* f32[n][3] base_solver.py:46 */
+    SPH_F_ORIG_POSITION = 22,    /* f32[n][3] rigid_particle_original_positions */
+    SPH_F_COUNT_
+} SphField;
+
+/* Individually callable phases (tests, profiling).  sph_step() runs them in the order of the
+   reference's _step() (WCSPH.py:27, DFSPH.py:298, PCISPH.py:165) followed by step() :692. */
+typedef enum {
+    SPH_PH_NEIGHBOR_SEARCH = 0,  /* base_container.py:544 prepare_neighborhood_search */
+    SPH_PH_RIGID_VOLUME = 1,     /* base_solver.py:106 */
+    SPH_PH_DENSITY = 2,          /* :522 (+ WCSPH.py:17 EOS when method == wcsph) */
+    SPH_PH_NON_PRESSURE = 3,     /* :190 + :643 (gravity, surface tension, viscosity, v += dt a) */
+    SPH_PH_PRESSURE_INTEGRATE = 4, /* :136 + :643 + :652 + :575 */
+    SPH_PH_DFSPH_ALPHA = 5,      /* DFSPH.py:23 */
+    SPH_PH_DFSPH_DIVERGENCE = 6, /* DFSPH.py:139 */
+    SPH_PH_DFSPH_DENSITY = 7,    /* DFSPH.py:225 */
+    SPH_PH_COUNT_
+} SphPhase;
+
+typedef struct {
+    int64_t steps;               /* steps executed since create */
+    int64_t pair_interactions;   /* accepted (i fluid, j != i, |x_ij| < dh) pairs summed over the
+                                    neighbour passes of the LAST step (SURVEY 8d metric) */
+    int32_t particle_num;
+    int32_t fluid_particle_num;
+    int32_t iter_divergence, iter_density, iter_pcisph, iter_cg; /* last step */
+    float   err_divergence, err_density, err_pcisph, err_cg;
+    int64_t lds_fallback_blocks; /* neighbour-pass workgroups that overflowed the LDS tile (last step) */
+    double  total_time;          /* container.total_time, base_solver.py:694 */
+} SphStats;
+
+/* Kernel ids for the HIP-event profiler (sph_profile_*). */
+typedef enum {
+    SPH_K_HASH_COUNT = 0, SPH_K_SCAN = 1, SPH_K_SCATTER = 2, SPH_K_DENSITY = 3,
+    SPH_K_NON_PRESSURE = 4, SPH_K_PRESSURE_INTEGRATE = 5, SPH_K_RIGID_VOLUME = 6,
+    SPH_K_DFSPH_DENSITY_ALPHA = 7, SPH_K_DFSPH_RHO_ADV = 8, SPH_K_DFSPH_CORRECT = 9,
+    SPH_K_REDUCE = 10, SPH_K_PCISPH_RHO_STAR = 11, SPH_K_PCISPH_PRESSURE_ACCEL = 12,
+    SPH_K_CG_PREPARE = 13, SPH_K_CG_AP = 14, SPH_K_CG_VECTOR = 15, SPH_K_MISC = 16,
+    SPH_K_HALO = 17, SPH_K_COUNT_
+} SphKernelId;
+
+/* --- lifetime -------------------------------------------------------------------------- */
+/* replaces XContainer.__init__ allocation (base_container.py:129-185) + XSolver.__init__ */
+int sph_create(const SphParams *params, SphHandle **out);
+void sph_destroy(SphHandle *h);
+/* message of the last failure on this handle (h == NULL: last failure of sph_create) */
+const char *sph_last_error(SphHandle *h);
+
+/* --- scene upload ---------------------------------------------------------------------- */
+/* replaces BaseContainer._add_particles (base_container.py:441): append n particles of one object.
+   pos/vel: f32[n][3]; density/pressure: f32[n]; material/is_dynamic: i32[n]; color: i32[n][3]. */
+int sph_append_particles(SphHandle *h, int object_id, int n, const float *pos, const float *vel,
+                         const float *density, const float *pressure, const int32_t *material,
+                         const int32_t *is_dynamic, const int32_t *color);
+/* object_materials / rigid_body_is_dynamic (base_container.py:150,156; insert_object :237,:317,:332) */
+int sph_set_object(SphHandle *h, int object_id, int material, int is_dynamic);
+/* pose written by the host rigid solver (SPH/rigid_solver/bullet_solver.py:158-167); rot9 row-major */
+int sph_set_rigid_pose(SphHandle *h, int object_id, const float *com, const float *rot9,
+                       const float *vel, const float *angvel, const float *com0);
+/* rigid_body_forces / rigid_body_torques read by bullet_solver.py:150-156; reset != 0 zeroes them */
+int sph_get_rigid_wrench(SphHandle *h, float *force, float *torque, int reset);
+
+/* --- time stepping --------------------------------------------------------------------- */
+/* replaces XSolver.prepare() (base_solver.py:683, DFSPH.py:321, PCISPH.py:188); particles of
+   entryTime <= 0 must have been appended */
+int sph_prepare(SphHandle *h);
+/* replaces XSolver.step() (base_solver.py:692) called nsteps times; synchronous on return */
+int sph_step(SphHandle *h, int nsteps);
+/* enqueue nsteps without the trailing host synchronisation (bench / overlap); only valid when no
+   per-iteration host read-back is needed (wcsph, or fixed_iterations > 0) */
+int sph_step_async(SphHandle *h, int nsteps);
+int sph_synchronize(SphHandle *h);
+/* one reference kernel group at a time (tests) */
+int sph_run_phase(SphHandle *h, int phase);
+
+/* --- state access ---------------------------------------------------------------------- */
+/* replaces field.to_numpy() / BaseContainer.dump (base_container.py:599).  bytes must equal
+   particle_num * element size of the field. */
+int sph_download(SphHandle *h, int field, void *dst, size_t bytes);
+int sph_upload(SphHandle *h, int field, const void *src, size_t bytes);
+int sph_particle_num(SphHandle *h);       /* container.particle_num[None] */
+int sph_fluid_particle_num(SphHandle *h); /* container.fluid_particle_num[None] */
+int sph_get_stats(SphHandle *h, SphStats *out);
+
+/* --- profiling (HIP events on the compute stream) -------------------------------------- */
+/* record a HIP event pair around every launch of `kernel_id` (-1: all kernels); accumulates. */
+int sph_profile_enable(SphHandle *h, int kernel_id, int on);
+int sph_profile_reset(SphHandle *h);
+/* resolves pending events; returns launches and total milliseconds of that kernel id */
+int sph_profile_read(SphHandle *h, int kernel_id, int64_t *launches, double *total_ms);
+const char *sph_kernel_name(int kernel_id);
+/* device properties the bench reports: name (<=255 chars), CU count, HBM bytes */
+int sph_device_info(SphHandle *h, char *name256, int *cu_count, int64_t *hbm_bytes);
+
+/* --- multi-GPU: z-slab sharding, one process per GPU, RCCL over xGMI ------------------- */
+/* 128-byte RCCL unique id, created on rank 0 and distributed by the host launcher */
+int sph_comm_unique_id(void *out128);
+/* attach this handle to a slab communicator.  The handle then owns the cell layers
+   [z_lo, z_hi) of the global grid plus one ghost layer on each interior side. */
+int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id128);
+int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi);
+int sph_comm_get_slab(SphHandle *h, int *z_lo, int *z_hi, int *n_owned, int *n_ghost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPH_HIP_H */

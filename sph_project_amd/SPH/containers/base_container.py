@@ -1,0 +1,358 @@
+"""Particle container with the public surface of the reference's BaseContainer
+(SPH/containers/base_container.py), backed by a libsph_hip handle.
+
+What lives where:
+  * host (this file): scene -> particle lattices, object bookkeeping, late insertion by
+    entryTime (base_container.py:212-341), dump (:599), the visibility buffers the reference's
+    GGUI loop reads (:567-597);
+  * device (libsph_hip): every per-particle field of base_container.py:132-185, the uniform grid,
+    counting sort and neighbour iteration (:468-560).
+Fields are exposed as small views (`container.particle_positions.to_numpy()`,
+`container.particle_num[None]`) so code written against the Taichi fields keeps reading.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _engine_fields as F
+from ..utils import SimConfig
+
+scene = F.scene
+
+
+class _Scalar:
+    """0-d field look-alike: value = s[None]."""
+
+    def __init__(self, getter, setter=None):
+        self._get, self._set = getter, setter
+
+    def __getitem__(self, key):
+        return self._get()
+
+    def __setitem__(self, key, value):
+        if self._set is None:
+            raise AttributeError("read-only scalar")
+        self._set(value)
+
+
+class _FieldView:
+    """Read view of one device field in the current sorted order (field.to_numpy())."""
+
+    def __init__(self, container, field_id):
+        self._c, self._f = container, field_id
+
+    def to_numpy(self):
+        return self._c.engine.download(self._f)
+
+    def from_numpy(self, arr):
+        self._c.engine.upload(self._f, arr)
+
+    def __getitem__(self, i):
+        return self.to_numpy()[i]
+
+    @property
+    def shape(self):
+        return (self._c.particle_max_num,)
+
+
+class BaseContainer:
+    METHOD = "wcsph"
+
+    def __init__(self, config: SimConfig, GGUI=False, **engine_opts):
+        self.cfg = config
+        self.GGUI = GGUI
+        self.total_time = 0.0
+
+        geo = scene.derive_geometry(config)
+        self.geometry = geo
+        self.domain_start, self.domain_end, self.domain_size = geo.domain_start, geo.domain_end, geo.domain_size
+        assert self.domain_start[1] >= 0.0, "domain start y should be greater than 0"
+        self.dim = geo.dim
+        self.material_rigid, self.material_fluid = scene.MATERIAL_RIGID, scene.MATERIAL_FLUID
+        self.dx, self.particle_diameter, self.dh = geo.dx, geo.particle_diameter, geo.dh
+        self.particle_spacing, self.V0 = geo.particle_spacing, geo.V0
+        self.max_num_object = F.MAX_OBJECTS
+        self.grid_size, self.grid_num, self.padding = geo.grid_size, geo.grid_num, geo.padding
+        self.add_domain_box = geo.add_domain_box
+        self.domain_box_thickness = geo.domain_box_thickness
+        if self.add_domain_box:
+            self.domain_box_start, self.domain_box_size = geo.domain_box_start, geo.domain_box_size
+
+        self.object_collection = dict()
+        self.object_id_rigid_body = set()
+        self.object_id_fluid_body = set()
+        self.present_object = []
+        self.object_visibility = np.zeros(self.max_num_object, dtype=np.int32)
+        self.object_materials = np.zeros(self.max_num_object, dtype=np.int32)
+        self.rigid_body_is_dynamic = np.zeros(self.max_num_object, dtype=np.int32)
+        self.rigid_body_particle_num = np.zeros(self.max_num_object, dtype=np.int32)
+        self.rigid_body_masses = np.zeros(self.max_num_object, dtype=np.float32)
+        self.rigid_body_velocities = np.zeros((self.max_num_object, 3), dtype=np.float32)
+
+        # ---- particle budget (base_container.py:74-120)
+        fluid_n = rigid_n = 0
+        self.fluid_bodies = self.cfg.get_fluid_bodies()
+        for body in self.fluid_bodies:
+            pts = self.load_fluid_body(body, pitch=self.particle_spacing)
+            body["particleNum"], body["voxelizedPoints"] = pts.shape[0], pts
+            fluid_n += pts.shape[0]
+        self.fluid_blocks = self.cfg.get_fluid_blocks()
+        for blk in self.fluid_blocks:
+            blk["particleNum"] = scene.cube_particle_num(blk["start"], blk["end"], self.particle_spacing)
+            fluid_n += blk["particleNum"]
+        self.rigid_bodies = self.cfg.get_rigid_bodies()
+        for body in self.rigid_bodies:
+            pts = self.load_rigid_body(body, pitch=self.particle_spacing)
+            body["particleNum"], body["voxelizedPoints"] = pts.shape[0], pts
+            rigid_n += pts.shape[0]
+        self.rigid_blocks = self.cfg.get_rigid_blocks()
+        for _ in self.rigid_blocks:
+            raise NotImplementedError  # base_container.py:105-106
+        n_objects = len(self.fluid_blocks) + len(self.fluid_bodies) + len(self.rigid_blocks) + len(self.rigid_bodies)
+        self.rigid_body_particle_num_total = rigid_n
+        box_n = (scene.box_particle_num(self.domain_box_start, self.domain_box_size, self.domain_box_thickness,
+                                        self.particle_spacing) if self.add_domain_box else 0)
+        self.particle_max_num = fluid_n + rigid_n + box_n
+        self._object_num = n_objects + (1 if self.add_domain_box else 0)
+        self.object_num = _Scalar(lambda: self._object_num)
+
+        # ---- device state
+        sol = scene.derive_solver_constants(config)
+        self.solver_constants = sol
+        pd = scene.params_dict(geo, sol, self.METHOD, self.particle_max_num,
+                               fixed_iterations=engine_opts.get("fixed_iterations", 0))
+        p = F.lib.SphParams()
+        p.domain_size[:] = pd["domain_size"]; p.particle_radius = pd["particle_radius"]
+        p.support_radius = pd["support_radius"]; p.V0 = pd["V0"]; p.padding = pd["padding"]
+        p.grid_num[:] = pd["grid_num"]; p.gravity[:] = pd["gravity"]; p.g_upper = pd["g_upper"]
+        p.viscosity = pd["viscosity"]; p.viscosity_b = pd["viscosity_b"]; p.density_0 = pd["density_0"]
+        p.surface_tension = pd["surface_tension"]; p.dt = pd["dt"]; p.particle_max_num = pd["particle_max_num"]
+        p.viscosity_implicit = pd["viscosity_implicit"]; p.method = F.METHOD[self.METHOD]
+        p.fixed_iterations = pd["fixed_iterations"]
+        p.fast_math = int(engine_opts.get("fast_math", 0))
+        p.device = int(engine_opts.get("device", -1))
+        p.force_global = int(engine_opts.get("force_global", 0))
+        p.deterministic = int(engine_opts.get("deterministic", 1))
+        self.params_dict = pd
+        self.engine = F.lib.Engine(p)
+
+        self.particle_num = _Scalar(lambda: self.engine.particle_num)
+        self.fluid_particle_num = _Scalar(lambda: self.engine.fluid_particle_num)
+        self.particle_positions = _FieldView(self, F.F_POSITION)
+        self.particle_velocities = _FieldView(self, F.F_VELOCITY)
+        self.particle_accelerations = _FieldView(self, F.F_ACCELERATION)
+        self.particle_rest_volumes = _FieldView(self, F.F_REST_VOLUME)
+        self.particle_masses = _FieldView(self, F.F_MASS)
+        self.particle_densities = _FieldView(self, F.F_DENSITY)
+        self.particle_pressures = _FieldView(self, F.F_PRESSURE)
+        self.particle_materials = _FieldView(self, F.F_MATERIAL)
+        self.particle_object_ids = _FieldView(self, F.F_OBJECT_ID)
+        self.particle_is_dynamic = _FieldView(self, F.F_IS_DYNAMIC)
+        self.particle_colors = _FieldView(self, F.F_COLOR)
+        self.particle_ids = _FieldView(self, F.F_PARTICLE_ID)
+        self.grid_ids = _FieldView(self, F.F_GRID_ID)
+        self.rigid_particle_original_positions = _FieldView(self, F.F_ORIG_POSITION)
+
+        self.x_vis_buffer = None
+        if self.GGUI:
+            self.x_vis_buffer = np.zeros((self.particle_max_num, self.dim), dtype=np.float32)
+            self.color_vis_buffer = np.zeros((self.particle_max_num, 3), dtype=np.float32)
+
+        if self.add_domain_box:  # base_container.py:192-209
+            box_id = self._object_num - 1
+            self.add_box(object_id=box_id, lower_corner=self.domain_box_start, cube_size=self.domain_box_size,
+                         thickness=self.domain_box_thickness, material=self.material_rigid, is_dynamic=False,
+                         space=self.particle_spacing, color=(127, 127, 127))
+            self.object_visibility[box_id] = 0
+            self.object_materials[box_id] = self.material_rigid
+            self.rigid_body_is_dynamic[box_id] = 0
+            self.object_collection[box_id] = 0  # dummy, as in the reference
+            self.engine.set_object(box_id, self.material_rigid, 0)
+
+    # ------------------------------------------------------------------ insertion
+    def insert_object(self):
+        """base_container.py:212: add every object whose entryTime has come (once)."""
+        for fluid in self.fluid_blocks:
+            obj_id = fluid["objectId"]
+            if obj_id in self.present_object or fluid["entryTime"] > self.total_time:
+                continue
+            offset = np.array(fluid["translation"])
+            start = np.array(fluid["start"]) + offset
+            end = np.array(fluid["end"]) + offset
+            scale = np.array(fluid["scale"])
+            self.object_id_fluid_body.add(obj_id)
+            self.object_visibility[obj_id] = fluid.get("visible", 1)
+            self.object_materials[obj_id] = self.material_fluid
+            self.object_collection[obj_id] = fluid
+            self.engine.set_object(obj_id, self.material_fluid, 0)
+            self.add_cube(object_id=obj_id, lower_corner=start, cube_size=(end - start) * scale,
+                          velocity=fluid["velocity"], density=fluid["density"], is_dynamic=1, color=fluid["color"],
+                          material=self.material_fluid, space=self.particle_spacing)
+            self.present_object.append(obj_id)
+
+        for body in self.fluid_bodies:
+            obj_id = body["objectId"]
+            if obj_id in self.present_object or body["entryTime"] > self.total_time:
+                continue
+            pts = np.asarray(body["voxelizedPoints"], dtype=np.float32)
+            n = body["particleNum"]
+            self.object_visibility[obj_id] = body.get("visible", 1)
+            self.object_materials[obj_id] = self.material_fluid
+            self.object_id_fluid_body.add(obj_id)
+            self.object_collection[obj_id] = body
+            self.engine.set_object(obj_id, self.material_fluid, 0)
+            self.add_particles(obj_id, n, pts, np.tile(np.asarray(body["velocity"], np.float32), (n, 1)),
+                               body["density"] * np.ones(n, np.float32), np.zeros(n, np.float32),
+                               np.full(n, self.material_fluid, np.int32), np.ones(n, np.int32),
+                               np.tile(np.asarray(body["color"], np.int32), (n, 1)))
+            self.present_object.append(obj_id)
+
+        for body in self.rigid_bodies:
+            obj_id = body["objectId"]
+            if obj_id in self.present_object or body["entryTime"] > self.total_time:
+                continue
+            self.object_id_rigid_body.add(obj_id)
+            n = body["particleNum"]
+            self.rigid_body_particle_num[obj_id] = n
+            pts = np.asarray(body["voxelizedPoints"], dtype=np.float32)
+            is_dynamic = int(bool(body["isDynamic"]))
+            velocity = np.asarray(body["velocity"], np.float32) if is_dynamic else np.zeros(self.dim, np.float32)
+            self.object_visibility[obj_id] = body.get("visible", 1)
+            self.object_materials[obj_id] = self.material_rigid
+            self.object_collection[obj_id] = body
+            self.engine.set_object(obj_id, self.material_rigid, is_dynamic)
+            self.add_particles(obj_id, n, pts, np.tile(velocity, (n, 1)), body["density"] * np.ones(n, np.float32),
+                               np.zeros(n, np.float32), np.full(n, self.material_rigid, np.int32),
+                               is_dynamic * np.ones(n, np.int32), np.tile(np.asarray(body["color"], np.int32), (n, 1)))
+            self.rigid_body_is_dynamic[obj_id] = is_dynamic
+            self.rigid_body_velocities[obj_id] = velocity
+            if is_dynamic:  # base_container.py:385 compute_rigid_body_mass
+                self.rigid_body_masses[obj_id] = np.float32(n) * np.float32(body["density"]) * np.float32(self.V0)
+            self.present_object.append(obj_id)
+
+        for _ in self.rigid_blocks:
+            raise NotImplementedError
+
+    def add_particles(self, object_id, new_particles_num, new_particles_positions, new_particles_velocity,
+                      new_particle_density, new_particle_pressure, new_particles_material,
+                      new_particles_is_dynamic, new_particles_color):
+        """base_container.py:417 / :441 -- append at particle_num."""
+        assert new_particles_positions.shape[0] == new_particles_num
+        self.engine.append_particles(object_id, new_particles_positions, new_particles_velocity,
+                                     new_particle_density, new_particle_pressure, new_particles_material,
+                                     new_particles_is_dynamic, new_particles_color)
+
+    def _uniform_attributes(self, n, material, is_dynamic, color, density, pressure, velocity, positions):
+        vel = (np.zeros_like(positions, dtype=np.float32) if velocity is None
+               else np.tile(np.asarray(velocity, np.float32), (n, 1)))
+        return (vel, np.full(n, density if density is not None else 1000.0, np.float32),
+                np.full(n, pressure if pressure is not None else 0.0, np.float32),
+                np.full(n, material, np.int32), np.full(n, int(is_dynamic), np.int32),
+                np.tile(np.asarray(color, np.int32), (n, 1)))
+
+    def add_cube(self, object_id, lower_corner, cube_size, material, is_dynamic, color=(0, 0, 0), density=None,
+                 pressure=None, velocity=None, space=None):
+        """base_container.py:753."""
+        space = self.particle_diameter if space is None else space
+        pos = scene.cube_lattice(lower_corner, cube_size, space)
+        n = pos.shape[0]
+        vel, den, prs, mat, dyn, col = self._uniform_attributes(n, material, is_dynamic, color, density, pressure,
+                                                                velocity, pos)
+        self.add_particles(object_id, n, pos, vel, den, prs, mat, dyn, col)
+
+    def add_box(self, object_id, lower_corner, cube_size, thickness, material, is_dynamic, color=(0, 0, 0),
+                density=None, pressure=None, velocity=None, space=None):
+        """base_container.py:800."""
+        space = self.particle_diameter if space is None else space
+        pos = scene.box_lattice(lower_corner, cube_size, thickness, space)
+        n = pos.shape[0]
+        vel, den, prs, mat, dyn, col = self._uniform_attributes(n, material, is_dynamic, color, density, pressure,
+                                                                velocity, pos)
+        self.add_particles(object_id, n, pos, vel, den, prs, mat, dyn, col)
+
+    # ------------------------------------------------------------------ neighbour search
+    def prepare_neighborhood_search(self):
+        """base_container.py:544 (init_grid + prefix sum + reorder_particles)."""
+        self.engine.run_phase(F.PH_NEIGHBOR_SEARCH)
+
+    # ------------------------------------------------------------------ read-back
+    def dump(self, obj_id):
+        """base_container.py:599."""
+        mask = self.engine.download(F.F_OBJECT_ID) == obj_id
+        return {"position": self.engine.download(F.F_POSITION)[mask],
+                "velocity": self.engine.download(F.F_VELOCITY)[mask]}
+
+    def copy_to_vis_buffer(self, invisible_objects=[], dim=3):
+        """base_container.py:567 (host arrays instead of GGUI fields)."""
+        assert self.GGUI
+        self.x_vis_buffer[:] = 0.0
+        self.color_vis_buffer[:] = 0.0
+        n = self.engine.particle_num
+        obj = self.engine.download(F.F_OBJECT_ID)
+        pos = self.engine.download(F.F_POSITION)
+        col = self.engine.download(F.F_COLOR).astype(np.float32) / 255.0
+        for obj_id in self.object_collection:
+            if self.object_visibility[obj_id] == 1:
+                m = obj == obj_id
+                self.x_vis_buffer[:n][m] = pos[m] if dim == 3 else pos[m] / self.domain_size[:2]
+                self.color_vis_buffer[:n][m] = col[m]
+
+    # ------------------------------------------------------------------ meshes (out of hot path)
+    def _points_from_body(self, body, what):
+        pts = body.get("voxelizedPoints")
+        if pts is None:
+            return None
+        if isinstance(pts, str):
+            pts = np.load(pts)
+        return np.asarray(pts, dtype=np.float32).reshape(-1, self.dim)
+
+    def load_rigid_body(self, rigid_body, pitch=None):
+        """base_container.py:611 voxelises the mesh with trimesh.  Mesh voxelisation is outside the
+        accelerated path: supply precomputed points via "voxelizedPoints" (array or .npy path) or
+        have trimesh installed."""
+        pts = self._points_from_body(rigid_body, "rigid")
+        if pts is not None:
+            return pts
+        try:
+            import trimesh as tm
+        except ImportError as exc:
+            raise NotImplementedError('RigidBodies need trimesh (absent) or a "voxelizedPoints" entry') from exc
+        pitch = self.particle_diameter if pitch is None else pitch
+        mesh = tm.load(rigid_body["geometryFile"])
+        mesh.apply_scale(rigid_body["scale"])
+        if not rigid_body["isDynamic"]:
+            angle = rigid_body["rotationAngle"] / 360 * 2 * 3.1415926
+            rot = tm.transformations.rotation_matrix(angle, rigid_body["rotationAxis"], mesh.vertices.mean(axis=0))
+            mesh.apply_transform(rot)
+            mesh.vertices += np.array(rigid_body["translation"])
+        rigid_body["mesh"] = mesh.copy()
+        rigid_body["restPosition"] = rigid_body["mesh"].vertices
+        rigid_body["restCenterOfMass"] = np.array([0.0, 0.0, 0.0])
+        tm.repair.fill_holes(mesh)
+        return np.asarray(mesh.voxelized(pitch=pitch).fill().points, dtype=np.float32)
+
+    def load_fluid_body(self, body, pitch=None):
+        """base_container.py:676 (same note as load_rigid_body)."""
+        pts = self._points_from_body(body, "fluid")
+        if pts is not None:
+            return pts
+        try:
+            import trimesh as tm
+        except ImportError as exc:
+            raise NotImplementedError('FluidBodies need trimesh (absent) or a "voxelizedPoints" entry') from exc
+        pitch = self.particle_diameter if pitch is None else pitch
+        mesh = tm.load(body["geometryFile"])
+        mesh.apply_scale(body["scale"])
+        angle = body["rotationAngle"] / 360 * 2 * 3.1415926
+        mesh.apply_transform(tm.transformations.rotation_matrix(angle, body["rotationAxis"], mesh.vertices.mean(axis=0)))
+        mesh.vertices += np.array(body["translation"])
+        lo, hi = mesh.bounding_box.bounds
+        axes = [np.arange(lo[i], hi[i], pitch) for i in range(self.dim)]
+        pts = scene._mesh_points(axes)
+        return pts[mesh.contains(pts)]
+
+    def compute_cube_particle_num(self, start, end, space=None):
+        return scene.cube_particle_num(start, end, self.particle_diameter if space is None else space)
+
+    def compute_box_particle_num(self, lower_corner, cube_size, thickness, space=None):
+        return scene.box_particle_num(lower_corner, cube_size, thickness, self.particle_diameter if space is None else space)

@@ -1,0 +1,14 @@
+from .. import _engine_fields as F
+from .base_container import BaseContainer, _FieldView
+
+
+class PCISPHContainer(BaseContainer):
+    """pcisph_container.py:15-19 of the reference."""
+    METHOD = "pcisph"
+
+    def __init__(self, config, GGUI=False, **engine_opts):
+        super().__init__(config, GGUI, **engine_opts)
+        self.particle_pressure_accelerations = _FieldView(self, F.F_PRESSURE_ACCEL)
+        self.particle_predicted_velocities = _FieldView(self, F.F_PREDICTED_VEL)
+        self.particle_predicted_positions = _FieldView(self, F.F_PREDICTED_POS)
+        self.particle_densities_star = _FieldView(self, F.F_DENSITY_STAR)

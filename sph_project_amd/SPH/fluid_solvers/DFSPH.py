@@ -1,0 +1,24 @@
+from .. import _engine_fields as F
+from ..containers import DFSPHContainer
+from .base_solver import BaseSolver
+
+
+class DFSPHSolver(BaseSolver):
+    """DFSPH.py of the reference (divergence-free + constant-density solvers)."""
+
+    def __init__(self, container: DFSPHContainer):
+        super().__init__(container)
+        self.m_max_iterations_v = 1000
+        self.m_max_iterations = 1000
+        self.m_eps = 1e-5
+        self.max_error_V = 0.001
+        self.max_error = 0.0001
+
+    def compute_alpha(self):
+        self.engine.run_phase(F.PH_DFSPH_ALPHA)
+
+    def correct_divergence_error(self):
+        self.engine.run_phase(F.PH_DFSPH_DIVERGENCE)
+
+    def correct_density_error(self):
+        self.engine.run_phase(F.PH_DFSPH_DENSITY)

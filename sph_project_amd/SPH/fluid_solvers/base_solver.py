@@ -1,0 +1,70 @@
+"""Time-step front end with the surface of the reference's BaseSolver
+(SPH/fluid_solvers/base_solver.py).  The physics (kernels :57-:103, density :522, pressure
+:136, surface tension :210, viscosity :232, boundary :575, integration :643-:666) runs inside
+libsph_hip; this class keeps the constants, the prepare()/step() protocol (:683-:696), late object
+insertion and the host rigid-solver hook."""
+import numpy as np
+
+from .. import _engine_fields as F
+from ..containers import BaseContainer
+from ..rigid_solver import PyBulletSolver
+
+
+class _DtField:
+    def __init__(self, value):
+        self._v = float(np.float32(value))
+
+    def __getitem__(self, key):
+        return self._v
+
+
+class BaseSolver:
+    def __init__(self, container: BaseContainer):
+        self.container = container
+        self.cfg = container.cfg
+        sol = container.solver_constants
+        self.g = sol.g
+        self.g_upper = sol.g_upper
+        self.viscosity_method = sol.viscosity_method
+        self.viscosity = sol.viscosity
+        self.viscosity_b = sol.viscosity_b
+        self.density_0 = sol.density_0
+        self.surface_tension = sol.surface_tension
+        self.dt = _DtField(sol.dt)
+        self.rigid_solver = PyBulletSolver(container, gravity=self.g, dt=self.dt[None])
+        self.engine = container.engine
+        if self.viscosity_method == "implicit":
+            self.cg_tol = 1e-6
+
+    # ---- individually callable reference kernels (tests / notebooks)
+    def compute_rigid_particle_volume(self):
+        self.engine.run_phase(F.PH_RIGID_VOLUME)
+
+    def compute_density(self):
+        self.engine.run_phase(F.PH_DENSITY)
+
+    def compute_non_pressure_acceleration_and_update_velocity(self):
+        self.engine.run_phase(F.PH_NON_PRESSURE)
+
+    # ---- protocol
+    def prepare(self):
+        """base_solver.py:683."""
+        self.container.insert_object()
+        self.rigid_solver.insert_rigid_object()
+        self.engine.prepare()
+
+    def _step(self):
+        self.engine.step(1)
+        self.rigid_solver.step()
+        # late entries (base_container.py:218-221): appended after the step they become due in
+        self.container.insert_object()
+        self.rigid_solver.insert_rigid_object()
+
+    def step(self):
+        """base_solver.py:692."""
+        self._step()
+        self.container.total_time += self.dt[None]
+        self.rigid_solver.total_time += self.dt[None]
+
+    def stats(self):
+        return self.engine.stats()

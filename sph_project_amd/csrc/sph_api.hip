@@ -1,0 +1,682 @@
+// sph_api.hip -- C-ABI of libsph_hip.so (include/sph_hip.h): device state, step orchestration,
+// host<->device transfers, HIP-event profiler.  Host code only; kernels live in sph_kernels.hip.
+#include "../../include/sph_hip.h"
+#include "sph_common.hpp"
+#include "sph_comm.hpp"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_create_error;
+
+struct ProfSlot {
+    bool on = false;
+    int64_t launches = 0;
+    double ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct SphHandle {
+    SphParams prm;
+    State st;
+    const Launch *L = nullptr;
+    std::string err;
+    int device = 0;
+    int n = 0;            // particle_num
+    int n_fluid = 0;      // fluid_particle_num
+    int n_nonfluid = 0;
+    int64_t steps = 0;
+    double total_time = 0.0;
+    bool prepared = false;
+    bool pose_dirty = false;
+    bool rigid_volume_done = false;
+    RigidPose pose_h;
+    SphStats last;
+    ProfSlot prof[SPH_K_COUNT_];
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<void *> allocs;
+    DevScalars *scal_h = nullptr;  // pinned
+    SlabComm comm;
+};
+
+static int fail(SphHandle *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((h), SPH_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <class T> static int dalloc(SphHandle *h, T **p, size_t count) {
+    void *q = nullptr;
+    if (count == 0) count = 1;
+    HIPCHK(h, hipMalloc(&q, count * sizeof(T)));
+    HIPCHK(h, hipMemset(q, 0, count * sizeof(T)));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return SPH_OK;
+}
+
+// host replica of base_solver.py:57 kernel_W, same rounding as oracle/sph_ref.c (host TU is built
+// with -ffp-contract=off)
+static float host_kernel_W(double hd, float r) {
+    float res = 0.0f;
+    float k = (float)(8.0 / M_PI);
+    k /= (float)(hd * hd * hd);
+    float q = r / (float)hd;
+    if (q <= 1.0f) {
+        if (q <= 0.5f) { float q2 = q * q; float q3 = q2 * q; res = k * (6.0f * q3 - 6.0f * q2 + 1.0f); }
+        else res = k * 2.0f * powf(1.0f - q, 3.0f);
+    }
+    return res;
+}
+
+static void fill_consts(SphHandle *h) {
+    const SphParams &p = h->prm;
+    Consts &c = h->st.c;
+    memset(&c, 0, sizeof(c));
+    c.nx = p.grid_num[0]; c.ny = p.grid_num[1]; c.nz = p.grid_num[2];
+    c.G = c.nx * c.ny * c.nz;
+    const double hd = p.support_radius;
+    c.grid_size = (float)hd;
+    c.h = (float)hd;
+    c.h2 = c.h * c.h;
+    float k = (float)(8.0 / M_PI);
+    c.kW = k / (float)(hd * hd * hd);
+    c.kG = 6.0f * k / (float)(hd * hd * hd);
+    c.W0 = host_kernel_W(hd, 0.0f);
+    const float d = (float)(2.0 * p.particle_radius);
+    c.Wd = host_kernel_W(hd, sqrtf(d * d + 0.0f + 0.0f));
+    const double dd = 2.0 * p.particle_radius;
+    c.diameter2 = (float)(dd * dd);
+    c.dt = (float)p.dt;
+    c.inv_dt = 1.0f / c.dt;
+    c.rho0 = (float)p.density_0;
+    c.inv_rho0 = 1.0f / c.rho0;
+    c.g_upper = (float)p.g_upper;
+    c.gx = (float)p.gravity[0]; c.gy = (float)p.gravity[1]; c.gz = (float)p.gravity[2];
+    c.st = (float)p.surface_tension;
+    c.cv = (float)(2 * (3 + 2) * p.viscosity);
+    c.cvb = (float)(2 * (3 + 2) * p.viscosity_b);
+    c.visc_eps = (float)(0.01 * hd * hd);
+    c.pad = (float)p.padding;
+    c.hix = (float)(p.domain_size[0] - p.padding);
+    c.hiy = (float)(p.domain_size[1] - p.padding);
+    c.hiz = (float)(p.domain_size[2] - p.padding);
+    c.thr_kappa = (float)1e-5 * c.dt;
+    c.V0 = (float)p.V0;
+    c.force_global = p.force_global;
+}
+
+static void refresh_counts(SphHandle *h) {
+    h->st.c.n = h->n;
+    h->st.has_emitter = h->prm.g_upper < 9999.0;
+    h->st.c.all_fluid = (h->n_nonfluid == 0 && !h->st.has_emitter) ? 1 : 0;
+    h->st.has_rigid = h->n_nonfluid > 0;
+}
+
+extern "C" const char *sph_last_error(SphHandle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" const char *sph_kernel_name(int k) {
+    static const char *names[SPH_K_COUNT_] = {
+        "hash_count", "scan", "scatter", "density", "non_pressure", "pressure_integrate", "rigid_volume",
+        "dfsph_density_alpha", "dfsph_rho_adv", "dfsph_correct", "reduce", "pcisph_rho_star",
+        "pcisph_pressure_accel", "cg_prepare", "cg_ap", "cg_vector", "misc", "halo"};
+    return (k >= 0 && k < SPH_K_COUNT_) ? names[k] : "?";
+}
+
+extern "C" void sph_destroy(SphHandle *h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->st.stream) hipStreamSynchronize(h->st.stream);
+    slab_comm_destroy(h->comm);
+    for (auto &s : h->prof) for (auto &pr : s.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto e : h->ev_pool) hipEventDestroy(e);
+    for (void *p : h->allocs) hipFree(p);
+    if (h->scal_h) hipHostFree(h->scal_h);
+    if (h->st.stream) hipStreamDestroy(h->st.stream);
+    delete h;
+}
+
+extern "C" int sph_create(const SphParams *params, SphHandle **out) {
+    if (!params || !out) return fail(nullptr, SPH_ERR_INVALID, "sph_create: null argument");
+    *out = nullptr;
+    const SphParams &p = *params;
+    if (p.particle_max_num < 0 || p.grid_num[0] <= 0 || p.grid_num[1] <= 0 || p.grid_num[2] <= 0 ||
+        !(p.support_radius > 0) || !(p.dt > 0))
+        return fail(nullptr, SPH_ERR_INVALID, "sph_create: invalid parameters");
+    if ((double)p.grid_num[0] * p.grid_num[1] * p.grid_num[2] > 2.0e9)
+        return fail(nullptr, SPH_ERR_INVALID, "sph_create: grid too large");
+    if (p.method < 0 || p.method > 2) return fail(nullptr, SPH_ERR_INVALID, "sph_create: unknown method %d", p.method);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, SPH_ERR_NO_DEVICE, "sph_create: no HIP device visible (libsph_hip has no CPU path)");
+    SphHandle *h = new SphHandle();
+    h->prm = p;
+    int dev = p.device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) { delete h; return fail(nullptr, SPH_ERR_NO_DEVICE, "sph_create: device %d not present", dev); }
+    h->device = dev;
+#define CHK_CREATE(call)                                                                   \
+    do {                                                                                   \
+        int rc_ = (call);                                                                  \
+        if (rc_ != SPH_OK) { g_create_error = h->err; sph_destroy(h); return rc_; }        \
+    } while (0)
+#define HIP_CREATE(call)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            fail(nullptr, SPH_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));     \
+            sph_destroy(h);                                                                \
+            return SPH_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+    HIP_CREATE(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIP_CREATE(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(nullptr, SPH_ERR_NO_DEVICE, "sph_create: device %d is %s, this library is built for gfx950 only", dev, prop.gcnArchName);
+        sph_destroy(h);
+        return SPH_ERR_NO_DEVICE;
+    }
+    h->L = p.fast_math ? sph_launch_fast() : sph_launch_strict();
+    State &s = h->st;
+    memset(&s.c, 0, sizeof(s.c));
+    s.stream = nullptr;
+    HIP_CREATE(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    fill_consts(h);
+    const size_t cap = (size_t)p.particle_max_num;
+    s.cap = p.particle_max_num;
+    for (int k = 0; k < 2; ++k) {
+        CHK_CREATE(dalloc(h, &s.posv.b[k], cap)); CHK_CREATE(dalloc(h, &s.velm.b[k], cap));
+        CHK_CREATE(dalloc(h, &s.meta.b[k], cap)); CHK_CREATE(dalloc(h, &s.pid.b[k], cap));
+        CHK_CREATE(dalloc(h, &s.color.b[k], cap)); CHK_CREATE(dalloc(h, &s.rho.b[k], cap));
+    }
+    s.orig.b[0] = s.orig.b[1] = nullptr;
+    const size_t G = (size_t)s.c.G;
+    CHK_CREATE(dalloc(h, &s.cell_count, G + 1)); CHK_CREATE(dalloc(h, &s.cell_start, G + 1));
+    CHK_CREATE(dalloc(h, &s.cellid, cap)); CHK_CREATE(dalloc(h, &s.rank, cap)); CHK_CREATE(dalloc(h, &s.tmp_idx, cap));
+    s.scan_blocks = (int)((G + 2047) / 2048);
+    CHK_CREATE(dalloc(h, &s.scan_partial, (size_t)s.scan_blocks + 1));
+    CHK_CREATE(dalloc(h, &s.rho_raw, cap)); CHK_CREATE(dalloc(h, &s.prs, cap)); CHK_CREATE(dalloc(h, &s.ptm, cap));
+    CHK_CREATE(dalloc(h, &s.acc, cap));
+    s.alpha = s.kappa = s.kappa_v = s.rho_star = s.rho_deriv = nullptr; s.kr = nullptr;
+    s.pacc = s.pvel = s.ppos = nullptr;
+    s.cg_p = s.cg_Ap = s.cg_x = s.cg_b = s.cg_r = s.cg_v0 = nullptr; s.cg_dinv = nullptr;
+    if (p.method == SPH_METHOD_DFSPH) {
+        CHK_CREATE(dalloc(h, &s.alpha, cap)); CHK_CREATE(dalloc(h, &s.kappa, cap)); CHK_CREATE(dalloc(h, &s.kappa_v, cap));
+        CHK_CREATE(dalloc(h, &s.rho_star, cap)); CHK_CREATE(dalloc(h, &s.rho_deriv, cap)); CHK_CREATE(dalloc(h, &s.kr, cap));
+    }
+    if (p.method == SPH_METHOD_PCISPH) {
+        CHK_CREATE(dalloc(h, &s.pacc, cap)); CHK_CREATE(dalloc(h, &s.pvel, cap)); CHK_CREATE(dalloc(h, &s.ppos, cap));
+        CHK_CREATE(dalloc(h, &s.rho_star, cap));
+    }
+    if (p.viscosity_implicit) {
+        CHK_CREATE(dalloc(h, &s.cg_p, cap)); CHK_CREATE(dalloc(h, &s.cg_Ap, cap)); CHK_CREATE(dalloc(h, &s.cg_x, cap));
+        CHK_CREATE(dalloc(h, &s.cg_b, cap)); CHK_CREATE(dalloc(h, &s.cg_r, cap)); CHK_CREATE(dalloc(h, &s.cg_v0, cap));
+        CHK_CREATE(dalloc(h, &s.cg_dinv, cap * 9));
+    }
+    s.red_blocks = (int)((cap + 255) / 256) + 1;
+    CHK_CREATE(dalloc(h, &s.red_partial, (size_t)s.red_blocks * 4));
+    CHK_CREATE(dalloc(h, &s.scal, 1)); CHK_CREATE(dalloc(h, &s.pose, 1));
+    HIP_CREATE(hipHostMalloc((void **)&h->scal_h, sizeof(DevScalars), hipHostMallocDefault));
+    memset(h->scal_h, 0, sizeof(DevScalars));
+    memset(&h->pose_h, 0, sizeof(h->pose_h));
+    for (int o = 0; o < SPH_NOBJ; ++o) { h->pose_h.rot[o][0] = h->pose_h.rot[o][4] = h->pose_h.rot[o][8] = 1.0f; }
+    memset(&h->last, 0, sizeof(h->last));
+    s.has_dynamic_rigid = 0; s.has_rigid = 0;
+    s.visc_rho_raw = (p.method == SPH_METHOD_WCSPH);
+    s.skip_viscosity = p.viscosity_implicit ? 1 : 0;
+    refresh_counts(h);
+    *out = h;
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------- scene upload
+extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const float *pos, const float *vel,
+                                    const float *density, const float *pressure, const int32_t *material,
+                                    const int32_t *is_dynamic, const int32_t *color) {
+    if (!h) return SPH_ERR_INVALID;
+    if (n < 0 || object_id < -1 || object_id >= SPH_MAX_OBJECTS) return fail(h, SPH_ERR_INVALID, "append: bad object id / count");
+    if (n == 0) return SPH_OK;
+    if (!pos || !vel || !density || !material || !is_dynamic) return fail(h, SPH_ERR_INVALID, "append: null array");
+    if (h->n + n > h->st.cap) return fail(h, SPH_ERR_CAPACITY, "append: %d + %d exceeds particle_max_num %d", h->n, n, h->st.cap);
+    HIPCHK(h, hipSetDevice(h->device));
+    State &s = h->st;
+    const float V0 = (float)h->prm.V0;
+    std::vector<float4> hp(n), hv(n), ho;
+    std::vector<int> hm(n), hid(n);
+    std::vector<unsigned> hc(n);
+    std::vector<float> hr(n), hpr(n);
+    bool any_dyn_rigid = false;
+    int nfl = 0;
+    for (int k = 0; k < n; ++k) {
+        // base_container.py:404 add_particle
+        hp[k] = make_float4(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2], V0);
+        hv[k] = make_float4(vel[3 * k], vel[3 * k + 1], vel[3 * k + 2], V0 * density[k]);
+        hm[k] = META_PACK(object_id, material[k], is_dynamic[k] ? 1 : 0);
+        hid[k] = h->n + k;
+        unsigned r = color ? (unsigned)(color[3 * k] & 0xff) : 0, g = color ? (unsigned)(color[3 * k + 1] & 0xff) : 0,
+                 b = color ? (unsigned)(color[3 * k + 2] & 0xff) : 0;
+        hc[k] = r | (g << 8) | (b << 16);
+        hr[k] = density[k];
+        hpr[k] = pressure ? pressure[k] : 0.0f;
+        if (material[k] == SPH_MAT_FLUID) nfl++;
+        if (material[k] == SPH_MAT_RIGID && is_dynamic[k]) any_dyn_rigid = true;
+    }
+    if (any_dyn_rigid && !s.orig.b[0]) {
+        int rc = dalloc(h, &s.orig.b[0], (size_t)s.cap); if (rc) return rc;
+        rc = dalloc(h, &s.orig.b[1], (size_t)s.cap); if (rc) return rc;
+        // existing particles: original position = current position
+        HIPCHK(h, hipMemcpyAsync(s.orig.cur(), s.posv.cur(), sizeof(float4) * (size_t)h->n, hipMemcpyDeviceToDevice, s.stream));
+        s.has_dynamic_rigid = 1;
+    }
+    HIPCHK(h, hipStreamSynchronize(s.stream));
+    const size_t off = (size_t)h->n;
+    HIPCHK(h, hipMemcpy(s.posv.cur() + off, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(s.velm.cur() + off, hv.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(s.meta.cur() + off, hm.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(s.pid.cur() + off, hid.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(s.color.cur() + off, hc.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(s.rho.cur() + off, hr.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(s.prs + off, hpr.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    if (s.orig.cur()) HIPCHK(h, hipMemcpy(s.orig.cur() + off, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    h->n += n;
+    h->n_fluid += nfl;
+    h->n_nonfluid += n - nfl;
+    h->rigid_volume_done = false;
+    refresh_counts(h);
+    return SPH_OK;
+}
+
+static int upload_pose(SphHandle *h) {
+    HIPCHK(h, hipMemcpyAsync(h->st.pose, &h->pose_h, sizeof(RigidPose), hipMemcpyHostToDevice, h->st.stream));
+    HIPCHK(h, hipStreamSynchronize(h->st.stream));  // pose_h may change right after
+    return SPH_OK;
+}
+
+extern "C" int sph_set_object(SphHandle *h, int object_id, int material, int is_dynamic) {
+    if (!h || object_id < 0 || object_id >= SPH_MAX_OBJECTS) return fail(h, SPH_ERR_INVALID, "set_object: bad object id");
+    HIPCHK(h, hipSetDevice(h->device));
+    h->pose_h.material[object_id] = material;
+    h->pose_h.is_dynamic[object_id] = is_dynamic ? 1 : 0;
+    return upload_pose(h);
+}
+
+extern "C" int sph_set_rigid_pose(SphHandle *h, int o, const float *com, const float *rot9, const float *vel,
+                                  const float *angvel, const float *com0) {
+    if (!h || o < 0 || o >= SPH_MAX_OBJECTS || !com || !rot9 || !vel || !angvel) return fail(h, SPH_ERR_INVALID, "set_rigid_pose: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int a = 0; a < 3; ++a) { h->pose_h.com[o][a] = com[a]; h->pose_h.vel[o][a] = vel[a]; h->pose_h.angvel[o][a] = angvel[a]; if (com0) h->pose_h.com0[o][a] = com0[a]; }
+    for (int a = 0; a < 9; ++a) h->pose_h.rot[o][a] = rot9[a];
+    h->pose_dirty = true;
+    return upload_pose(h);
+}
+
+extern "C" int sph_get_rigid_wrench(SphHandle *h, float *force, float *torque, int reset) {
+    if (!h || !force || !torque) return fail(h, SPH_ERR_INVALID, "get_rigid_wrench: null");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->scal_h, h->st.scal, sizeof(DevScalars), hipMemcpyDeviceToHost, h->st.stream));
+    HIPCHK(h, hipStreamSynchronize(h->st.stream));
+    memcpy(force, h->scal_h->wrench, sizeof(float) * SPH_NOBJ * 3);
+    memcpy(torque, h->scal_h->wrench + SPH_NOBJ * 3, sizeof(float) * SPH_NOBJ * 3);
+    if (reset)
+        HIPCHK(h, hipMemsetAsync((char *)h->st.scal + offsetof(DevScalars, wrench), 0, sizeof(float) * 2 * SPH_NOBJ * 3, h->st.stream));
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------- profiling
+static hipEvent_t get_event(SphHandle *h) {
+    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+static void prof_resolve(SphHandle *h) {
+    hipStreamSynchronize(h->st.stream);
+    for (auto &s : h->prof) {
+        for (auto &pr : s.pending) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { s.ms += ms; s.launches++; }
+            h->ev_pool.push_back(pr.first); h->ev_pool.push_back(pr.second);
+        }
+        s.pending.clear();
+    }
+}
+
+struct ProfScope {
+    SphHandle *h; int k; hipEvent_t e1 = nullptr;
+    ProfScope(SphHandle *h_, int k_) : h(h_), k(k_) {
+        if (h->prof[k].on) {
+            if (h->prof[k].pending.size() > 8192) prof_resolve(h);
+            hipEvent_t e0 = get_event(h); e1 = get_event(h);
+            hipEventRecord(e0, h->st.stream);
+            h->prof[k].pending.push_back({e0, e1});
+        }
+    }
+    ~ProfScope() { if (e1) hipEventRecord(e1, h->st.stream); }
+};
+
+extern "C" int sph_profile_enable(SphHandle *h, int kernel_id, int on) {
+    if (!h || kernel_id >= SPH_K_COUNT_) return SPH_ERR_INVALID;
+    for (int k = 0; k < SPH_K_COUNT_; ++k) if (kernel_id < 0 || kernel_id == k) h->prof[k].on = on != 0;
+    return SPH_OK;
+}
+extern "C" int sph_profile_reset(SphHandle *h) {
+    if (!h) return SPH_ERR_INVALID;
+    hipSetDevice(h->device);
+    prof_resolve(h);
+    for (auto &s : h->prof) { s.launches = 0; s.ms = 0.0; }
+    return SPH_OK;
+}
+extern "C" int sph_profile_read(SphHandle *h, int kernel_id, int64_t *launches, double *total_ms) {
+    if (!h || kernel_id < 0 || kernel_id >= SPH_K_COUNT_) return SPH_ERR_INVALID;
+    hipSetDevice(h->device);
+    prof_resolve(h);
+    if (launches) *launches = h->prof[kernel_id].launches;
+    if (total_ms) *total_ms = h->prof[kernel_id].ms;
+    return SPH_OK;
+}
+
+extern "C" int sph_device_info(SphHandle *h, char *name256, int *cu_count, int64_t *hbm_bytes) {
+    if (!h) return SPH_ERR_INVALID;
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+    if (name256) { snprintf(name256, 256, "%s (%s)", prop.name, prop.gcnArchName); }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------- phases
+static int check_async(SphHandle *h) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, SPH_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return SPH_OK;
+}
+
+// base_container.py:544 prepare_neighborhood_search
+static void ph_neighbor_search(SphHandle *h) {
+    State &s = h->st;
+    { ProfScope p(h, SPH_K_HASH_COUNT); h->L->hash_count(s); }
+    { ProfScope p(h, SPH_K_SCAN); h->L->scan(s); }
+    { ProfScope p(h, SPH_K_SCATTER); if (h->prm.deterministic) h->L->scatter_stable(s); else h->L->scatter(s); }
+}
+
+static void ph_rigid_volume(SphHandle *h) {
+    // base_solver.py:106.  Static boundaries: the sum only involves same-object (static) particles,
+    // so the value computed once after the first sort is bit-identical to recomputing every step
+    // (:696); with dynamic bodies it is recomputed after every sort.
+    if (!h->st.has_rigid) return;
+    if (h->rigid_volume_done && !h->st.has_dynamic_rigid) return;
+    ProfScope p(h, SPH_K_RIGID_VOLUME);
+    h->L->rigid_volume(h->st);
+    h->rigid_volume_done = true;
+}
+
+static void step_begin(SphHandle *h) {
+    State &s = h->st;
+    hipMemsetAsync(s.scal, 0, offsetof(DevScalars, wrench), s.stream);  // pairs + fallback
+    if (h->pose_dirty) { ProfScope p(h, SPH_K_MISC); h->L->renew_rigid(s); h->pose_dirty = false; }
+}
+
+#include "sph_steps.hpp"
+
+static int read_scalars(SphHandle *h) {
+    HIPCHK(h, hipMemcpyAsync(h->scal_h, h->st.scal, sizeof(DevScalars), hipMemcpyDeviceToHost, h->st.stream));
+    HIPCHK(h, hipStreamSynchronize(h->st.stream));
+    h->last.pair_interactions = (int64_t)h->scal_h->pairs;
+    h->last.lds_fallback_blocks = (int64_t)h->scal_h->fallback;
+    return SPH_OK;
+}
+
+extern "C" int sph_prepare(SphHandle *h) {
+    if (!h) return SPH_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    refresh_counts(h);
+    State &s = h->st;
+    int rc = upload_pose(h); if (rc) return rc;
+    // base_solver.py:683 prepare: prepare_emitter, renew_rigid_particle_state, neighbour search,
+    // compute_rigid_particle_volume (+ DFSPH.py:321 / PCISPH.py:188)
+    { ProfScope p(h, SPH_K_MISC); h->L->prepare_emitter(s); h->L->renew_rigid(s); }
+    h->pose_dirty = false;
+    ph_neighbor_search(h);
+    h->rigid_volume_done = false;
+    ph_rigid_volume(h);
+    rc = method_prepare(h); if (rc) return rc;
+    rc = check_async(h); if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(s.stream));
+    h->prepared = true;
+    return SPH_OK;
+}
+
+static int step_once(SphHandle *h, bool allow_readback) {
+    step_begin(h);
+    int rc;
+    switch (h->prm.method) {
+        case SPH_METHOD_WCSPH: rc = wcsph_step(h); break;
+        case SPH_METHOD_DFSPH: rc = dfsph_step(h, allow_readback); break;
+        default: rc = pcisph_step(h, allow_readback); break;
+    }
+    if (rc) return rc;
+    h->total_time += (double)h->st.c.dt;  // base_solver.py:694
+    h->steps++;
+    return SPH_OK;
+}
+
+extern "C" int sph_step_async(SphHandle *h, int nsteps) {
+    if (!h || nsteps < 0) return SPH_ERR_INVALID;
+    if (!h->prepared) return fail(h, SPH_ERR_INVALID, "sph_step before sph_prepare");
+    if (h->prm.method != SPH_METHOD_WCSPH && h->prm.fixed_iterations <= 0)
+        return fail(h, SPH_ERR_UNSUPPORTED, "sph_step_async needs wcsph or fixed_iterations > 0");
+    HIPCHK(h, hipSetDevice(h->device));
+    refresh_counts(h);
+    for (int k = 0; k < nsteps; ++k) { int rc = step_once(h, false); if (rc) return rc; }
+    return check_async(h);
+}
+
+extern "C" int sph_synchronize(SphHandle *h) {
+    if (!h) return SPH_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->st.stream));
+    return SPH_OK;
+}
+
+extern "C" int sph_step(SphHandle *h, int nsteps) {
+    if (!h || nsteps < 0) return SPH_ERR_INVALID;
+    if (!h->prepared) return fail(h, SPH_ERR_INVALID, "sph_step before sph_prepare");
+    HIPCHK(h, hipSetDevice(h->device));
+    refresh_counts(h);
+    for (int k = 0; k < nsteps; ++k) { int rc = step_once(h, true); if (rc) return rc; }
+    int rc = check_async(h); if (rc) return rc;
+    return read_scalars(h);
+}
+
+extern "C" int sph_run_phase(SphHandle *h, int phase) {
+    if (!h) return SPH_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    refresh_counts(h);
+    State &s = h->st;
+    switch (phase) {
+        case SPH_PH_NEIGHBOR_SEARCH: ph_neighbor_search(h); break;
+        case SPH_PH_RIGID_VOLUME: h->rigid_volume_done = false; ph_rigid_volume(h); break;
+        case SPH_PH_DENSITY: { ProfScope p(h, SPH_K_DENSITY); h->L->density(s, h->prm.method == SPH_METHOD_WCSPH); } break;
+        case SPH_PH_NON_PRESSURE: { int rc = run_non_pressure(h); if (rc) return rc; } break;
+        case SPH_PH_PRESSURE_INTEGRATE: { ProfScope p(h, SPH_K_PRESSURE_INTEGRATE); h->L->pressure_integrate(s); } break;
+        default: { int rc = method_run_phase(h, phase); if (rc) return rc; }
+    }
+    int rc = check_async(h); if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(s.stream));
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------- state access
+extern "C" int sph_particle_num(SphHandle *h) { return h ? h->n : SPH_ERR_INVALID; }
+extern "C" int sph_fluid_particle_num(SphHandle *h) { return h ? h->n_fluid : SPH_ERR_INVALID; }
+
+extern "C" int sph_get_stats(SphHandle *h, SphStats *out) {
+    if (!h || !out) return SPH_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = read_scalars(h); if (rc) return rc;
+    h->last.steps = h->steps;
+    h->last.particle_num = h->n;
+    h->last.fluid_particle_num = h->n_fluid;
+    h->last.total_time = h->total_time;
+    *out = h->last;
+    return SPH_OK;
+}
+
+static const float4 *vec_field(SphHandle *h, int field) {
+    State &s = h->st;
+    switch (field) {
+        case SPH_F_POSITION: case SPH_F_REST_VOLUME: return s.posv.cur();
+        case SPH_F_VELOCITY: case SPH_F_MASS: return s.velm.cur();
+        case SPH_F_ACCELERATION: return s.acc;
+        case SPH_F_PRESSURE_ACCEL: return s.pacc;
+        case SPH_F_PREDICTED_VEL: return s.pvel;
+        case SPH_F_PREDICTED_POS: return s.ppos;
+        case SPH_F_CG_X: return s.cg_x;
+        case SPH_F_ORIG_POSITION: return s.orig.cur() ? s.orig.cur() : s.posv.cur();
+        default: return nullptr;
+    }
+}
+static const float *scalar_field(SphHandle *h, int field) {
+    State &s = h->st;
+    switch (field) {
+        case SPH_F_DENSITY: return s.rho.cur();
+        case SPH_F_PRESSURE: return s.prs;
+        case SPH_F_DFSPH_ALPHA: return s.alpha;
+        case SPH_F_DFSPH_KAPPA: return s.kappa;
+        case SPH_F_DFSPH_KAPPA_V: return s.kappa_v;
+        case SPH_F_DENSITY_STAR: return s.rho_star;
+        case SPH_F_DENSITY_DERIV: return s.rho_deriv;
+        default: return nullptr;
+    }
+}
+
+extern "C" int sph_download(SphHandle *h, int field, void *dst, size_t bytes) {
+    if (!h || !dst) return SPH_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    State &s = h->st;
+    const size_t n = (size_t)h->n;
+    HIPCHK(h, hipStreamSynchronize(s.stream));
+    const bool is_vec3 = field == SPH_F_POSITION || field == SPH_F_VELOCITY || field == SPH_F_ACCELERATION ||
+                         field == SPH_F_PRESSURE_ACCEL || field == SPH_F_PREDICTED_VEL || field == SPH_F_PREDICTED_POS ||
+                         field == SPH_F_CG_X || field == SPH_F_ORIG_POSITION;
+    if (is_vec3) {
+        const float4 *src = vec_field(h, field);
+        if (!src) return fail(h, SPH_ERR_UNSUPPORTED, "download: field %d not allocated for this method", field);
+        if (bytes != n * 12) return fail(h, SPH_ERR_INVALID, "download: field %d needs %zu bytes, got %zu", field, n * 12, bytes);
+        std::vector<float4> tmp(n);
+        HIPCHK(h, hipMemcpy(tmp.data(), src, n * sizeof(float4), hipMemcpyDeviceToHost));
+        float *d = (float *)dst;
+        for (size_t i = 0; i < n; ++i) { d[3 * i] = tmp[i].x; d[3 * i + 1] = tmp[i].y; d[3 * i + 2] = tmp[i].z; }
+        return SPH_OK;
+    }
+    if (field == SPH_F_REST_VOLUME || field == SPH_F_MASS) {
+        if (bytes != n * 4) return fail(h, SPH_ERR_INVALID, "download: size mismatch");
+        std::vector<float4> tmp(n);
+        HIPCHK(h, hipMemcpy(tmp.data(), vec_field(h, field), n * sizeof(float4), hipMemcpyDeviceToHost));
+        float *d = (float *)dst;
+        for (size_t i = 0; i < n; ++i) d[i] = tmp[i].w;
+        return SPH_OK;
+    }
+    if (const float *src = scalar_field(h, field)) {
+        if (bytes != n * 4) return fail(h, SPH_ERR_INVALID, "download: size mismatch");
+        HIPCHK(h, hipMemcpy(dst, src, n * 4, hipMemcpyDeviceToHost));
+        return SPH_OK;
+    }
+    if (field == SPH_F_MATERIAL || field == SPH_F_OBJECT_ID || field == SPH_F_IS_DYNAMIC) {
+        if (bytes != n * 4) return fail(h, SPH_ERR_INVALID, "download: size mismatch");
+        std::vector<int> tmp(n);
+        HIPCHK(h, hipMemcpy(tmp.data(), s.meta.cur(), n * 4, hipMemcpyDeviceToHost));
+        int32_t *d = (int32_t *)dst;
+        for (size_t i = 0; i < n; ++i)
+            d[i] = field == SPH_F_MATERIAL ? META_MAT(tmp[i]) : field == SPH_F_OBJECT_ID ? META_OBJ(tmp[i]) : META_DYN(tmp[i]);
+        return SPH_OK;
+    }
+    if (field == SPH_F_PARTICLE_ID) {
+        if (bytes != n * 4) return fail(h, SPH_ERR_INVALID, "download: size mismatch");
+        HIPCHK(h, hipMemcpy(dst, s.pid.cur(), n * 4, hipMemcpyDeviceToHost));
+        return SPH_OK;
+    }
+    if (field == SPH_F_COLOR) {
+        if (bytes != n * 12) return fail(h, SPH_ERR_INVALID, "download: size mismatch");
+        std::vector<unsigned> tmp(n);
+        HIPCHK(h, hipMemcpy(tmp.data(), s.color.cur(), n * 4, hipMemcpyDeviceToHost));
+        int32_t *d = (int32_t *)dst;
+        for (size_t i = 0; i < n; ++i) { d[3 * i] = tmp[i] & 0xff; d[3 * i + 1] = (tmp[i] >> 8) & 0xff; d[3 * i + 2] = (tmp[i] >> 16) & 0xff; }
+        return SPH_OK;
+    }
+    if (field == SPH_F_GRID_ID) {
+        if (bytes != n * 4) return fail(h, SPH_ERR_INVALID, "download: size mismatch");
+        std::vector<float4> tmp(n);
+        HIPCHK(h, hipMemcpy(tmp.data(), s.posv.cur(), n * sizeof(float4), hipMemcpyDeviceToHost));
+        int32_t *d = (int32_t *)dst;
+        const Consts &c = s.c;
+        auto cc = [](float x, float gs, int nn) { int v = (int)(x / gs); v = v < 0 ? 0 : v; return v > nn - 1 ? nn - 1 : v; };
+        for (size_t i = 0; i < n; ++i)
+            d[i] = (cc(tmp[i].x, c.grid_size, c.nx) * c.ny + cc(tmp[i].y, c.grid_size, c.ny)) * c.nz + cc(tmp[i].z, c.grid_size, c.nz);
+        return SPH_OK;
+    }
+    return fail(h, SPH_ERR_INVALID, "download: unknown field %d", field);
+}
+
+extern "C" int sph_upload(SphHandle *h, int field, const void *src, size_t bytes) {
+    if (!h || !src) return SPH_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    State &s = h->st;
+    const size_t n = (size_t)h->n;
+    HIPCHK(h, hipStreamSynchronize(s.stream));
+    float4 *vdst = nullptr;
+    bool w_only = false;
+    switch (field) {
+        case SPH_F_POSITION: vdst = s.posv.cur(); break;
+        case SPH_F_VELOCITY: vdst = s.velm.cur(); break;
+        case SPH_F_REST_VOLUME: vdst = s.posv.cur(); w_only = true; break;
+        case SPH_F_MASS: vdst = s.velm.cur(); w_only = true; break;
+        case SPH_F_CG_X: vdst = s.cg_x; break;
+        default: break;
+    }
+    if (vdst) {
+        const size_t need = w_only ? n * 4 : n * 12;
+        if (bytes != need) return fail(h, SPH_ERR_INVALID, "upload: field %d needs %zu bytes", field, need);
+        std::vector<float4> tmp(n);
+        HIPCHK(h, hipMemcpy(tmp.data(), vdst, n * sizeof(float4), hipMemcpyDeviceToHost));
+        const float *f = (const float *)src;
+        for (size_t i = 0; i < n; ++i) {
+            if (w_only) tmp[i].w = f[i];
+            else { tmp[i].x = f[3 * i]; tmp[i].y = f[3 * i + 1]; tmp[i].z = f[3 * i + 2]; }
+        }
+        HIPCHK(h, hipMemcpy(vdst, tmp.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        return SPH_OK;
+    }
+    float *fdst = nullptr;
+    switch (field) {
+        case SPH_F_DENSITY: fdst = s.rho.cur(); break;
+        case SPH_F_PRESSURE: fdst = s.prs; break;
+        default: break;
+    }
+    if (fdst) {
+        if (bytes != n * 4) return fail(h, SPH_ERR_INVALID, "upload: size mismatch");
+        HIPCHK(h, hipMemcpy(fdst, src, n * 4, hipMemcpyHostToDevice));
+        return SPH_OK;
+    }
+    return fail(h, SPH_ERR_UNSUPPORTED, "upload: field %d is read-only", field);
+}
+
+#include "sph_comm_api.hpp"

@@ -1,0 +1,136 @@
+// sph_common.hpp -- host/device shared declarations of libsph_hip (gfx950 only).
+//
+// Data layout in HBM (all arrays have capacity particle_max_num, index = slot in the current
+// cell-sorted order; cells linearised z-fastest as in the reference, lin = (cx*ny + cy)*nz + cz, so the
+// 27 neighbour cells of a particle are 9 contiguous particle runs):
+//   posv  float4  (x, y, z, rest volume V)       double-buffered (sort scatter / integration)
+//   velm  float4  (vx, vy, vz, mass m)           double-buffered (sort scatter / v* update)
+//   meta  int32   object_id+1 | material<<8 | is_dynamic<<10      } moved by the sort together with
+//   pid   int32   insertion index (persistent particle id)        } color (r|g<<8|b<<16), rho and
+//   rho   float   particle_densities                              } the rigid original positions
+// Per-step scratch that the reference does not reorder either (base_container.py:506 list):
+//   rho_raw, prs, ptm (= p / rho^2), acc, DFSPH alpha/kappa/..., PCISPH predicted state, CG vectors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SPH_NOBJ 20
+
+// meta packing
+#define META_OBJ(m) (((m) & 0xff) - 1)
+#define META_MAT(m) (((m) >> 8) & 0x3)
+#define META_DYN(m) (((m) >> 10) & 0x1)
+#define META_PACK(obj, mat, dyn) ((((obj) + 1) & 0xff) | (((mat) & 0x3) << 8) | (((dyn) & 1) << 10))
+#define META_SET_MAT(m, mat) (((m) & ~(0x3 << 8)) | (((mat) & 0x3) << 8))
+
+struct Consts {
+    int nx, ny, nz, G;
+    float grid_size;        // f32(dh): cell size
+    float h, h2;            // support radius, squared
+    float kW, kG;           // cubic spline constants (base_solver.py:57, :81)
+    float W0, Wd;           // kernel_W(0), kernel_W(particle diameter)
+    float diameter2;
+    float dt, inv_dt, rho0, inv_rho0, g_upper;
+    float gx, gy, gz;
+    float st;               // surface tension coefficient (0.01)
+    float cv, cvb, visc_eps;// 2*(dim+2)*viscosity, ..*viscosity_b, 0.01*dh^2
+    float pad, hix, hiy, hiz; // domain clamp
+    float thr_kappa;        // DFSPH m_eps * dt
+    float V0;
+    float pcisph_k;
+    int   n;                // particle_num
+    int   all_fluid;        // no rigid / emitter particles in the container
+    int   force_global;
+};
+
+// Device-side scalar block (zeroed / read back by the host)
+struct DevScalars {
+    unsigned long long pairs;        // accepted pairs of the running step
+    unsigned long long fallback;     // LDS-overflow workgroups
+    float wrench[2 * SPH_NOBJ * 3];  // rigid_body_forces, rigid_body_torques
+    float red[8];                    // reduction results (errors, CG dots)
+    int   flags[4];
+};
+
+struct RigidPose {  // rigid_body_* fields of the container (base_container.py:156-164)
+    float com[SPH_NOBJ][3], com0[SPH_NOBJ][3], rot[SPH_NOBJ][9], vel[SPH_NOBJ][3], angvel[SPH_NOBJ][3];
+    int   is_dynamic[SPH_NOBJ], material[SPH_NOBJ];
+};
+
+template <class T> struct DBuf {
+    T *b[2] = {nullptr, nullptr};
+    int c = 0;
+    T *cur() const { return b[c]; }
+    T *alt() const { return b[1 - c]; }
+    void flip() { c = 1 - c; }
+};
+
+// Everything a launcher needs.  Owned by SphHandle.
+struct State {
+    Consts c;
+    hipStream_t stream;
+    int cap;             // particle_max_num
+    // sorted, carried state
+    DBuf<float4> posv, velm, orig;
+    DBuf<int> meta, pid;
+    DBuf<unsigned> color;
+    DBuf<float> rho;
+    // grid
+    int *cell_count;     // G+1
+    int *cell_start;     // G+1 (exclusive scan, cell_start[G] = n)
+    int *cellid, *rank;  // per particle (pre-sort)
+    int *tmp_idx;        // stable-sort scratch (source index per sorted slot)
+    int *scan_partial;   // block sums
+    int scan_blocks;
+    // per-step scratch
+    float *rho_raw, *prs, *ptm;
+    float4 *acc;
+    // DFSPH
+    float *alpha, *kappa, *kappa_v, *rho_star, *rho_deriv;
+    float2 *kr;          // (kappa, rho) staging pair for the correction pass
+    // PCISPH
+    float4 *pacc, *pvel, *ppos;
+    // CG (implicit viscosity)
+    float4 *cg_p, *cg_Ap, *cg_x, *cg_b, *cg_r, *cg_v0;
+    float *cg_dinv;      // 9 floats per particle
+    // reductions
+    float *red_partial;  // per-block partial sums
+    int red_blocks;
+    DevScalars *scal;    // device
+    RigidPose *pose;     // device copy
+    int has_dynamic_rigid;
+    int has_rigid;
+    int has_emitter;     // gravitationUpper set (base_solver.py:18-23)
+    int visc_rho_raw;    // viscosity reads rho_raw (WCSPH: density before the EOS clamp)
+    int skip_viscosity;  // implicit viscosity: explicit term not part of the fused pass
+};
+
+// Function table implemented twice (strict / fast math), see sph_kernels.hip.
+struct Launch {
+    void (*hash_count)(State &);
+    void (*scan)(State &);
+    void (*scatter)(State &);
+    void (*scatter_stable)(State &);
+    void (*density)(State &, int eos);
+    void (*non_pressure)(State &);
+    void (*pressure_integrate)(State &);
+    void (*rigid_volume)(State &);
+    void (*renew_rigid)(State &);
+    void (*prepare_emitter)(State &);
+    // DFSPH
+    void (*dfsph_density_alpha)(State &);
+    void (*dfsph_rho_adv)(State &, int mode);   // 0: density derivative (+kappa_v), 1: density star (+kappa)
+    void (*dfsph_correct)(State &, int mode);   // 0: divergence step, 1: density step
+    void (*advect_boundary)(State &);           // x += dt v, emitter, boundary (DFSPH position update)
+    void (*reduce_sum)(State &, int slot, float scale);
+    // PCISPH
+    void (*pcisph_init)(State &);
+    void (*pcisph_rho_star)(State &);
+    void (*pcisph_pressure_accel)(State &);
+    void (*compute_pcisph_k)(State &);
+    // generic
+    void (*unpack3)(State &, const float4 *src, float *dst, int n);
+};
+
+const Launch *sph_launch_strict();
+const Launch *sph_launch_fast();

@@ -1,0 +1,202 @@
+// sph_kernels.hip -- kernel instantiations + launchers.  Compiled twice:
+//   -DSPH_FAST=0 -ffp-contract=off   -> sph_launch_strict()  (IEEE div/sqrt, no FMA contraction)
+//   -DSPH_FAST=1 -ffp-contract=fast  -> sph_launch_fast()    (v_rcp_f32 / v_sqrt_f32, FMA)
+#include "sph_common.hpp"
+
+#if SPH_FAST
+#define SPH_LAUNCH_FN sph_launch_fast
+#define SPH_NS sph_fast_ns
+#else
+#define SPH_LAUNCH_FN sph_launch_strict
+#define SPH_NS sph_strict_ns
+#endif
+
+// every kernel lives in a per-build namespace so the strict and fast objects can be linked together
+namespace SPH_NS {
+#include "sph_passes.hpp"
+#include "sph_solvers.hpp"
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+void l_hash_count(State &s) {
+    const int n = s.c.n;
+    hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 1), s.stream);
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_hash_count, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.cellid,
+                       s.rank, s.cell_count);
+}
+
+void l_scan(State &s) {
+    const int G = s.c.G;
+    const int nb = cdiv(G, SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_TPB), 0, s.stream, s.scan_partial, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial,
+                       s.cell_start, s.c.n);
+}
+
+void l_scatter_impl(State &s, bool stable) {
+    const int n = s.c.n;
+    if (n == 0) return;
+    SortArrays a;
+    a.posv_in = s.posv.cur(); a.posv_out = s.posv.alt();
+    a.velm_in = s.velm.cur(); a.velm_out = s.velm.alt();
+    a.meta_in = s.meta.cur(); a.meta_out = s.meta.alt();
+    a.pid_in = s.pid.cur(); a.pid_out = s.pid.alt();
+    a.color_in = s.color.cur(); a.color_out = s.color.alt();
+    a.rho_in = s.rho.cur(); a.rho_out = s.rho.alt();
+    a.orig_in = s.orig.cur(); a.orig_out = s.orig.alt();
+    int *tmp_idx = (int *)s.red_partial;  // reused scratch (sized >= n ints by the allocator)
+    if (stable) {
+        hipLaunchKernelGGL(k_scatter_index, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
+                           s.cell_start, s.tmp_idx);
+        hipLaunchKernelGGL(k_scatter<true>, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
+                           s.cell_start, s.tmp_idx, a);
+    } else {
+        hipLaunchKernelGGL(k_scatter<false>, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
+                           s.cell_start, s.tmp_idx, a);
+    }
+    (void)tmp_idx;
+    s.posv.flip(); s.velm.flip(); s.meta.flip(); s.pid.flip(); s.color.flip(); s.rho.flip();
+    if (s.orig.cur()) s.orig.flip();
+}
+void l_scatter(State &s) { l_scatter_impl(s, false); }
+void l_scatter_stable(State &s) { l_scatter_impl(s, true); }
+
+template <class P> void launch_pass(State &s, const P &p) {
+    const int n = s.c.n;
+    if (n == 0) return;
+    const int nb = cdiv(n, P::BLOCK);
+    hipLaunchKernelGGL((k_nbr_pass<P>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb);
+}
+
+void l_density(State &s, int eos) {
+    if (s.c.all_fluid) {
+        if (eos) { DensityPass<true, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p); }
+        else { DensityPass<true, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p); }
+    } else {
+        if (eos) { DensityPass<false, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p); }
+        else { DensityPass<false, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p); }
+    }
+}
+
+// rho_src: WCSPH viscosity reads the unclamped density (rho_raw); DFSPH/PCISPH read particle_densities.
+void l_non_pressure(State &s) {
+    const float *rho_src = s.visc_rho_raw ? s.rho_raw : s.rho.cur();
+    if (s.c.all_fluid) {
+        NonPressurePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), rho_src, s.velm.alt(), s.scal, s.pose, s.c.rho0, s.skip_viscosity};
+        launch_pass(s, p);
+    } else {
+        NonPressurePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), rho_src, s.velm.alt(), s.scal, s.pose, s.c.rho0, s.skip_viscosity};
+        launch_pass(s, p);
+    }
+    s.velm.flip();
+}
+
+// base_solver.py:660-666 emitter branch of update_fluid_position, run after the position pass so
+// that no neighbour sees a material flip mid-kernel.
+__global__ void __launch_bounds__(256)
+k_emitter_advance(const Consts c, float4 *posv, const float4 *velm, int *meta, const RigidPose *pose) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c.n) return;
+    const int m = meta[i];
+    if (META_MAT(m) == 1) return;
+    float4 p = posv[i];
+    if (p.y > c.g_upper) {
+        const int obj = META_OBJ(m);
+        if (obj >= 0 && pose->material[obj] == 1) {
+            const float4 v = velm[i];
+            p.x += c.dt * v.x; p.y += c.dt * v.y; p.z += c.dt * v.z;
+            posv[i] = p;
+            if (p.y <= c.g_upper) meta[i] = META_SET_MAT(m, 1);
+        }
+    }
+}
+
+void l_pressure_integrate(State &s) {
+    if (s.c.all_fluid) {
+        PressurePass<true> p{s.posv.cur(), s.meta.cur(), s.ptm, s.prs, s.rho.cur(), s.velm.cur(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, 1};
+        launch_pass(s, p);
+    } else {
+        PressurePass<false> p{s.posv.cur(), s.meta.cur(), s.ptm, s.prs, s.rho.cur(), s.velm.cur(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, 1};
+        launch_pass(s, p);
+    }
+    s.posv.flip();
+    if (s.has_emitter && s.c.n > 0)
+        hipLaunchKernelGGL(k_emitter_advance, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(),
+                           s.velm.cur(), s.meta.cur(), s.pose);
+}
+
+void l_rigid_volume(State &s) {
+    RigidVolumePass p{s.posv.cur(), s.velm.cur(), s.meta.cur()};
+    launch_pass(s, p);
+}
+
+// base_solver.py:616 _renew_rigid_particle_state
+__global__ void __launch_bounds__(256)
+k_renew_rigid(const Consts c, float4 *posv, float4 *velm, const float4 *orig, const int *meta, const RigidPose *pose) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c.n) return;
+    const int m = meta[i];
+    if (META_MAT(m) != 2 || !META_DYN(m)) return;
+    const int o = META_OBJ(m);
+    if (o < 0 || !pose->is_dynamic[o]) return;
+    const float4 q0 = orig[i];
+    const float qx = q0.x - pose->com0[o][0], qy = q0.y - pose->com0[o][1], qz = q0.z - pose->com0[o][2];
+    const float *R = pose->rot[o];
+    const float px = R[0] * qx + R[1] * qy + R[2] * qz;
+    const float py = R[3] * qx + R[4] * qy + R[5] * qz;
+    const float pz = R[6] * qx + R[7] * qy + R[8] * qz;
+    float4 p = posv[i], v = velm[i];
+    p.x = pose->com[o][0] + px; p.y = pose->com[o][1] + py; p.z = pose->com[o][2] + pz;
+    const float wx = pose->angvel[o][0], wy = pose->angvel[o][1], wz = pose->angvel[o][2];
+    v.x = pose->vel[o][0] + (wy * pz - wz * py);
+    v.y = pose->vel[o][1] + (wz * px - wx * pz);
+    v.z = pose->vel[o][2] + (wx * py - wy * px);
+    posv[i] = p; velm[i] = v;
+}
+
+void l_renew_rigid(State &s) {
+    if (!s.has_dynamic_rigid || s.c.n == 0 || !s.orig.cur()) return;
+    hipLaunchKernelGGL(k_renew_rigid, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(),
+                       s.velm.cur(), s.orig.cur(), s.meta.cur(), s.pose);
+}
+
+// base_solver.py:670 prepare_emitter
+__global__ void __launch_bounds__(256) k_prepare_emitter(const Consts c, const float4 *posv, int *meta) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c.n) return;
+    const int m = meta[i];
+    if (META_MAT(m) == 1 && posv[i].y > c.g_upper) meta[i] = META_SET_MAT(m, 2);
+}
+
+void l_prepare_emitter(State &s) {
+    if (!s.has_emitter || s.c.n == 0) return;
+    hipLaunchKernelGGL(k_prepare_emitter, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(),
+                       s.meta.cur());
+}
+
+#include "sph_solvers_impl.hpp"
+}  // namespace SPH_NS
+
+using namespace SPH_NS;
+
+const Launch *SPH_LAUNCH_FN() {
+    static Launch L;
+    static bool init = false;
+    if (!init) {
+        L.hash_count = l_hash_count;
+        L.scan = l_scan;
+        L.scatter = l_scatter;
+        L.scatter_stable = l_scatter_stable;
+        L.density = l_density;
+        L.non_pressure = l_non_pressure;
+        L.pressure_integrate = l_pressure_integrate;
+        L.rigid_volume = l_rigid_volume;
+        L.renew_rigid = l_renew_rigid;
+        L.prepare_emitter = l_prepare_emitter;
+        register_solver_launchers(L);
+        init = true;
+    }
+    return &L;
+}

@@ -1,0 +1,264 @@
+// sph_passes.hpp -- pair-physics functors plugged into k_nbr_pass (see sph_device.hpp).
+// Each functor cites the reference kernel(s) it fuses.  AF = "all fluid" specialisation
+// (no rigid / emitter particles in the container): material tests compile away.
+#pragma once
+#include "sph_device.hpp"
+
+__device__ __forceinline__ void add_wrench(DevScalars *scal, int obj, float fx, float fy, float fz,
+                                           float tx, float ty, float tz) {
+    float *f = scal->wrench + obj * 3;
+    float *t = scal->wrench + SPH_NOBJ * 3 + obj * 3;
+    atomicAdd(f + 0, fx); atomicAdd(f + 1, fy); atomicAdd(f + 2, fz);
+    atomicAdd(t + 0, tx); atomicAdd(t + 1, ty); atomicAdd(t + 2, tz);
+}
+
+// ---------------------------------------------------------------------------------------
+// base_solver.py:522 compute_density (+task :535); with EOS also WCSPH.py:17 compute_pressure.
+// Algorithmic HBM bytes / particle: R posv 16 -> W rho 4 (+ rho_raw 4, prs 4, ptm 4 with EOS).
+template <bool AF, bool EOS>
+struct DensityPass {
+    static constexpr int BLOCK = 256, CAP = 4096;
+    static constexpr bool HAS_B = false, COUNT_PAIRS = true;
+    typedef int BT;
+    struct Own { float sum; };
+    const float4 *posv; const int *meta;
+    float *rho_raw, *rho, *prs, *ptm;
+
+    __device__ float4 loadA(int j) const { return posv[j]; }
+    __device__ BT loadB(int) const { return 0; }
+    __device__ float4 stage(const Consts &, int j, BT &) const { return posv[j]; }
+    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
+        o.sum = 0.0f;
+        return AF || META_MAT(meta[i]) == 1;
+    }
+    __device__ void pair(const Consts &c, Own &o, float, float, float, float r2, const float4 &a, const BT &,
+                         int) const {
+        o.sum += a.w * kernW(c, fsqrt(r2));
+    }
+    __device__ void finish(const Consts &c, int i, const float4 &pi, Own &o) const {
+        float den = pi.w * c.W0;
+        den += o.sum;
+        den *= c.rho0;
+        if (EOS) {
+            rho_raw[i] = den;
+            float rc = fmaxf(den, c.rho0);
+            rho[i] = rc;
+            float pr = 50000.0f * (powf(rc / c.rho0, 7.0f) - 1.0f);
+            prs[i] = pr;
+            ptm[i] = pr / (rc * rc);
+        } else {
+            rho[i] = den;
+        }
+    }
+    __device__ void passive(const Consts &, int, const float4 &) const {}
+};
+
+// ---------------------------------------------------------------------------------------
+// base_solver.py:203 gravity + :210 surface tension (+task :218) + :232 explicit viscosity
+// (+task :240) + :643 update_fluid_velocity, fused: v* = v + dt (g + a_st + a_visc / rho0).
+// Bytes / particle: R posv 16 + velm 16 + rho_raw 4 -> W velm 16.
+template <bool AF>
+struct NonPressurePass {
+    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr bool HAS_B = true, COUNT_PAIRS = true;
+    typedef float4 BT;
+    struct Own { float vx, vy, vz, m, rho, st_m, sx, sy, sz, ax, ay, az; };
+    const float4 *posv, *velm; const int *meta; const float *rho_raw;
+    float4 *vel_out; DevScalars *scal; const RigidPose *pose; float rho0;
+    int skip_viscosity;  // implicit viscosity handles the viscous term elsewhere
+
+    __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
+    __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
+    __device__ float4 stage_impl(int j, BT &bj) const {
+        const float4 p = posv[j];
+        const float4 v = velm[j];
+        float aw, bw;
+        if (AF) { aw = v.w; bw = rho_raw[j]; }
+        else {
+            const int m = meta[j];
+            const bool fl = META_MAT(m) == 1;
+            aw = fl ? v.w : rho0 * p.w;
+            bw = fl ? rho_raw[j] : (META_DYN(m) ? -2.0f : -1.0f);
+        }
+        bj = make_float4(v.x, v.y, v.z, bw);
+        return make_float4(p.x, p.y, p.z, aw);
+    }
+    __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
+    __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
+        if (!AF && META_MAT(meta[i]) != 1) return false;
+        const float4 v = velm[i];
+        o.vx = v.x; o.vy = v.y; o.vz = v.z; o.m = v.w;
+        o.rho = rho_raw[i];
+        o.st_m = fdiv(c.st, v.w);
+        o.sx = o.sy = o.sz = 0.0f;
+        o.ax = o.ay = o.az = 0.0f;
+        return true;
+    }
+    __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
+                         const BT &bj, int j) const {
+        const float rn = fsqrt(r2);
+        float gx, gy, gz;
+        if (AF || bj.w >= 0.0f) {
+            // surface tension
+            const float cst = o.st_m * a.w;
+            const float w = r2 > c.diameter2 ? kernW(c, rn) : c.Wd;
+            o.sx -= (cst * dx) * w; o.sy -= (cst * dy) * w; o.sz -= (cst * dz) * w;
+            if (skip_viscosity) return;
+            kernGrad(c, dx, dy, dz, rn, gx, gy, gz);
+            const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
+            const float m_ij = (o.m + a.w) * 0.5f;
+            const float cc = fdiv(fdiv(c.cv * m_ij, bj.w), rn * rn + c.visc_eps) * v_xy;
+            o.ax += cc * gx; o.ay += cc * gy; o.az += cc * gz;
+        } else {
+            if (skip_viscosity) return;
+            kernGrad(c, dx, dy, dz, rn, gx, gy, gz);
+            const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
+            const float cc = fdiv(fdiv(c.cvb * a.w, o.rho), rn * rn + c.visc_eps) * v_xy;
+            const float acx = cc * gx, acy = cc * gy, acz = cc * gz;
+            o.ax += acx; o.ay += acy; o.az += acz;
+            if (bj.w == -2.0f) {  // dynamic rigid neighbour: base_solver.py:272-278
+                const int obj = META_OBJ(meta[j]);
+                const float fx = fdiv(-acx * o.m, c.rho0), fy = fdiv(-acy * o.m, c.rho0), fz = fdiv(-acz * o.m, c.rho0);
+                const float rx = a.x - pose->com[obj][0], ry = a.y - pose->com[obj][1], rz = a.z - pose->com[obj][2];
+                add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
+            }
+        }
+    }
+    __device__ void finish(const Consts &c, int i, const float4 &, Own &o) const {
+        float ax = c.gx, ay = c.gy, az = c.gz;
+        ax += o.sx; ay += o.sy; az += o.sz;
+        ax += fdiv(o.ax, c.rho0); ay += fdiv(o.ay, c.rho0); az += fdiv(o.az, c.rho0);
+        vel_out[i] = make_float4(o.vx + c.dt * ax, o.vy + c.dt * ay, o.vz + c.dt * az, o.m);
+    }
+    __device__ void passive(const Consts &, int i, const float4 &) const { vel_out[i] = velm[i]; }
+};
+
+// base_solver.py:575 enforce_domain_boundary_3D + :545 simulate_collisions
+__device__ __forceinline__ void enforce_boundary(const Consts &c, float &x, float &y, float &z, float &vx,
+                                                 float &vy, float &vz) {
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    const float ox = x, oy = y, oz = z;
+    if (ox > c.hix) { nx += 1.0f; x = c.hix; }
+    if (ox <= c.pad) { nx += -1.0f; x = c.pad; }
+    if (oy > c.hiy) { ny += 1.0f; y = c.hiy; }
+    if (oy <= c.pad) { ny += -1.0f; y = c.pad; }
+    if (oz > c.hiz) { nz += 1.0f; z = c.hiz; }
+    if (oz <= c.pad) { nz += -1.0f; z = c.pad; }
+    const float len = __builtin_sqrtf(nx * nx + ny * ny + nz * nz);
+    if (len > 1e-6f) {
+        const float ux = nx / len, uy = ny / len, uz = nz / len;
+        const float s = (1.0f + 0.5f) * (vx * ux + vy * uy + vz * uz);
+        vx -= s * ux; vy -= s * uy; vz -= s * uz;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// base_solver.py:136 compute_pressure_acceleration (+task :147) + :643 update_fluid_velocity
+// + :652 update_fluid_position + :575 enforce_domain_boundary_3D, fused.
+// Bytes / particle: R posv 16 + velm 16 + ptm 4 -> W acc 16 + posv 16 + velm 16.
+template <bool AF>
+struct PressurePass {
+    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr bool HAS_B = true, COUNT_PAIRS = true;
+    typedef float BT;
+    struct Own { float pt, p, rho2, ax, ay, az, x, y, z, m0; };
+    const float4 *posv; const int *meta; const float *ptm, *prs, *rho;
+    float4 *velm;      // in: v* (+m), out: v
+    float4 *acc, *posv_out; DevScalars *scal; const RigidPose *pose; float rho0;
+    int integrate;     // 1: WCSPH/PCISPH tail (v, x update + boundary); 0: acceleration only
+
+    __device__ float4 stage_impl(int j, BT &bj) const {
+        const float4 p = posv[j];
+        const float m = velm[j].w;
+        if (AF) { bj = ptm[j]; return make_float4(p.x, p.y, p.z, m); }
+        const int mt = meta[j];
+        const bool fl = META_MAT(mt) == 1;
+        bj = fl ? ptm[j] : (META_DYN(mt) ? -2.0f : -1.0f);
+        return make_float4(p.x, p.y, p.z, fl ? m : rho0 * p.w);
+    }
+    __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
+    __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
+    __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
+    __device__ bool begin(const Consts &, int i, const float4 &pi, Own &o) const {
+        if (!AF) { const int m = meta[i]; if (META_MAT(m) != 1 || !META_DYN(m)) return false; }
+        o.x = pi.x; o.y = pi.y; o.z = pi.z; o.m0 = rho0 * pi.w;
+        o.pt = ptm[i]; o.p = prs[i];
+        const float r = rho[i];
+        o.rho2 = r * r;
+        o.ax = o.ay = o.az = 0.0f;
+        return true;
+    }
+    __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
+                         const BT &bj, int j) const {
+        const float rn = fsqrt(r2);
+        float gx, gy, gz;
+        kernGrad(c, dx, dy, dz, rn, gx, gy, gz);
+        if (AF || bj >= 0.0f) {
+            const float cc = -a.w * (o.pt + bj);
+            o.ax += cc * gx; o.ay += cc * gy; o.az += cc * gz;
+        } else {
+            const float cc = fdiv(-a.w * o.p, o.rho2);
+            o.ax += cc * gx; o.ay += cc * gy; o.az += cc * gz;
+            if (bj == -2.0f) {  // base_solver.py:174-187 (torque about pos_i, sic)
+                const int obj = META_OBJ(meta[j]);
+                const float cf = fdiv(a.w * o.p, o.rho2);
+                const float fx = (cf * gx) * o.m0, fy = (cf * gy) * o.m0, fz = (cf * gz) * o.m0;
+                const float rx = o.x - pose->com[obj][0], ry = o.y - pose->com[obj][1], rz = o.z - pose->com[obj][2];
+                add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
+            }
+        }
+    }
+    __device__ void finish(const Consts &c, int i, const float4 &pi, Own &o) const {
+        acc[i] = make_float4(o.ax, o.ay, o.az, 0.0f);
+        if (!integrate) return;
+        const float4 v = velm[i];
+        float vx = v.x + c.dt * o.ax, vy = v.y + c.dt * o.ay, vz = v.z + c.dt * o.az;
+        float x = pi.x + c.dt * vx, y = pi.y + c.dt * vy, z = pi.z + c.dt * vz;
+        enforce_boundary(c, x, y, z, vx, vy, vz);
+        posv_out[i] = make_float4(x, y, z, pi.w);
+        velm[i] = make_float4(vx, vy, vz, v.w);
+    }
+    __device__ void passive(const Consts &, int i, const float4 &pi) const {
+        acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (integrate) posv_out[i] = pi;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// base_solver.py:106 compute_rigid_particle_volume (+task :117).  i rigid, j same object.
+struct RigidVolumePass {
+    static constexpr int BLOCK = 256, CAP = 4096;
+    static constexpr bool HAS_B = false, COUNT_PAIRS = false;
+    typedef int BT;
+    struct Own { float sum; int obj; };
+    float4 *posv; float4 *velm; const int *meta;
+
+    __device__ float4 stage_impl(int j) const {
+        const float4 p = posv[j];
+        const int m = meta[j];
+        const int key = META_MAT(m) == 2 ? META_OBJ(m) : -100;
+        return make_float4(p.x, p.y, p.z, __int_as_float(key));
+    }
+    __device__ float4 loadA(int j) const { return stage_impl(j); }
+    __device__ BT loadB(int) const { return 0; }
+    __device__ float4 stage(const Consts &, int j, BT &) const { return stage_impl(j); }
+    __device__ bool begin(const Consts &c, int i, const float4 &pi, Own &o) const {
+        const int m = meta[i];
+        if (META_MAT(m) != 2 || !(pi.y <= c.g_upper)) return false;
+        o.obj = META_OBJ(m);
+        o.sum = c.W0;
+        return true;
+    }
+    __device__ void pair(const Consts &c, Own &o, float, float, float, float r2, const float4 &a, const BT &,
+                         int) const {
+        if (__float_as_int(a.w) == o.obj) o.sum += kernW(c, fsqrt(r2));
+    }
+    __device__ void finish(const Consts &c, int i, const float4 &pi, Own &o) const {
+        const float V = 1.0f / o.sum;
+        posv[i] = make_float4(pi.x, pi.y, pi.z, V);  // only .w changes; readers use xyz + meta
+        float4 v = velm[i];
+        v.w = c.rho0 * V;
+        velm[i] = v;
+    }
+    __device__ void passive(const Consts &, int, const float4 &) const {}
+};

@@ -1,0 +1,119 @@
+"""Shared scene builders for the tests: one JSON-like scene dict feeds both the product containers
+(HIP) and the oracle (CPU), so the comparison reads like `reference scene in -> state out`."""
+import copy
+
+import numpy as np
+
+from oracle import ref as oracle_ref
+from sph_project_amd import scene
+from sph_project_amd.SPH.utils import SimConfig
+
+
+def dam_break_scene(method="wcsph", domain_end=(1.0, 1.0, 1.0), start=(0.0, 0.0, 0.0), end=(0.4, 0.4, 0.4),
+                    translation=(0.1, 0.1, 0.1), velocity=(0.0, 0.0, 0.0), dt=4e-4, viscosity=10.0,
+                    add_domain_box=False, viscosity_method="standard", radius=0.01, **extra):
+    """SURVEY 8(d) config C1 by default: 20^3 = 8000-particle cube, WCSPH."""
+    cfg = {
+        "Configuration": {
+            "domainStart": [0.0, 0.0, 0.0], "domainEnd": list(domain_end), "addDomainBox": add_domain_box,
+            "particleRadius": radius, "density0": 1000, "simulationMethod": method,
+            "viscosityMethod": viscosity_method, "gravitation": [0.0, -9.81, 0.0], "timeStepSize": dt,
+            "viscosity": viscosity,
+        },
+        "FluidBlocks": [{
+            "objectId": 0, "start": list(start), "end": list(end), "translation": list(translation),
+            "scale": [1, 1, 1], "velocity": list(velocity), "density": 1000.0, "color": [50, 100, 200],
+            "entryTime": -1.0,
+        }],
+    }
+    cfg["Configuration"].update(extra)
+    return cfg
+
+
+def perturb(pos, amplitude, seed=0):
+    rng = np.random.default_rng(seed)
+    return (pos + rng.uniform(-amplitude, amplitude, pos.shape)).astype(np.float32)
+
+
+def scene_particles(cfg_dict):
+    """Host lattice of every object in the scene, in the reference's insertion order
+    (domain box first: base_container.py:192, then FluidBlocks: :215)."""
+    cfg = SimConfig(config=copy.deepcopy(cfg_dict))
+    geo = scene.derive_geometry(cfg)
+    batches = []
+    blocks = cfg.get_fluid_blocks()
+    n_obj = len(blocks)
+    if geo.add_domain_box:
+        pos = scene.box_lattice(geo.domain_box_start, geo.domain_box_size, geo.domain_box_thickness, geo.particle_spacing)
+        n = pos.shape[0]
+        batches.append(dict(object_id=n_obj, pos=pos, vel=np.zeros((n, 3), np.float32),
+                            density=np.full(n, 1000.0, np.float32), material=np.full(n, 2, np.int32),
+                            is_dynamic=np.zeros(n, np.int32)))
+    for blk in blocks:
+        off = np.array(blk["translation"])
+        s, e = np.array(blk["start"]) + off, np.array(blk["end"]) + off
+        pos = scene.cube_lattice(s, (e - s) * np.array(blk["scale"]), geo.particle_spacing)
+        n = pos.shape[0]
+        batches.append(dict(object_id=blk["objectId"], pos=pos, vel=np.tile(np.asarray(blk["velocity"], np.float32), (n, 1)),
+                            density=np.full(n, blk["density"], np.float32), material=np.full(n, 1, np.int32),
+                            is_dynamic=np.ones(n, np.int32)))
+    return cfg, geo, batches
+
+
+def build_oracle(cfg_dict, jitter=0.0, seed=0, fixed_iterations=0):
+    cfg, geo, batches = scene_particles(cfg_dict)
+    sol = scene.derive_solver_constants(cfg)
+    total = sum(b["pos"].shape[0] for b in batches)
+    pd = scene.params_dict(geo, sol, cfg.get_cfg("simulationMethod"), total, fixed_iterations=fixed_iterations)
+    sim = oracle_ref.RefSim(pd)
+    next_id = 0
+    for b in batches:
+        n = b["pos"].shape[0]
+        pos = perturb(b["pos"], jitter, seed) if (jitter > 0 and b["material"][0] == 1) else b["pos"]
+        color = np.zeros((n, 3), np.int32)
+        color[:, 0] = np.arange(next_id, next_id + n)
+        next_id += n
+        sim.set_object(b["object_id"], int(b["material"][0]), 0)
+        sim.add_particles(b["object_id"], pos, b["vel"], b["density"], np.zeros(n, np.float32), b["material"],
+                          b["is_dynamic"], color)
+    return sim
+
+
+def oracle_ids(sim):
+    return sim.field("particle_colors")[:, 0].copy()
+
+
+def build_product(cfg_dict, jitter=0.0, seed=0, **engine_opts):
+    """Product containers driven exactly like run_simulation.py drives the reference."""
+    from sph_project_amd.SPH import containers, fluid_solvers
+    cfg = SimConfig(config=copy.deepcopy(cfg_dict))
+    method = cfg.get_cfg("simulationMethod")
+    ccls = {"wcsph": containers.WCSPHContainer, "dfsph": containers.DFSPHContainer, "pcisph": containers.PCISPHContainer}[method]
+    scls = {"wcsph": fluid_solvers.WCSPHSolver, "dfsph": fluid_solvers.DFSPHSolver, "pcisph": fluid_solvers.PCISPHSolver}[method]
+    container = ccls(cfg, GGUI=False, **engine_opts)
+    solver = scls(container)
+    if jitter > 0:
+        # same perturbed fluid lattice as build_oracle: insert, then overwrite positions before prepare()
+        container.insert_object()
+        solver.rigid_solver.insert_rigid_object()
+        from sph_project_amd import _lib as L
+        pos = container.engine.download(L.F_POSITION)
+        mat = container.engine.download(L.F_MATERIAL)
+        fl = mat == 1
+        pos[fl] = perturb(pos[fl], jitter, seed)
+        container.engine.upload(L.F_POSITION, pos)
+    return container, solver
+
+
+def by_id(ids, arr):
+    """Reorder `arr` (current sorted order) into particle-id order."""
+    out = np.empty_like(arr)
+    out[ids] = arr
+    return out
+
+
+def drift(x, x_ref, dh):
+    """SURVEY 8(c) parity metric: |x - x_ref| / max(|x_ref|, dh), per particle."""
+    num = np.linalg.norm(x.astype(np.float64) - x_ref.astype(np.float64), axis=1)
+    den = np.maximum(np.linalg.norm(x_ref.astype(np.float64), axis=1), dh)
+    return num / den
