@@ -99,7 +99,14 @@ class BaseContainer:
         self.fluid_blocks = self.cfg.get_fluid_blocks()
         for blk in self.fluid_blocks:
             blk["particleNum"] = scene.cube_particle_num(blk["start"], blk["end"], self.particle_spacing)
-            fluid_n += blk["particleNum"]
+            # The reference budgets with the untranslated start/end (base_container.py:89) but inserts the
+            # translated, scaled cube (:241); np.arange end-point rounding can make the two differ, in which
+            # case the reference overruns its fields.  Budget for whichever is larger.
+            off = np.array(blk["translation"])
+            lo, hi = np.array(blk["start"]) + off, np.array(blk["end"]) + off
+            actual = int(np.prod([len(np.arange(lo[i], lo[i] + ((hi - lo) * np.array(blk["scale"]))[i],
+                                                self.particle_spacing)) for i in range(self.dim)]))
+            fluid_n += max(blk["particleNum"], actual)
         self.rigid_bodies = self.cfg.get_rigid_bodies()
         for body in self.rigid_bodies:
             pts = self.load_rigid_body(body, pitch=self.particle_spacing)

@@ -365,7 +365,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         }
         if (P::COUNT_PAIRS) {
             float fp = wave_sum((float)npairs);  // <= 64 * few hundred: exact in f32
-            if ((tid & 63) == 0 && fp > 0.0f) atomicAdd(&scal->pairs, (unsigned long long)fp);
+            if ((tid & 63) == 0 && fp > 0.0f) atomicAdd(&scal->pairs, (unsigned long long)fp * P::PAIR_WEIGHT);
         }
     }
     if (valid) {

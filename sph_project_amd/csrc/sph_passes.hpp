@@ -19,6 +19,7 @@ template <bool AF, bool EOS>
 struct DensityPass {
     static constexpr int BLOCK = 256, CAP = 4096;
     static constexpr bool HAS_B = false, COUNT_PAIRS = true;
+    static constexpr int PAIR_WEIGHT = 1;
     typedef int BT;
     struct Own { float sum; };
     const float4 *posv; const int *meta;
@@ -61,6 +62,7 @@ template <bool AF>
 struct NonPressurePass {
     static constexpr int BLOCK = 128, CAP = 2048;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
+    static constexpr int PAIR_WEIGHT = 2;  // surface tension (:210) + viscosity (:232) = two reference passes
     typedef float4 BT;
     struct Own { float vx, vy, vz, m, rho, st_m, sx, sy, sz, ax, ay, az; };
     const float4 *posv, *velm; const int *meta; const float *rho_raw;
@@ -160,6 +162,7 @@ template <bool AF>
 struct PressurePass {
     static constexpr int BLOCK = 128, CAP = 2048;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
+    static constexpr int PAIR_WEIGHT = 1;
     typedef float BT;
     struct Own { float pt, p, rho2, ax, ay, az, x, y, z, m0; };
     const float4 *posv; const int *meta; const float *ptm, *prs, *rho;
@@ -229,6 +232,7 @@ struct PressurePass {
 struct RigidVolumePass {
     static constexpr int BLOCK = 256, CAP = 4096;
     static constexpr bool HAS_B = false, COUNT_PAIRS = false;
+    static constexpr int PAIR_WEIGHT = 0;
     typedef int BT;
     struct Own { float sum; int obj; };
     float4 *posv; float4 *velm; const int *meta;

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the oracle's OpenMP loops are tiny in the tests; hundreds of host threads only add overhead
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
