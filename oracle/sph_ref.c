@@ -164,6 +164,7 @@ int sphref_add_particles(SphRef *s, int object_id, int n, const float *pos, cons
 }
 
 void sphref_set_object(SphRef *s, int object_id, int material, int is_dynamic) {
+    if (object_id < 0 || object_id >= SPHREF_MAX_OBJECTS) return;
     s->object_materials[object_id] = material;
     s->rigid_body_is_dynamic[object_id] = is_dynamic;
 }

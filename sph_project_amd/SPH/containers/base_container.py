@@ -167,7 +167,9 @@ class BaseContainer:
 
         if self.add_domain_box:  # base_container.py:192-209
             box_id = self._object_num - 1
-            self.add_box(object_id=box_id, lower_corner=self.domain_box_start, cube_size=self.domain_box_size,
+            # BaseSolver.prepare() starts with init_object_id() (base_solver.py:680-681), which resets the ids
+            # of everything added before it -- i.e. exactly this box -- to -1.  Insert it that way.
+            self.add_box(object_id=-1, lower_corner=self.domain_box_start, cube_size=self.domain_box_size,
                          thickness=self.domain_box_thickness, material=self.material_rigid, is_dynamic=False,
                          space=self.particle_spacing, color=(127, 127, 127))
             self.object_visibility[box_id] = 0

@@ -214,7 +214,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     CHK_CREATE(dalloc(h, &s.rho_raw, cap)); CHK_CREATE(dalloc(h, &s.prs, cap)); CHK_CREATE(dalloc(h, &s.ptm, cap));
     CHK_CREATE(dalloc(h, &s.acc, cap));
     s.alpha = s.kappa = s.kappa_v = s.rho_star = s.rho_deriv = nullptr; s.kr = nullptr;
-    s.pacc = s.pvel = s.ppos = nullptr;
+    s.pacc = s.pvel = s.ppos = s.acc_np = nullptr; s.np_acc_out = nullptr;
     s.cg_p = s.cg_Ap = s.cg_x = s.cg_b = s.cg_r = s.cg_v0 = nullptr; s.cg_dinv = nullptr;
     if (p.method == SPH_METHOD_DFSPH) {
         CHK_CREATE(dalloc(h, &s.alpha, cap)); CHK_CREATE(dalloc(h, &s.kappa, cap)); CHK_CREATE(dalloc(h, &s.kappa_v, cap));
@@ -222,7 +222,8 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     }
     if (p.method == SPH_METHOD_PCISPH) {
         CHK_CREATE(dalloc(h, &s.pacc, cap)); CHK_CREATE(dalloc(h, &s.pvel, cap)); CHK_CREATE(dalloc(h, &s.ppos, cap));
-        CHK_CREATE(dalloc(h, &s.rho_star, cap));
+        CHK_CREATE(dalloc(h, &s.rho_star, cap)); CHK_CREATE(dalloc(h, &s.acc_np, cap));
+        s.np_acc_out = s.acc_np;
     }
     if (p.viscosity_implicit) {
         CHK_CREATE(dalloc(h, &s.cg_p, cap)); CHK_CREATE(dalloc(h, &s.cg_Ap, cap)); CHK_CREATE(dalloc(h, &s.cg_x, cap));

@@ -89,7 +89,7 @@ struct State {
     float *alpha, *kappa, *kappa_v, *rho_star, *rho_deriv;
     float2 *kr;          // (kappa, rho) staging pair for the correction pass
     // PCISPH
-    float4 *pacc, *pvel, *ppos;
+    float4 *pacc, *pvel, *ppos, *acc_np;
     // CG (implicit viscosity)
     float4 *cg_p, *cg_Ap, *cg_x, *cg_b, *cg_r, *cg_v0;
     float *cg_dinv;      // 9 floats per particle
@@ -103,6 +103,7 @@ struct State {
     int has_emitter;     // gravitationUpper set (base_solver.py:18-23)
     int visc_rho_raw;    // viscosity reads rho_raw (WCSPH: density before the EOS clamp)
     int skip_viscosity;  // implicit viscosity: explicit term not part of the fused pass
+    float4 *np_acc_out;  // non-pressure acceleration sink (PCISPH), else null
 };
 
 // Function table implemented twice (strict / fast math), see sph_kernels.hip.
@@ -122,14 +123,10 @@ struct Launch {
     void (*dfsph_rho_adv)(State &, int mode);   // 0: density derivative (+kappa_v), 1: density star (+kappa)
     void (*dfsph_correct)(State &, int mode);   // 0: divergence step, 1: density step
     void (*advect_boundary)(State &);           // x += dt v, emitter, boundary (DFSPH position update)
-    void (*reduce_sum)(State &, int slot, float scale);
     // PCISPH
     void (*pcisph_init)(State &);
     void (*pcisph_rho_star)(State &);
     void (*pcisph_pressure_accel)(State &);
-    void (*compute_pcisph_k)(State &);
-    // generic
-    void (*unpack3)(State &, const float4 *src, float *dst, int n);
 };
 
 const Launch *sph_launch_strict();

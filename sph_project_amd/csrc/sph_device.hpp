@@ -368,8 +368,34 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             if ((tid & 63) == 0 && fp > 0.0f) atomicAdd(&scal->pairs, (unsigned long long)fp * P::PAIR_WEIGHT);
         }
     }
+    float red = 0.0f;
     if (valid) {
-        if (active) p.finish(c, i, pi, own);
+        if (active) red = p.finish(c, i, pi, own);
         else p.passive(c, i, pi);
     }
+    if constexpr (P::HAS_REDUCE) {
+        // deterministic per-workgroup partial sum (fixed tree), finished by k_reduce_partials
+        __shared__ float s_red[BLOCK / 64];
+        const float w = wave_sum(red);
+        if ((tid & 63) == 0) s_red[tid >> 6] = w;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < BLOCK / 64; ++k) t += s_red[k];
+            p.red_out[b] = t;
+        }
+    }
+}
+
+// sums partial[0..n) in a fixed order into scal->red[slot]
+__global__ void __launch_bounds__(256)
+k_reduce_partials(const float *__restrict__ partial, int n, DevScalars *__restrict__ scal, int slot) {
+    __shared__ float s_w[4];
+    float t = 0.0f;
+    for (int k = threadIdx.x; k < n; k += 256) t += partial[k];
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) scal->red[slot] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }

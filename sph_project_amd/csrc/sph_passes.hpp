@@ -20,6 +20,7 @@ struct DensityPass {
     static constexpr int BLOCK = 256, CAP = 4096;
     static constexpr bool HAS_B = false, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 1;
+    static constexpr bool HAS_REDUCE = false;
     typedef int BT;
     struct Own { float sum; };
     const float4 *posv; const int *meta;
@@ -36,7 +37,7 @@ struct DensityPass {
                          int) const {
         o.sum += a.w * kernW(c, fsqrt(r2));
     }
-    __device__ void finish(const Consts &c, int i, const float4 &pi, Own &o) const {
+    __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
         float den = pi.w * c.W0;
         den += o.sum;
         den *= c.rho0;
@@ -50,6 +51,7 @@ struct DensityPass {
         } else {
             rho[i] = den;
         }
+        return 0.0f;
     }
     __device__ void passive(const Consts &, int, const float4 &) const {}
 };
@@ -63,11 +65,13 @@ struct NonPressurePass {
     static constexpr int BLOCK = 128, CAP = 2048;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 2;  // surface tension (:210) + viscosity (:232) = two reference passes
+    static constexpr bool HAS_REDUCE = false;
     typedef float4 BT;
     struct Own { float vx, vy, vz, m, rho, st_m, sx, sy, sz, ax, ay, az; };
     const float4 *posv, *velm; const int *meta; const float *rho_raw;
     float4 *vel_out; DevScalars *scal; const RigidPose *pose; float rho0;
-    int skip_viscosity;  // implicit viscosity handles the viscous term elsewhere
+    int skip_viscosity;
+    float4 *acc_out;     // PCISPH keeps the non-pressure acceleration (PCISPH.py:22); null otherwise  // implicit viscosity handles the viscous term elsewhere
 
     __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
@@ -126,11 +130,13 @@ struct NonPressurePass {
             }
         }
     }
-    __device__ void finish(const Consts &c, int i, const float4 &, Own &o) const {
+    __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {
         float ax = c.gx, ay = c.gy, az = c.gz;
         ax += o.sx; ay += o.sy; az += o.sz;
         ax += fdiv(o.ax, c.rho0); ay += fdiv(o.ay, c.rho0); az += fdiv(o.az, c.rho0);
+        if (acc_out) acc_out[i] = make_float4(ax, ay, az, 0.0f);
         vel_out[i] = make_float4(o.vx + c.dt * ax, o.vy + c.dt * ay, o.vz + c.dt * az, o.m);
+        return 0.0f;
     }
     __device__ void passive(const Consts &, int i, const float4 &) const { vel_out[i] = velm[i]; }
 };
@@ -163,6 +169,7 @@ struct PressurePass {
     static constexpr int BLOCK = 128, CAP = 2048;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 1;
+    static constexpr bool HAS_REDUCE = false;
     typedef float BT;
     struct Own { float pt, p, rho2, ax, ay, az, x, y, z, m0; };
     const float4 *posv; const int *meta; const float *ptm, *prs, *rho;
@@ -211,15 +218,16 @@ struct PressurePass {
             }
         }
     }
-    __device__ void finish(const Consts &c, int i, const float4 &pi, Own &o) const {
+    __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
         acc[i] = make_float4(o.ax, o.ay, o.az, 0.0f);
-        if (!integrate) return;
+        if (!integrate) return 0.0f;
         const float4 v = velm[i];
         float vx = v.x + c.dt * o.ax, vy = v.y + c.dt * o.ay, vz = v.z + c.dt * o.az;
         float x = pi.x + c.dt * vx, y = pi.y + c.dt * vy, z = pi.z + c.dt * vz;
         enforce_boundary(c, x, y, z, vx, vy, vz);
         posv_out[i] = make_float4(x, y, z, pi.w);
         velm[i] = make_float4(vx, vy, vz, v.w);
+        return 0.0f;
     }
     __device__ void passive(const Consts &, int i, const float4 &pi) const {
         acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -233,6 +241,7 @@ struct RigidVolumePass {
     static constexpr int BLOCK = 256, CAP = 4096;
     static constexpr bool HAS_B = false, COUNT_PAIRS = false;
     static constexpr int PAIR_WEIGHT = 0;
+    static constexpr bool HAS_REDUCE = false;
     typedef int BT;
     struct Own { float sum; int obj; };
     float4 *posv; float4 *velm; const int *meta;
@@ -257,12 +266,13 @@ struct RigidVolumePass {
                          int) const {
         if (__float_as_int(a.w) == o.obj) o.sum += kernW(c, fsqrt(r2));
     }
-    __device__ void finish(const Consts &c, int i, const float4 &pi, Own &o) const {
+    __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
         const float V = 1.0f / o.sum;
         posv[i] = make_float4(pi.x, pi.y, pi.z, V);  // only .w changes; readers use xyz + meta
         float4 v = velm[i];
         v.w = c.rho0 * V;
         velm[i] = v;
+        return 0.0f;
     }
     __device__ void passive(const Consts &, int, const float4 &) const {}
 };

@@ -1,3 +1,264 @@
-// sph_solvers.hpp -- DFSPH / PCISPH / implicit-viscosity pass functors (filled in sph_solvers_impl.hpp)
+// sph_solvers.hpp -- DFSPH / PCISPH pair functors for k_nbr_pass (included inside the per-build namespace).
 #pragma once
 #include "sph_passes.hpp"
+
+// ---------------------------------------------------------------------------------------
+// base_solver.py:522 compute_density + DFSPH.py:23 compute_alpha (+task :48), fused (both run
+// right after the sort and need the same neighbours).  Staged w = +V fluid / -V rigid.
+// Bytes / particle: R posv 16 -> W rho 4 + alpha 4.
+template <bool AF>
+struct DfsphDensityAlphaPass {
+    static constexpr int BLOCK = 256, CAP = 4096;
+    static constexpr bool HAS_B = false, COUNT_PAIRS = true, HAS_REDUCE = false;
+    static constexpr int PAIR_WEIGHT = 2;  // density pass + alpha pass of the reference
+    typedef int BT;
+    struct Own { float sum, s3, gx, gy, gz; };
+    const float4 *posv; const int *meta; float *rho, *alpha; float *red_out;
+
+    __device__ float4 stage_impl(int j) const {
+        float4 p = posv[j];
+        if (!AF && META_MAT(meta[j]) != 1) p.w = -p.w;
+        return p;
+    }
+    __device__ float4 loadA(int j) const { return stage_impl(j); }
+    __device__ BT loadB(int) const { return 0; }
+    __device__ float4 stage(const Consts &, int j, BT &) const { return stage_impl(j); }
+    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
+        o.sum = o.s3 = o.gx = o.gy = o.gz = 0.0f;
+        return AF || META_MAT(meta[i]) == 1;
+    }
+    __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a, const BT &,
+                         int) const {
+        const float rn = fsqrt(r2);
+        const float V = fabsf(a.w);
+        o.sum += V * kernW(c, rn);
+        float gx, gy, gz;
+        kernGrad(c, dx, dy, dz, rn, gx, gy, gz);
+        const float px = -V * gx, py = -V * gy, pz = -V * gz;
+        if (AF || a.w > 0.0f) o.s3 += px * px + py * py + pz * pz;
+        o.gx += px; o.gy += py; o.gz += pz;
+    }
+    __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
+        float den = pi.w * c.W0;
+        den += o.sum;
+        den *= c.rho0;
+        rho[i] = den;
+        float s = o.s3;
+        s += o.gx * o.gx + o.gy * o.gy + o.gz * o.gz;
+        alpha[i] = s > 1e-5f ? 1.0f / s : 0.0f;
+        return 0.0f;
+    }
+    __device__ void passive(const Consts &, int, const float4 &) const {}
+};
+
+// ---------------------------------------------------------------------------------------
+// DFSPH.py:66 compute_density_derivative (+:133 compute_kappa_v, +:206 error) when MODE == 0,
+// DFSPH.py:105 compute_density_star (+:218 compute_kappa, +:286 error) when MODE == 1.
+// Bytes / particle: R posv 16 + velm 16 (+rho, alpha 8) -> W 8.
+template <bool AF, int MODE>
+struct DfsphRhoAdvPass {
+    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
+    static constexpr int PAIR_WEIGHT = 1;
+    typedef float4 BT;
+    struct Own { float vx, vy, vz, sum; int cnt; };
+    const float4 *posv, *velm; const int *meta; const float *rho, *alpha;
+    float *out_adv, *out_kappa; float *red_out;
+
+    __device__ float4 loadA(int j) const { return posv[j]; }
+    __device__ BT loadB(int j) const { return velm[j]; }
+    __device__ float4 stage(const Consts &, int j, BT &bj) const { bj = velm[j]; return posv[j]; }
+    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
+        if (!AF && META_MAT(meta[i]) != 1) return false;
+        const float4 v = velm[i];
+        o.vx = v.x; o.vy = v.y; o.vz = v.z; o.sum = 0.0f; o.cnt = 0;
+        return true;
+    }
+    __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
+                         const BT &bj, int) const {
+        float gx, gy, gz;
+        kernGrad(c, dx, dy, dz, fsqrt(r2), gx, gy, gz);
+        o.sum += a.w * ((o.vx - bj.x) * gx + (o.vy - bj.y) * gy + (o.vz - bj.z) * gz);
+        o.cnt += 1;
+    }
+    __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {
+        if (MODE == 0) {
+            float adv = fmaxf(o.sum, 0.0f);
+            if (o.cnt < 20) adv = 0.0f;
+            out_adv[i] = adv;
+            out_kappa[i] = adv * alpha[i];
+            return c.rho0 * adv;
+        } else {
+            const float adv = rho[i] / c.rho0 + c.dt * o.sum;
+            const float star = fmaxf(adv, 1.0f);
+            out_adv[i] = star;
+            out_kappa[i] = (star - 1.0f) * alpha[i] * c.inv_dt;
+            return star - 1.0f;
+        }
+    }
+    __device__ void passive(const Consts &, int, const float4 &) const {}
+};
+
+// ---------------------------------------------------------------------------------------
+// DFSPH.py:162 correct_divergence_step (+task :173) when MODE == 0 (dv accumulated, then added),
+// DFSPH.py:246 correct_density_error_step (+task :255) when MODE == 1 (velocity updated pair by pair).
+// Bytes / particle: R posv 16 + kappa 4 + rho 4 + velm 16 -> W velm 16.
+template <bool AF, int MODE>
+struct DfsphCorrectPass {
+    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
+    static constexpr int PAIR_WEIGHT = 1;
+    typedef float2 BT;
+    struct Own { float k, rho, vx, vy, vz, m0; };
+    const float4 *posv; const int *meta; const float *kappa, *rho;
+    float4 *velm; DevScalars *scal; const RigidPose *pose; float rho0; float *red_out;
+
+    __device__ float4 stage_impl(int j, BT &bj) const {
+        float4 p = posv[j];
+        if (!AF) {
+            const int m = meta[j];
+            if (META_MAT(m) != 1) { p.w = -p.w; bj = make_float2(META_DYN(m) ? 1.0f : 0.0f, 1.0f); return p; }
+        }
+        bj = make_float2(kappa[j], rho[j]);
+        return p;
+    }
+    __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
+    __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
+    __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
+    __device__ bool begin(const Consts &, int i, const float4 &pi, Own &o) const {
+        if (!AF && META_MAT(meta[i]) != 1) return false;
+        o.k = kappa[i]; o.rho = rho[i];
+        if (MODE == 1) { const float4 v = velm[i]; o.vx = v.x; o.vy = v.y; o.vz = v.z; }
+        else { o.vx = o.vy = o.vz = 0.0f; }
+        o.m0 = pi.w * rho0;
+        return true;
+    }
+    __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
+                         const BT &bj, int j) const {
+        float gx, gy, gz;
+        if (AF || a.w > 0.0f) {
+            const float ks = o.k + bj.x;
+            if (fabsf(ks) > c.thr_kappa) {
+                kernGrad(c, dx, dy, dz, fsqrt(r2), gx, gy, gz);
+                const float cc = fdiv(o.k, o.rho) + fdiv(bj.x, bj.y);
+                o.vx -= ((a.w * gx) * cc) * c.rho0; o.vy -= ((a.w * gy) * cc) * c.rho0; o.vz -= ((a.w * gz) * cc) * c.rho0;
+            }
+        } else {
+            if (fabsf(o.k) > c.thr_kappa) {
+                kernGrad(c, dx, dy, dz, fsqrt(r2), gx, gy, gz);
+                const float V = -a.w;
+                const float cc = fdiv(o.k, o.rho);
+                const float tx = ((V * gx) * cc) * c.rho0, ty = ((V * gy) * cc) * c.rho0, tz = ((V * gz) * cc) * c.rho0;
+                o.vx -= tx; o.vy -= ty; o.vz -= tz;
+                if (bj.x == 1.0f) {  // dynamic rigid: DFSPH.py:195-204 / :277-285
+                    const int obj = META_OBJ(meta[j]);
+                    const float fx = fdiv(tx, c.dt) * o.m0, fy = fdiv(ty, c.dt) * o.m0, fz = fdiv(tz, c.dt) * o.m0;
+                    const float4 pj = posv[j];
+                    const float rx = pj.x - pose->com[obj][0], ry = pj.y - pose->com[obj][1], rz = pj.z - pose->com[obj][2];
+                    add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
+                }
+            }
+        }
+    }
+    __device__ float finish(const Consts &, int i, const float4 &, Own &o) const {
+        float4 v = velm[i];
+        if (MODE == 1) { v.x = o.vx; v.y = o.vy; v.z = o.vz; }
+        else { v.x += o.vx; v.y += o.vy; v.z += o.vz; }
+        velm[i] = v;
+        return 0.0f;
+    }
+    __device__ void passive(const Consts &, int, const float4 &) const {}
+};
+
+// ---------------------------------------------------------------------------------------
+// PCISPH.py:33 compute_density_star (+task :49) + :66 update_pressure, fused.  The neighbour
+// test runs on the current positions (for_all_neighbors), the kernel on predicted positions of
+// fluid neighbours / current positions of rigid neighbours.
+// Bytes / particle: R posv 16 + ppos 16 + prs 4 + rho 4 -> W rho_star 4 + prs 4 + ptm 4.
+template <bool AF>
+struct PcisphRhoStarPass {
+    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
+    static constexpr int PAIR_WEIGHT = 1;
+    typedef float4 BT;
+    struct Own { float px, py, pz, sum; };
+    const float4 *posv, *ppos; const int *meta; const float *rho;
+    float *rho_star, *prs, *ptm; float *red_out;
+
+    __device__ float4 loadA(int j) const { return posv[j]; }
+    __device__ BT loadB(int j) const {
+        if (!AF && META_MAT(meta[j]) != 1) return posv[j];
+        return ppos[j];
+    }
+    __device__ float4 stage(const Consts &, int j, BT &bj) const { bj = loadB(j); return posv[j]; }
+    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
+        if (!AF && META_MAT(meta[i]) != 1) return false;
+        const float4 q = ppos[i];
+        o.px = q.x; o.py = q.y; o.pz = q.z; o.sum = 0.0f;
+        return true;
+    }
+    __device__ void pair(const Consts &c, Own &o, float, float, float, float, const float4 &a, const BT &bj, int) const {
+        const float dx = o.px - bj.x, dy = o.py - bj.y, dz = o.pz - bj.z;
+        o.sum += a.w * kernW(c, fsqrt(dx * dx + dy * dy + dz * dz));
+    }
+    __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {
+        const float star = o.sum * c.rho0;
+        rho_star[i] = star;
+        float p = prs[i] + c.pcisph_k * (c.rho0 - star);
+        if (p < 0.0f) p = 0.0f;
+        prs[i] = p;
+        const float r = rho[i];
+        ptm[i] = p / (r * r);
+        return fmaxf(0.0f, o.sum - 1.0f);
+    }
+    __device__ void passive(const Consts &, int, const float4 &) const {}
+};
+
+// PCISPH.py:75 compute_temp_pressure_acceleration (+task :85) + :19 compute_predicted_velocity
+// + :26 compute_predicted_position, fused.
+// Bytes / particle: R posv 16 + velm 16 + ptm 4 + acc 16 -> W pacc 16 + ppos 16 (+pvel 16).
+template <bool AF>
+struct PcisphPressureAccelPass {
+    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
+    static constexpr int PAIR_WEIGHT = 1;
+    typedef float BT;
+    struct Own { float pt, ax, ay, az; };
+    const float4 *posv, *velm; const int *meta; const float *ptm;
+    const float4 *acc_np, *vel0;   // non-pressure acceleration, velocity at the start of the step
+    float4 *pacc, *pvel, *ppos; float rho0; float *red_out;
+
+    __device__ float4 stage_impl(int j, BT &bj) const {
+        const float4 p = posv[j];
+        const float m = velm[j].w;
+        if (AF) { bj = ptm[j]; return make_float4(p.x, p.y, p.z, m); }
+        const bool fl = META_MAT(meta[j]) == 1;
+        bj = fl ? ptm[j] : -1.0f;
+        return make_float4(p.x, p.y, p.z, fl ? m : rho0 * p.w);
+    }
+    __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
+    __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
+    __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
+    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
+        if (!AF && META_MAT(meta[i]) != 1) return false;
+        o.pt = ptm[i];
+        o.ax = o.ay = o.az = 0.0f;
+        return true;
+    }
+    __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
+                         const BT &bj, int) const {
+        float gx, gy, gz;
+        kernGrad(c, dx, dy, dz, fsqrt(r2), gx, gy, gz);
+        const float cc = (AF || bj >= 0.0f) ? -a.w * (o.pt + bj) : -a.w * o.pt;
+        o.ax += cc * gx; o.ay += cc * gy; o.az += cc * gz;
+    }
+    __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
+        pacc[i] = make_float4(o.ax, o.ay, o.az, 0.0f);
+        const float4 a = acc_np[i], v = vel0[i];
+        const float vx = v.x + c.dt * (a.x + o.ax), vy = v.y + c.dt * (a.y + o.ay), vz = v.z + c.dt * (a.z + o.az);
+        pvel[i] = make_float4(vx, vy, vz, 0.0f);
+        ppos[i] = make_float4(pi.x + c.dt * vx, pi.y + c.dt * vy, pi.z + c.dt * vz, 0.0f);
+        return 0.0f;
+    }
+    __device__ void passive(const Consts &, int i, const float4 &) const { pacc[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+};

@@ -1,3 +1,122 @@
 // sph_solvers_impl.hpp -- launchers of the iterative pressure solvers; included by sph_kernels.hip
+// inside the per-build namespace.
 #pragma once
-static void register_solver_launchers(Launch &L) { (void)L; }
+
+// DFSPH position update: base_solver.py:652 update_fluid_position + :575 enforce_domain_boundary_3D
+__global__ void __launch_bounds__(256)
+k_advect_boundary(const Consts c, float4 *posv, float4 *velm, int *meta, const RigidPose *pose, int all_fluid) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c.n) return;
+    float4 p = posv[i], v = velm[i];
+    const int m = all_fluid ? META_PACK(0, 1, 1) : meta[i];
+    if (META_MAT(m) == 1) {
+        p.x += c.dt * v.x; p.y += c.dt * v.y; p.z += c.dt * v.z;
+        if (META_DYN(m)) enforce_boundary(c, p.x, p.y, p.z, v.x, v.y, v.z);
+        posv[i] = p; velm[i] = v;
+    } else if (p.y > c.g_upper) {  // emitter branch :660-666
+        const int obj = META_OBJ(m);
+        if (obj >= 0 && pose->material[obj] == 1) {
+            p.x += c.dt * v.x; p.y += c.dt * v.y; p.z += c.dt * v.z;
+            if (p.y <= c.g_upper) {
+                meta[i] = META_SET_MAT(m, 1);
+                if (META_DYN(m)) enforce_boundary(c, p.x, p.y, p.z, v.x, v.y, v.z);
+                velm[i] = v;
+            }
+            posv[i] = p;
+        }
+    }
+}
+
+static void l_advect_boundary(State &s) {
+    if (s.c.n == 0) return;
+    hipLaunchKernelGGL(k_advect_boundary, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(),
+                       s.velm.cur(), s.meta.cur(), s.pose, s.c.all_fluid);
+}
+
+static void l_reduce_sum(State &s, int slot, int nblocks) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s.stream, s.red_partial, nblocks, s.scal, slot);
+}
+
+static void l_dfsph_density_alpha(State &s) {
+    if (s.c.all_fluid) { DfsphDensityAlphaPass<true> p{s.posv.cur(), s.meta.cur(), s.rho.cur(), s.alpha, s.red_partial}; launch_pass(s, p); }
+    else { DfsphDensityAlphaPass<false> p{s.posv.cur(), s.meta.cur(), s.rho.cur(), s.alpha, s.red_partial}; launch_pass(s, p); }
+}
+
+template <int MODE> static void dfsph_rho_adv_t(State &s, int slot) {
+    float *out_adv = MODE == 0 ? s.rho_deriv : s.rho_star;
+    float *out_k = MODE == 0 ? s.kappa_v : s.kappa;
+    if (s.c.all_fluid) {
+        DfsphRhoAdvPass<true, MODE> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.alpha, out_adv, out_k, s.red_partial};
+        launch_pass(s, p);
+    } else {
+        DfsphRhoAdvPass<false, MODE> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.alpha, out_adv, out_k, s.red_partial};
+        launch_pass(s, p);
+    }
+    if (s.c.n > 0) l_reduce_sum(s, slot, cdiv(s.c.n, 128));
+}
+static void l_dfsph_rho_adv(State &s, int mode) { if (mode == 0) dfsph_rho_adv_t<0>(s, 0); else dfsph_rho_adv_t<1>(s, 1); }
+
+template <int MODE> static void dfsph_correct_t(State &s) {
+    const float *kap = MODE == 0 ? s.kappa_v : s.kappa;
+    if (s.c.all_fluid) {
+        DfsphCorrectPass<true, MODE> p{s.posv.cur(), s.meta.cur(), kap, s.rho.cur(), s.velm.cur(), s.scal, s.pose, s.c.rho0, s.red_partial};
+        launch_pass(s, p);
+    } else {
+        DfsphCorrectPass<false, MODE> p{s.posv.cur(), s.meta.cur(), kap, s.rho.cur(), s.velm.cur(), s.scal, s.pose, s.c.rho0, s.red_partial};
+        launch_pass(s, p);
+    }
+}
+static void l_dfsph_correct(State &s, int mode) { if (mode == 0) dfsph_correct_t<0>(s); else dfsph_correct_t<1>(s); }
+
+// PCISPH.py:154 init_step
+__global__ void __launch_bounds__(256)
+k_pcisph_init(const Consts c, const float4 *posv, const float4 *vel0, const float4 *acc_np, const int *meta,
+              float *prs, float *ptm, float4 *pacc, float4 *pvel, float4 *ppos, int all_fluid) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c.n) return;
+    prs[i] = 0.0f; ptm[i] = 0.0f;
+    pacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!all_fluid && META_MAT(meta[i]) != 1) return;
+    const float4 x = posv[i], v = vel0[i], a = acc_np[i];
+    const float vx = v.x + c.dt * a.x, vy = v.y + c.dt * a.y, vz = v.z + c.dt * a.z;
+    pvel[i] = make_float4(vx, vy, vz, 0.f);
+    ppos[i] = make_float4(x.x + c.dt * vx, x.y + c.dt * vy, x.z + c.dt * vz, 0.f);
+}
+
+// called after the non-pressure pass: velm.cur() = v*, velm.alt() = v (start of step)
+static void l_pcisph_init(State &s) {
+    if (s.c.n == 0) return;
+    hipLaunchKernelGGL(k_pcisph_init, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.velm.alt(),
+                       s.acc_np, s.meta.cur(), s.prs, s.ptm, s.pacc, s.pvel, s.ppos, s.c.all_fluid);
+}
+
+static void l_pcisph_rho_star(State &s) {
+    if (s.c.all_fluid) {
+        PcisphRhoStarPass<true> p{s.posv.cur(), s.ppos, s.meta.cur(), s.rho.cur(), s.rho_star, s.prs, s.ptm, s.red_partial};
+        launch_pass(s, p);
+    } else {
+        PcisphRhoStarPass<false> p{s.posv.cur(), s.ppos, s.meta.cur(), s.rho.cur(), s.rho_star, s.prs, s.ptm, s.red_partial};
+        launch_pass(s, p);
+    }
+    if (s.c.n > 0) l_reduce_sum(s, 2, cdiv(s.c.n, 128));
+}
+
+static void l_pcisph_pressure_accel(State &s) {
+    if (s.c.all_fluid) {
+        PcisphPressureAccelPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.ptm, s.acc_np, s.velm.alt(), s.pacc, s.pvel, s.ppos, s.c.rho0, s.red_partial};
+        launch_pass(s, p);
+    } else {
+        PcisphPressureAccelPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.ptm, s.acc_np, s.velm.alt(), s.pacc, s.pvel, s.ppos, s.c.rho0, s.red_partial};
+        launch_pass(s, p);
+    }
+}
+
+static void register_solver_launchers(Launch &L) {
+    L.dfsph_density_alpha = l_dfsph_density_alpha;
+    L.dfsph_rho_adv = l_dfsph_rho_adv;
+    L.dfsph_correct = l_dfsph_correct;
+    L.advect_boundary = l_advect_boundary;
+    L.pcisph_init = l_pcisph_init;
+    L.pcisph_rho_star = l_pcisph_rho_star;
+    L.pcisph_pressure_accel = l_pcisph_pressure_accel;
+}

@@ -2,9 +2,23 @@
 // Order of operations follows WCSPH.py:27, DFSPH.py:298, PCISPH.py:165 and base_solver.py:692.
 #pragma once
 
+// reads scal->red[slot] (one small D2H copy + stream sync: the reference's python loops read one
+// scalar per iteration too, DFSPH.py:150, :236; PCISPH.py:122)
+static int read_red(SphHandle *h, int slot, float *out) {
+    HIPCHK(h, hipMemcpyAsync(&h->scal_h->red[slot], &h->st.scal->red[slot], sizeof(float), hipMemcpyDeviceToHost, h->st.stream));
+    HIPCHK(h, hipStreamSynchronize(h->st.stream));
+    *out = h->scal_h->red[slot];
+    return SPH_OK;
+}
+
+static int implicit_viscosity_non_pressure(SphHandle *h);
+
 // base_solver.py:190 compute_non_pressure_acceleration + :643 update_fluid_velocity
 static int run_non_pressure(SphHandle *h) {
-    if (h->prm.viscosity_implicit) return fail(h, SPH_ERR_UNSUPPORTED, "implicit viscosity is not built in this round");
+    if (h->prm.viscosity_implicit) {
+        int rc = implicit_viscosity_non_pressure(h);
+        return rc;
+    }
     ProfScope p(h, SPH_K_NON_PRESSURE);
     h->L->non_pressure(h->st);
     return SPH_OK;
@@ -20,21 +34,149 @@ static int wcsph_step(SphHandle *h) {
     return SPH_OK;
 }
 
+// DFSPH.py:139 correct_divergence_error
+static int dfsph_divergence(SphHandle *h, bool allow_readback) {
+    State &s = h->st;
+    const int fixed = h->prm.fixed_iterations;
+    const int max_itr = fixed > 0 ? fixed : 1000;
+    { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 0); }
+    int itr = 0;
+    float avg = 0.0f;
+    while (itr < 1 || itr < max_itr) {
+        { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 0); }
+        { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 0); }
+        itr++;
+        if (fixed > 0) continue;
+        if (!allow_readback) return fail(h, SPH_ERR_UNSUPPORTED, "dfsph needs host read-back unless fixed_iterations > 0");
+        float sum; int rc = read_red(h, 0, &sum); if (rc) return rc;
+        avg = sum / (float)h->n;                                    // DFSPH.py:212 (divides by particle_num)
+        const double eta = 0.001 * h->prm.density_0 / (double)s.c.dt;  // :150
+        if ((double)avg <= eta) break;
+    }
+    h->last.iter_divergence = itr; h->last.err_divergence = avg;
+    return SPH_OK;
+}
+
+// DFSPH.py:225 correct_density_error
+static int dfsph_density(SphHandle *h, bool allow_readback) {
+    State &s = h->st;
+    const int fixed = h->prm.fixed_iterations;
+    const int max_itr = fixed > 0 ? fixed : 1000;
+    { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 1); }
+    int itr = 0;
+    float avg = 0.0f;
+    while (itr < 1 || itr < max_itr) {
+        { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 1); }
+        { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 1); }
+        itr++;
+        if (fixed > 0) continue;
+        if (!allow_readback) return fail(h, SPH_ERR_UNSUPPORTED, "dfsph needs host read-back unless fixed_iterations > 0");
+        float sum; int rc = read_red(h, 1, &sum); if (rc) return rc;
+        avg = sum / (float)h->n;                                    // DFSPH.py:293
+        if ((double)avg <= 0.0001) break;                            // :239
+    }
+    h->last.iter_density = itr; h->last.err_density = avg;
+    return SPH_OK;
+}
+
 static int dfsph_step(SphHandle *h, bool allow_readback) {
-    (void)allow_readback;
-    return fail(h, SPH_ERR_UNSUPPORTED, "dfsph step not built yet");
+    State &s = h->st;
+    int rc = run_non_pressure(h); if (rc) return rc;                          // DFSPH.py:299-300
+    rc = dfsph_density(h, allow_readback); if (rc) return rc;                 // :301
+    { ProfScope p(h, SPH_K_MISC); h->L->advect_boundary(s); }                 // :303, :311-314
+    ph_neighbor_search(h);                                                    // :316
+    ph_rigid_volume(h);
+    { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha(s); } // :317-318
+    return dfsph_divergence(h, allow_readback);                               // :319
+}
+
+// PCISPH.py:110 refine
+static int pcisph_refine(SphHandle *h, bool allow_readback) {
+    State &s = h->st;
+    const int fixed = h->prm.fixed_iterations;
+    const int max_itr = fixed > 0 ? fixed : 1000;
+    int itr = 0;
+    float err = 100.0f;
+    while (itr < max_itr) {
+        { ProfScope p(h, SPH_K_PCISPH_RHO_STAR); h->L->pcisph_rho_star(s); }
+        { ProfScope p(h, SPH_K_PCISPH_PRESSURE_ACCEL); h->L->pcisph_pressure_accel(s); }
+        itr++;
+        if (fixed > 0) continue;
+        if (!allow_readback) return fail(h, SPH_ERR_UNSUPPORTED, "pcisph needs host read-back unless fixed_iterations > 0");
+        float sum; int rc = read_red(h, 2, &sum); if (rc) return rc;
+        err = h->n_fluid > 0 ? sum / (float)h->n_fluid : 0.0f;       // PCISPH.py:43-46
+        if (err < 0.001f) break;                                    // :122
+    }
+    h->last.iter_pcisph = itr; h->last.err_pcisph = err;
+    return SPH_OK;
 }
 
 static int pcisph_step(SphHandle *h, bool allow_readback) {
-    (void)allow_readback;
-    return fail(h, SPH_ERR_UNSUPPORTED, "pcisph step not built yet");
+    State &s = h->st;
+    ph_neighbor_search(h);                                                    // PCISPH.py:166
+    ph_rigid_volume(h);
+    { ProfScope p(h, SPH_K_DENSITY); h->L->density(s, 0); }                   // :167
+    int rc = run_non_pressure(h); if (rc) return rc;                          // :168 (+ :174, v* kept aside)
+    { ProfScope p(h, SPH_K_MISC); h->L->pcisph_init(s); }                     // :169
+    rc = pcisph_refine(h, allow_readback); if (rc) return rc;                 // :170
+    { ProfScope p(h, SPH_K_PRESSURE_INTEGRATE); h->L->pressure_integrate(s); } // :175-177, :185
+    return SPH_OK;
+}
+
+// host replica of PCISPH.py:129 compute_pcisph_k (same arithmetic as oracle/sph_ref.c)
+static float host_pcisph_k(const SphParams &p) {
+    const double hd = p.support_radius;
+    const float hf = (float)hd;
+    float kg = (float)(8.0 / M_PI);
+    kg = 6.0f * kg / (float)(hd * hd * hd);
+    const float diam = (float)(2.0 * p.particle_radius * 0.97);
+    float sx = 0.f, sy = 0.f, sz = 0.f, s2 = 0.f;
+    const int max_i = (int)(hf / diam) + 1;
+    for (int i = -max_i; i <= max_i; i++)
+        for (int j = -max_i; j <= max_i; j++)
+            for (int k = -max_i; k <= max_i; k++) {
+                const float rx = 0.0f - (float)i * diam, ry = 0.0f - (float)j * diam, rz = 0.0f - (float)k * diam;
+                const float rn = sqrtf(rx * rx + ry * ry + rz * rz);
+                if (rn < hf) {
+                    float gx = 0.f, gy = 0.f, gz = 0.f;
+                    const float q = rn / hf;
+                    if (rn > 1e-5f && q <= 1.0f) {
+                        const float den = rn * hf;
+                        float sc;
+                        if (q <= 0.5f) sc = kg * q * (3.0f * q - 2.0f);
+                        else { const float f = 1.0f - q; sc = kg * (-f * f); }
+                        gx = sc * (rx / den); gy = sc * (ry / den); gz = sc * (rz / den);
+                    }
+                    sx += gx; sy += gy; sz += gz;
+                    s2 += gx * gx + gy * gy + gz * gz;
+                }
+            }
+    const float dtV0 = (float)p.dt * (float)p.V0;
+    return -0.5f / dtV0 / dtV0 / ((sx * sx + sy * sy + sz * sz) + s2);
 }
 
 static int method_prepare(SphHandle *h) {
-    if (h->prm.method == SPH_METHOD_WCSPH) return SPH_OK;
-    return fail(h, SPH_ERR_UNSUPPORTED, "method %d not built yet", h->prm.method);
+    State &s = h->st;
+    if (h->prm.method == SPH_METHOD_DFSPH) {  // DFSPH.py:321-324
+        ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA);
+        h->L->dfsph_density_alpha(s);
+    } else if (h->prm.method == SPH_METHOD_PCISPH) {  // PCISPH.py:188-190
+        s.c.pcisph_k = host_pcisph_k(h->prm);
+    }
+    return SPH_OK;
 }
 
 static int method_run_phase(SphHandle *h, int phase) {
-    return fail(h, SPH_ERR_INVALID, "unknown phase %d", phase);
+    State &s = h->st;
+    if (h->prm.method == SPH_METHOD_DFSPH) {
+        switch (phase) {
+            case SPH_PH_DFSPH_ALPHA: { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha(s); } return SPH_OK;
+            case SPH_PH_DFSPH_DIVERGENCE: return dfsph_divergence(h, true);
+            case SPH_PH_DFSPH_DENSITY: return dfsph_density(h, true);
+            default: break;
+        }
+    }
+    return fail(h, SPH_ERR_INVALID, "unknown phase %d for method %d", phase, h->prm.method);
 }
+
+#include "sph_cg_steps.hpp"

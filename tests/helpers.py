@@ -46,7 +46,9 @@ def scene_particles(cfg_dict):
     if geo.add_domain_box:
         pos = scene.box_lattice(geo.domain_box_start, geo.domain_box_size, geo.domain_box_thickness, geo.particle_spacing)
         n = pos.shape[0]
-        batches.append(dict(object_id=n_obj, pos=pos, vel=np.zeros((n, 3), np.float32),
+        # BaseSolver.prepare() -> init_object_id() (base_solver.py:680) runs after the box was added in
+        # BaseContainer.__init__, so the reference's box particles carry object id -1
+        batches.append(dict(object_id=-1, pos=pos, vel=np.zeros((n, 3), np.float32),
                             density=np.full(n, 1000.0, np.float32), material=np.full(n, 2, np.int32),
                             is_dynamic=np.zeros(n, np.int32)))
     for blk in blocks:
@@ -73,7 +75,8 @@ def build_oracle(cfg_dict, jitter=0.0, seed=0, fixed_iterations=0):
         color = np.zeros((n, 3), np.int32)
         color[:, 0] = np.arange(next_id, next_id + n)
         next_id += n
-        sim.set_object(b["object_id"], int(b["material"][0]), 0)
+        if b["object_id"] >= 0:
+            sim.set_object(b["object_id"], int(b["material"][0]), 0)
         sim.add_particles(b["object_id"], pos, b["vel"], b["density"], np.zeros(n, np.float32), b["material"],
                           b["is_dynamic"], color)
     return sim
