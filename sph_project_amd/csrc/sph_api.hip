@@ -10,6 +10,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <utility>
 
 static thread_local std::string g_create_error;
 
@@ -213,12 +214,13 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     CHK_CREATE(dalloc(h, &s.scan_partial, (size_t)s.scan_blocks + 1));
     CHK_CREATE(dalloc(h, &s.rho_raw, cap)); CHK_CREATE(dalloc(h, &s.prs, cap)); CHK_CREATE(dalloc(h, &s.ptm, cap));
     CHK_CREATE(dalloc(h, &s.acc, cap));
-    s.alpha = s.kappa = s.kappa_v = s.rho_star = s.rho_deriv = nullptr; s.kr = nullptr;
+    s.alpha = s.kappa = s.kappa_v = s.rho_star = s.rho_deriv = s.kappa_next = s.kappa_v_next = nullptr; s.kr = nullptr;
     s.pacc = s.pvel = s.ppos = s.acc_np = nullptr; s.np_acc_out = nullptr;
     s.cg_p = s.cg_Ap = s.cg_x = s.cg_b = s.cg_r = s.cg_v0 = nullptr; s.cg_dinv = nullptr;
     if (p.method == SPH_METHOD_DFSPH) {
         CHK_CREATE(dalloc(h, &s.alpha, cap)); CHK_CREATE(dalloc(h, &s.kappa, cap)); CHK_CREATE(dalloc(h, &s.kappa_v, cap));
         CHK_CREATE(dalloc(h, &s.rho_star, cap)); CHK_CREATE(dalloc(h, &s.rho_deriv, cap)); CHK_CREATE(dalloc(h, &s.kr, cap));
+        CHK_CREATE(dalloc(h, &s.kappa_next, cap)); CHK_CREATE(dalloc(h, &s.kappa_v_next, cap));
     }
     if (p.method == SPH_METHOD_PCISPH) {
         CHK_CREATE(dalloc(h, &s.pacc, cap)); CHK_CREATE(dalloc(h, &s.pvel, cap)); CHK_CREATE(dalloc(h, &s.ppos, cap));

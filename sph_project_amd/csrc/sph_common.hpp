@@ -87,6 +87,7 @@ struct State {
     float4 *acc;
     // DFSPH
     float *alpha, *kappa, *kappa_v, *rho_star, *rho_deriv;
+    float *kappa_next, *kappa_v_next;  // written by the rho_adv pass, consumed (after a swap) by the next correction
     float2 *kr;          // (kappa, rho) staging pair for the correction pass
     // PCISPH
     float4 *pacc, *pvel, *ppos, *acc_np;

@@ -44,7 +44,7 @@ static void l_dfsph_density_alpha(State &s) {
 
 template <int MODE> static void dfsph_rho_adv_t(State &s, int slot) {
     float *out_adv = MODE == 0 ? s.rho_deriv : s.rho_star;
-    float *out_k = MODE == 0 ? s.kappa_v : s.kappa;
+    float *out_k = MODE == 0 ? s.kappa_v_next : s.kappa_next;
     if (s.c.all_fluid) {
         DfsphRhoAdvPass<true, MODE> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.alpha, out_adv, out_k, s.red_partial};
         launch_pass(s, p);

@@ -43,6 +43,7 @@ static int dfsph_divergence(SphHandle *h, bool allow_readback) {
     int itr = 0;
     float avg = 0.0f;
     while (itr < 1 || itr < max_itr) {
+        std::swap(s.kappa_v, s.kappa_v_next);  // DFSPH.py:133 compute_kappa_v: value of the last density-derivative pass
         { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 0); }
         { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 0); }
         itr++;
@@ -66,6 +67,7 @@ static int dfsph_density(SphHandle *h, bool allow_readback) {
     int itr = 0;
     float avg = 0.0f;
     while (itr < 1 || itr < max_itr) {
+        std::swap(s.kappa, s.kappa_next);      // DFSPH.py:218 compute_kappa
         { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 1); }
         { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 1); }
         itr++;

@@ -40,6 +40,7 @@ def test_hip_matches_golden(gpu, path, fast_math):
     np.testing.assert_array_equal(e.download(L.F_PARTICLE_ID), z["prep_ids"])
     np.testing.assert_array_equal(e.download(L.F_POSITION), z["prep_positions"])
     step = 0
+    slot_fluid, slot_fluid_step = z["prep_materials"] == 1, 0   # who occupied each slot before the last sort
     for cp in z["checkpoints"]:
         while step < cp:
             solver.step()
@@ -56,9 +57,20 @@ def test_hip_matches_golden(gpu, path, fast_math):
             if pre + key not in z.files or (key == "accelerations" and method not in ACC_METHODS):
                 continue
             try:
-                mine = H.by_id(ids, e.download(fid))
+                raw = e.download(fid)
             except L.SphError:
                 continue
+            if method == "dfsph" and key in ("kappa", "densities_star"):
+                # computed before the end-of-step sort and not reordered by it (base_container.py:506 list):
+                # slot-indexed in the reference and here alike, so compare slot by slot
+                # ... and only where the slot held a fluid particle when the value was written (slots that held a
+                # boundary particle keep stale values of earlier steps in the reference)
+                if slot_fluid_step != cp - 1 and not slot_fluid.all():
+                    continue
+                scale = max(float(np.abs(z[pre + key]).max()), 1e-30)
+                worst[key] = float(np.abs(raw.astype(np.float64) - z[pre + key].astype(np.float64))[slot_fluid].max()) / scale
+                continue
+            mine = H.by_id(ids, raw)
             ref = H.by_id(z[pre + "ids"], z[pre + key])
             if key not in ("positions", "velocities", "rest_volumes", "masses"):
                 mine, ref = mine[fluid], ref[fluid]
@@ -67,4 +79,5 @@ def test_hip_matches_golden(gpu, path, fast_math):
         lim = {"positions": 1e-5, "velocities": 5e-4, "densities": 2e-5, "rest_volumes": 1e-5, "masses": 1e-5}
         for k, v in worst.items():
             assert v < lim.get(k, 5e-3), (cp, k, v, worst)
+        slot_fluid, slot_fluid_step = z[pre + "materials"] == 1, cp
     print(os.path.basename(path), "fast" if fast_math else "strict", "final drift %.2e" % d, worst)

@@ -21,7 +21,7 @@ def _ref_xv(ref):
 
 
 @pytest.mark.parametrize("method,steps,spacing", [("dfsph", 30, None), ("dfsph", 15, 0.0185), ("pcisph", 30, None),
-                                                   ("pcisph", 10, 0.0185)])
+                                                   ("pcisph", 10, 0.0165)])
 def test_solver_drift_vs_oracle(gpu, method, steps, spacing):
     extra = {} if spacing is None else {"particleSpacing": spacing}
     dt = 6e-4 if method == "dfsph" else 4e-4

@@ -74,6 +74,25 @@ def test_drift_100_steps_8k(gpu):
     assert d.max() <= 1e-4
 
 
+@pytest.mark.parametrize("fast_math", [0, 1])
+def test_drift_compressed_block(gpu, fast_math):
+    """Lattice packed 10 % tighter than rest spacing: rho > rho0 from step 0, so the Tait pressure force (which
+    a rest lattice never triggers: rho = 0.8 rho0 is clamped to rho0, p = 0) dominates the motion."""
+    cfg = H.dam_break_scene(end=(0.36, 0.36, 0.36), particleSpacing=0.018, velocity=(0.0, -0.5, 0.0))
+    container, solver = H.build_product(cfg, jitter=0.002, seed=9, fast_math=fast_math)
+    solver.prepare()
+    ref = H.build_oracle(cfg, jitter=0.002, seed=9)
+    ref.prepare()
+    for _ in range(60):
+        solver.step()
+    ref.step(60)
+    a, b = _state(container), _ref_state(ref)
+    assert np.abs(b["p"]).max() > 1e3
+    d = H.drift(a["x"], b["x"], container.dh)
+    print("compressed drift (fast=%d) max %.3e p99 %.3e, n=%d" % (fast_math, d.max(), np.percentile(d, 99), len(d)))
+    assert d.max() <= 1e-4
+
+
 def test_fast_math_drift(gpu):
     cfg = H.dam_break_scene()
     container, solver = H.build_product(cfg, fast_math=1)
