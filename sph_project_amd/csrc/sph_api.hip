@@ -215,7 +215,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     CHK_CREATE(dalloc(h, &s.rho_raw, cap)); CHK_CREATE(dalloc(h, &s.prs, cap)); CHK_CREATE(dalloc(h, &s.ptm, cap));
     CHK_CREATE(dalloc(h, &s.acc, cap));
     s.alpha = s.kappa = s.kappa_v = s.rho_star = s.rho_deriv = s.kappa_next = s.kappa_v_next = nullptr; s.kr = nullptr;
-    s.pacc = s.pvel = s.ppos = s.acc_np = nullptr; s.np_acc_out = nullptr;
+    s.pacc = s.pvel = s.ppos = s.acc_np = nullptr; s.np_acc_out = nullptr; s.np_visc_vel = nullptr;
     s.cg_p = s.cg_Ap = s.cg_x = s.cg_b = s.cg_r = s.cg_v0 = nullptr; s.cg_dinv = nullptr;
     if (p.method == SPH_METHOD_DFSPH) {
         CHK_CREATE(dalloc(h, &s.alpha, cap)); CHK_CREATE(dalloc(h, &s.kappa, cap)); CHK_CREATE(dalloc(h, &s.kappa_v, cap));
@@ -242,7 +242,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     memset(&h->last, 0, sizeof(h->last));
     s.has_dynamic_rigid = 0; s.has_rigid = 0;
     s.visc_rho_raw = (p.method == SPH_METHOD_WCSPH);
-    s.skip_viscosity = p.viscosity_implicit ? 1 : 0;
+    s.skip_viscosity = 0;
     refresh_counts(h);
     *out = h;
     return SPH_OK;

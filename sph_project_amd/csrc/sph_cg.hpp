@@ -1,0 +1,260 @@
+// sph_cg.hpp -- implicit viscosity (base_solver.py:282-517): matrix-free, block-Jacobi-scaled CG
+// over the neighbour graph.  Included inside the per-build namespace.
+#pragma once
+#include "sph_passes.hpp"
+
+__device__ __forceinline__ void mat3_inverse(const float *a, float *o) {
+    // ti.math.inverse for 3x3 (cofactor form, 1/det first) -- same formula as oracle/sph_ref.c m3_inverse
+    const float det = a[0] * (a[4] * a[8] - a[7] * a[5]) - a[3] * (a[1] * a[8] - a[7] * a[2]) + a[6] * (a[1] * a[5] - a[4] * a[2]);
+    const float inv = 1.0f / det;
+#define E(x, y) a[((x) % 3) * 3 + ((y) % 3)]
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            o[j * 3 + i] = inv * (E(i + 1, j + 1) * E(i + 2, j + 2) - E(i + 2, j + 1) * E(i + 1, j + 2));
+#undef E
+}
+
+// base_solver.py:282 prepare_conjugate_gradient_solver1 (+tasks :326, :334, :349)
+// Bytes / particle: R posv 16 + velm 16 + rho 4 + cg_x 16 -> W dinv 36 + b 16 + p 16 + x 16 + v0 16 (+ zero fills).
+template <bool AF>
+struct CgPreparePass {
+    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
+    static constexpr int PAIR_WEIGHT = 2;  // A_ii pass + b_i pass of the reference
+    typedef float4 BT;
+    struct Own { float m, rho; float a[9]; float bx, by, bz; };
+    const float4 *posv, *velm; const int *meta; const float *rho;
+    float4 *cg_x, *cg_p, *cg_b, *cg_r, *cg_Ap, *cg_v0; float *dinv; float rho0; float *red_out;
+
+    __device__ float4 stage_impl(int j, BT &bj) const {
+        const float4 p = posv[j], v = velm[j];
+        if (AF) { bj = make_float4(v.x, v.y, v.z, rho[j]); return make_float4(p.x, p.y, p.z, v.w); }
+        const bool fl = META_MAT(meta[j]) == 1;
+        bj = make_float4(v.x, v.y, v.z, fl ? rho[j] : -1.0f);
+        return make_float4(p.x, p.y, p.z, fl ? v.w : p.w);  // fluid: mass, rigid: rest volume
+    }
+    __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
+    __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
+    __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
+    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
+        if (!AF && META_MAT(meta[i]) != 1) return false;
+        o.m = velm[i].w; o.rho = rho[i];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o.a[k] = 0.0f;
+        o.bx = o.by = o.bz = 0.0f;
+        return true;
+    }
+    __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
+                         const BT &bj, int) const {
+        float g[3];
+        kernGrad(c, dx, dy, dz, fsqrt(r2), g[0], g[1], g[2]);
+        const float R[3] = {dx, dy, dz};
+        float s;
+        if (AF || bj.w >= 0.0f) {
+            const float m_ij = (o.m + a.w) * 0.5f;
+            s = fdiv(fdiv(-c.cv * m_ij, bj.w), r2 + c.visc_eps);
+        } else {
+            const float m_ij = c.rho0 * a.w;
+            s = fdiv(fdiv(-c.cvb * m_ij, o.rho), r2 + c.visc_eps);
+            const float cb = fdiv(fdiv(c.cvb * c.rho0 * a.w, o.rho) * (bj.x * dx + bj.y * dy + bj.z * dz), r2 + c.visc_eps);
+            o.bx += cb * g[0]; o.by += cb * g[1]; o.bz += cb * g[2];
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) o.a[p * 3 + q] -= s * (g[p] * R[q]);
+    }
+    __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {
+        float d[9], inv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) d[k] = ((k % 4 == 0) ? 1.0f : 0.0f) - fdiv(o.a[k] * c.dt, c.rho0);
+        mat3_inverse(d, inv);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dinv[(size_t)i * 9 + k] = inv[k];
+        const float4 v = velm[i];
+        float4 x = cg_x[i];
+        x.x += v.x; x.y += v.y; x.z += v.z;                     // :293 initial guess
+        cg_x[i] = x;
+        cg_v0[i] = make_float4(v.x, v.y, v.z, 0.f);             // :298
+        cg_b[i] = make_float4(v.x - fdiv(c.dt * o.bx, c.rho0), v.y - fdiv(c.dt * o.by, c.rho0), v.z - fdiv(c.dt * o.bz, c.rho0), 0.f);
+        cg_p[i] = x;                                            // :315
+        cg_r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        cg_Ap[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return 0.0f;
+    }
+    __device__ void passive(const Consts &, int i, const float4 &) const {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        cg_r[i] = z; cg_p[i] = z; cg_v0[i] = z; cg_b[i] = z; cg_Ap[i] = z;
+    }
+};
+
+// base_solver.py:374 compute_Ap (+task :386)
+// Bytes / particle: R posv 16 + m 4 + rho 4 + dinv 36 + p 16 -> W Ap 16.
+template <bool AF>
+struct CgApPass {
+    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
+    static constexpr int PAIR_WEIGHT = 1;
+    typedef float4 BT;
+    struct Own { float m; float d[9]; float x, y, z; };
+    const float4 *posv, *velm; const int *meta; const float *rho; const float4 *cg_p; const float *dinv;
+    float4 *cg_Ap; float *red_out;
+
+    __device__ float4 stage_impl(int j, BT &bj) const {
+        const float4 p = posv[j], q = cg_p[j];
+        const float m = velm[j].w;
+        const bool fl = AF || META_MAT(meta[j]) == 1;
+        bj = make_float4(q.x, q.y, q.z, fl ? rho[j] : -1.0f);
+        return make_float4(p.x, p.y, p.z, m);
+    }
+    __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
+    __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
+    __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
+    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
+        if (!AF && META_MAT(meta[i]) != 1) return false;
+        o.m = velm[i].w;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o.d[k] = dinv[(size_t)i * 9 + k];
+        o.x = o.y = o.z = 0.0f;
+        return true;
+    }
+    __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
+                         const BT &bj, int) const {
+        if (!AF && bj.w < 0.0f) return;
+        float g[3];
+        kernGrad(c, dx, dy, dz, fsqrt(r2), g[0], g[1], g[2]);
+        const float m_ij = (o.m + a.w) * 0.5f;
+        const float s = fdiv(fdiv(-c.cv * m_ij, bj.w), r2 + c.visc_eps);
+        const float R[3] = {dx, dy, dz};
+#if SPH_FAST
+        // (-A) = -s g R^T  =>  Dinv (-A) p = -s (R.p) (Dinv g)
+        const float t = -s * (R[0] * bj.x + R[1] * bj.y + R[2] * bj.z);
+        o.x += t * (o.d[0] * g[0] + o.d[1] * g[1] + o.d[2] * g[2]);
+        o.y += t * (o.d[3] * g[0] + o.d[4] * g[1] + o.d[5] * g[2]);
+        o.z += t * (o.d[6] * g[0] + o.d[7] * g[1] + o.d[8] * g[2]);
+#else
+        float nA[9], M[9];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) nA[p * 3 + q] = -(s * (g[p] * R[q]));
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) M[p * 3 + q] = o.d[p * 3] * nA[q] + o.d[p * 3 + 1] * nA[3 + q] + o.d[p * 3 + 2] * nA[6 + q];
+        o.x += M[0] * bj.x + M[1] * bj.y + M[2] * bj.z;
+        o.y += M[3] * bj.x + M[4] * bj.y + M[5] * bj.z;
+        o.z += M[6] * bj.x + M[7] * bj.y + M[8] * bj.z;
+#endif
+    }
+    __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {
+        const float4 p = cg_p[i];
+        float x = o.x * c.dt, y = o.y * c.dt, z = o.z * c.dt;
+        x = fdiv(x, c.rho0); y = fdiv(y, c.rho0); z = fdiv(z, c.rho0);
+        cg_Ap[i] = make_float4(x + p.x, y + p.y, z + p.z, 0.f);
+        return 0.0f;
+    }
+    __device__ void passive(const Consts &, int, const float4 &) const {}
+};
+
+// ---- per-particle vector kernels with fixed-order block reductions -------------------------------
+__device__ __forceinline__ void block_sum2(float a, float b, float *out_a, float *out_b) {
+    __shared__ float s_a[4], s_b[4];
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out_a[blockIdx.x] = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+        out_b[blockIdx.x] = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+    }
+}
+
+__device__ __forceinline__ bool is_fluid(const int *meta, int i, int all_fluid) { return all_fluid || META_MAT(meta[i]) == 1; }
+
+// :318 prepare_conjugate_gradient_solver2
+__global__ void __launch_bounds__(256)
+k_cg_prepare2(int n, const int *meta, int all_fluid, const float *dinv, const float4 *b, const float4 *Ap, float4 *r, float4 *p) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !is_fluid(meta, i, all_fluid)) return;
+    const float *d = dinv + (size_t)i * 9;
+    const float4 bb = b[i], a = Ap[i];
+    const float4 rr = make_float4((d[0] * bb.x + d[1] * bb.y + d[2] * bb.z) - a.x, (d[3] * bb.x + d[4] * bb.y + d[5] * bb.z) - a.y,
+                                  (d[6] * bb.x + d[7] * bb.y + d[8] * bb.z) - a.z, 0.f);
+    r[i] = rr; p[i] = rr;
+}
+
+// :394 compute_cg_alpha, partial sums of |r|^2 and p.Ap
+__global__ void __launch_bounds__(256)
+k_cg_dots(int n, const int *meta, int all_fluid, const float4 *r, const float4 *p, const float4 *Ap, float *part_a, float *part_b) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    float num = 0.f, den = 0.f;
+    if (i < n && is_fluid(meta, i, all_fluid)) {
+        const float4 rr = r[i], pp = p[i], a = Ap[i];
+        num = rr.x * rr.x + rr.y * rr.y + rr.z * rr.z;
+        den = pp.x * a.x + pp.y * a.y + pp.z * a.z;
+    }
+    block_sum2(num, den, part_a, part_b);
+}
+
+// finishes a two-sum reduction; mode 0: alpha = num/den (:403); mode 1: beta = num/den, err = sqrt(num) (:427-431)
+__global__ void __launch_bounds__(256)
+k_cg_scalars(const float *part_a, const float *part_b, int nb, DevScalars *scal, int mode) {
+    __shared__ float s_a[4], s_b[4];
+    float a = 0.f, b = 0.f;
+    for (int k = threadIdx.x; k < nb; k += 256) { a += part_a[k]; b += part_b[k]; }
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float num = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+        const float den = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+        const float q = den > 1e-18f ? num / den : 0.0f;
+        if (mode == 0) scal->red[4] = q;                       // cg_alpha
+        else { scal->red[5] = q; scal->red[3] = __builtin_sqrtf(num); }  // cg_beta, cg_error
+    }
+}
+
+// :409 update_cg_x + :415 update_cg_r_and_beta (partials of |new_r|^2 and |r|^2)
+__global__ void __launch_bounds__(256)
+k_cg_update_xr(int n, const int *meta, int all_fluid, const DevScalars *scal, float4 *x, float4 *r, const float4 *p,
+               const float4 *Ap, float *part_a, float *part_b) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    float num = 0.f, den = 0.f;
+    if (i < n && is_fluid(meta, i, all_fluid)) {
+        const float alpha = scal->red[4];
+        float4 xx = x[i];
+        const float4 pp = p[i], rr = r[i], a = Ap[i];
+        xx.x += alpha * pp.x; xx.y += alpha * pp.y; xx.z += alpha * pp.z;
+        x[i] = xx;
+        const float4 nr = make_float4(rr.x - alpha * a.x, rr.y - alpha * a.y, rr.z - alpha * a.z, 0.f);
+        num = nr.x * nr.x + nr.y * nr.y + nr.z * nr.z;
+        den = rr.x * rr.x + rr.y * rr.y + rr.z * rr.z;
+        r[i] = nr;
+    }
+    block_sum2(num, den, part_a, part_b);
+}
+
+// :434 update_p
+__global__ void __launch_bounds__(256)
+k_cg_update_p(int n, const int *meta, int all_fluid, const DevScalars *scal, const float4 *r, float4 *p) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !is_fluid(meta, i, all_fluid)) return;
+    const float beta = scal->red[5];
+    const float4 rr = r[i];
+    float4 pp = p[i];
+    pp.x = rr.x + beta * pp.x; pp.y = rr.y + beta * pp.y; pp.z = rr.z + beta * pp.z;
+    p[i] = pp;
+}
+
+// :440 prepare_guess
+__global__ void __launch_bounds__(256)
+k_cg_prepare_guess(int n, const int *meta, int all_fluid, float4 *x, const float4 *v0) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !is_fluid(meta, i, all_fluid)) return;
+    float4 xx = x[i];
+    const float4 v = v0[i];
+    xx.x -= v.x; xx.y -= v.y; xx.z -= v.z;
+    x[i] = xx;
+}

@@ -105,6 +105,7 @@ struct State {
     int visc_rho_raw;    // viscosity reads rho_raw (WCSPH: density before the EOS clamp)
     int skip_viscosity;  // implicit viscosity: explicit term not part of the fused pass
     float4 *np_acc_out;  // non-pressure acceleration sink (PCISPH), else null
+    const float4 *np_visc_vel; // velocities for the viscous term (implicit viscosity: cg_x), else null
 };
 
 // Function table implemented twice (strict / fast math), see sph_kernels.hip.
@@ -128,6 +129,14 @@ struct Launch {
     void (*pcisph_init)(State &);
     void (*pcisph_rho_star)(State &);
     void (*pcisph_pressure_accel)(State &);
+    // implicit viscosity (CG)
+    void (*cg_prepare)(State &);
+    void (*cg_ap)(State &);
+    void (*cg_prepare2)(State &);
+    void (*cg_alpha)(State &);
+    void (*cg_update_xr)(State &);
+    void (*cg_update_p)(State &);
+    void (*cg_prepare_guess)(State &);
 };
 
 const Launch *sph_launch_strict();

@@ -15,6 +15,7 @@
 namespace SPH_NS {
 #include "sph_passes.hpp"
 #include "sph_solvers.hpp"
+#include "sph_cg.hpp"
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -84,10 +85,10 @@ void l_density(State &s, int eos) {
 void l_non_pressure(State &s) {
     const float *rho_src = s.visc_rho_raw ? s.rho_raw : s.rho.cur();
     if (s.c.all_fluid) {
-        NonPressurePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), rho_src, s.velm.alt(), s.scal, s.pose, s.c.rho0, s.skip_viscosity, s.np_acc_out};
+        NonPressurePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), rho_src, s.velm.alt(), s.scal, s.pose, s.c.rho0, s.skip_viscosity, s.np_acc_out, s.np_visc_vel};
         launch_pass(s, p);
     } else {
-        NonPressurePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), rho_src, s.velm.alt(), s.scal, s.pose, s.c.rho0, s.skip_viscosity, s.np_acc_out};
+        NonPressurePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), rho_src, s.velm.alt(), s.scal, s.pose, s.c.rho0, s.skip_viscosity, s.np_acc_out, s.np_visc_vel};
         launch_pass(s, p);
     }
     s.velm.flip();

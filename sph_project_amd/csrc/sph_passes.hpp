@@ -71,13 +71,15 @@ struct NonPressurePass {
     const float4 *posv, *velm; const int *meta; const float *rho_raw;
     float4 *vel_out; DevScalars *scal; const RigidPose *pose; float rho0;
     int skip_viscosity;
-    float4 *acc_out;     // PCISPH keeps the non-pressure acceleration (PCISPH.py:22); null otherwise  // implicit viscosity handles the viscous term elsewhere
+    float4 *acc_out;     // PCISPH keeps the non-pressure acceleration (PCISPH.py:22); null otherwise
+    const float4 *visc_vel;  // implicit viscosity: velocities the viscous term is evaluated with (cg_x), else null  // implicit viscosity handles the viscous term elsewhere
 
     __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage_impl(int j, BT &bj) const {
         const float4 p = posv[j];
-        const float4 v = velm[j];
+        float4 v = velm[j];
+        if (visc_vel && (AF || META_MAT(meta[j]) == 1)) { const float4 u = visc_vel[j]; v.x = u.x; v.y = u.y; v.z = u.z; }
         float aw, bw;
         if (AF) { aw = v.w; bw = rho_raw[j]; }
         else {
@@ -92,7 +94,8 @@ struct NonPressurePass {
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
     __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
         if (!AF && META_MAT(meta[i]) != 1) return false;
-        const float4 v = velm[i];
+        float4 v = velm[i];
+        if (visc_vel) { const float4 u = visc_vel[i]; v.x = u.x; v.y = u.y; v.z = u.z; }  // base_solver.py:464
         o.vx = v.x; o.vy = v.y; o.vz = v.z; o.m = v.w;
         o.rho = rho_raw[i];
         o.st_m = fdiv(c.st, v.w);
@@ -135,7 +138,9 @@ struct NonPressurePass {
         ax += o.sx; ay += o.sy; az += o.sz;
         ax += fdiv(o.ax, c.rho0); ay += fdiv(o.ay, c.rho0); az += fdiv(o.az, c.rho0);
         if (acc_out) acc_out[i] = make_float4(ax, ay, az, 0.0f);
-        vel_out[i] = make_float4(o.vx + c.dt * ax, o.vy + c.dt * ay, o.vz + c.dt * az, o.m);
+        float vx = o.vx, vy = o.vy, vz = o.vz;
+        if (visc_vel) { const float4 v = velm[i]; vx = v.x; vy = v.y; vz = v.z; }  // :470 copy_back_original_velocity
+        vel_out[i] = make_float4(vx + c.dt * ax, vy + c.dt * ay, vz + c.dt * az, o.m);
         return 0.0f;
     }
     __device__ void passive(const Consts &, int i, const float4 &) const { vel_out[i] = velm[i]; }

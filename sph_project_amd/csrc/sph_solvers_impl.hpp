@@ -111,7 +111,45 @@ static void l_pcisph_pressure_accel(State &s) {
     }
 }
 
+// ---- implicit viscosity
+static void l_cg_prepare(State &s) {
+    if (s.c.all_fluid) { CgPreparePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p); }
+    else { CgPreparePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p); }
+}
+static void l_cg_ap(State &s) {
+    if (s.c.all_fluid) { CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, s.red_partial}; launch_pass(s, p); }
+    else { CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, s.red_partial}; launch_pass(s, p); }
+}
+static void l_cg_prepare2(State &s) {
+    if (s.c.n == 0) return;
+    hipLaunchKernelGGL(k_cg_prepare2, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_dinv, s.cg_b, s.cg_Ap, s.cg_r, s.cg_p);
+}
+static void l_cg_alpha(State &s) {
+    if (s.c.n == 0) return;
+    const int nb = cdiv(s.c.n, 256);
+    float *pa = s.red_partial, *pb = s.red_partial + s.red_blocks;
+    hipLaunchKernelGGL(k_cg_dots, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_r, s.cg_p, s.cg_Ap, pa, pb);
+    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 0);
+}
+static void l_cg_update_xr(State &s) {
+    if (s.c.n == 0) return;
+    const int nb = cdiv(s.c.n, 256);
+    float *pa = s.red_partial, *pb = s.red_partial + s.red_blocks;
+    hipLaunchKernelGGL(k_cg_update_xr, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap, pa, pb);
+    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 1);
+}
+static void l_cg_update_p(State &s) {
+    if (s.c.n == 0) return;
+    hipLaunchKernelGGL(k_cg_update_p, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_r, s.cg_p);
+}
+static void l_cg_prepare_guess(State &s) {
+    if (s.c.n == 0) return;
+    hipLaunchKernelGGL(k_cg_prepare_guess, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_x, s.cg_v0);
+}
+
 static void register_solver_launchers(Launch &L) {
+    L.cg_prepare = l_cg_prepare; L.cg_ap = l_cg_ap; L.cg_prepare2 = l_cg_prepare2; L.cg_alpha = l_cg_alpha;
+    L.cg_update_xr = l_cg_update_xr; L.cg_update_p = l_cg_update_p; L.cg_prepare_guess = l_cg_prepare_guess;
     L.dfsph_density_alpha = l_dfsph_density_alpha;
     L.dfsph_rho_adv = l_dfsph_rho_adv;
     L.dfsph_correct = l_dfsph_correct;

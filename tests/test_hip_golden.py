@@ -21,14 +21,16 @@ FIELDS = {"positions": L.F_POSITION, "velocities": L.F_VELOCITY, "densities": L.
 ACC_METHODS = ("wcsph", "pcisph")
 
 
+def slot_fluid_now(z, pre):
+    return z[pre + "materials"] == 1
+
+
 @pytest.mark.parametrize("fast_math", [0, 1])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_hip_matches_golden(gpu, path, fast_math):
     z = np.load(path)
     cfg = json.loads(bytes(z["scene_json"]).decode())
     method = cfg["Configuration"]["simulationMethod"]
-    if cfg["Configuration"]["viscosityMethod"] == "implicit":
-        pytest.skip("implicit viscosity: covered by test_hip_implicit.py once built")
     container, solver = H.build_product(cfg, fast_math=fast_math)
     container.insert_object()
     solver.rigid_solver.insert_rigid_object()
@@ -76,6 +78,12 @@ def test_hip_matches_golden(gpu, path, fast_math):
                 mine, ref = mine[fluid], ref[fluid]
             scale = max(float(np.abs(ref).max()), 1e-30)
             worst[key] = float(np.abs(mine.astype(np.float64) - ref.astype(np.float64)).max()) / scale
+        if pre + "cg_x" in z.files:
+            # CG warm start: slot-indexed in the reference (not reordered by the sort) and here; it holds x - v
+            cgx = e.download(L.F_CG_X)
+            vs = max(float(np.abs(z[pre + "velocities"]).max()), 1e-30)
+            worst["cg_x"] = float(np.abs(cgx.astype(np.float64) - z[pre + "cg_x"].astype(np.float64))[slot_fluid_now(z, pre)].max()) / vs
+            assert abs(solver.stats()["iter_cg"] - int(z[pre + "iter_cg"])) <= 2, (solver.stats()["iter_cg"], int(z[pre + "iter_cg"]))
         lim = {"positions": 1e-5, "velocities": 5e-4, "densities": 2e-5, "rest_volumes": 1e-5, "masses": 1e-5}
         for k, v in worst.items():
             assert v < lim.get(k, 5e-3), (cp, k, v, worst)
