@@ -104,7 +104,7 @@ def main():
     cfg = c1_scene(method) if args.config == "c1" else c2_scene(method)
     from tests import helpers as H  # scene -> container/solver exactly like run_simulation.py
     opts = dict(fast_math=0 if args.strict_math else 1, deterministic=0 if args.no_deterministic else 1,
-                force_global=int(args.force_global), device=local_rank if world > 1 else -1)
+                force_global=int(os.environ.get('SPH_DEBUG_MODE', int(args.force_global))), device=local_rank if world > 1 else -1)
     if method != "wcsph":
         opts["fixed_iterations"] = 2
     container, solver = H.build_product(cfg, **opts)

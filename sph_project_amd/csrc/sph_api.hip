@@ -95,6 +95,7 @@ static void fill_consts(SphHandle *h) {
     c.grid_size = (float)hd;
     c.h = (float)hd;
     c.h2 = c.h * c.h;
+    c.inv_h = 1.0f / c.h;
     float k = (float)(8.0 / M_PI);
     c.kW = k / (float)(hd * hd * hd);
     c.kG = 6.0f * k / (float)(hd * hd * hd);
@@ -442,8 +443,10 @@ static void step_begin(SphHandle *h) {
 static int read_scalars(SphHandle *h) {
     HIPCHK(h, hipMemcpyAsync(h->scal_h, h->st.scal, sizeof(DevScalars), hipMemcpyDeviceToHost, h->st.stream));
     HIPCHK(h, hipStreamSynchronize(h->st.stream));
-    h->last.pair_interactions = (int64_t)h->scal_h->pairs;
-    h->last.lds_fallback_blocks = (int64_t)h->scal_h->fallback;
+    unsigned long long pairs = 0, fb = 0;
+    for (int k = 0; k < SPH_STAT_SLOTS; ++k) { pairs += h->scal_h->pairs[k]; fb += h->scal_h->fallback[k]; }
+    h->last.pair_interactions = (int64_t)pairs;
+    h->last.lds_fallback_blocks = (int64_t)fb;
     return SPH_OK;
 }
 

@@ -20,7 +20,7 @@ __device__ __forceinline__ void mat3_inverse(const float *a, float *o) {
 // Bytes / particle: R posv 16 + velm 16 + rho 4 + cg_x 16 -> W dinv 36 + b 16 + p 16 + x 16 + v0 16 (+ zero fills).
 template <bool AF>
 struct CgPreparePass {
-    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr int BLOCK = 64, CAP = 288, GROUPS = 3;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 2;  // A_ii pass + b_i pass of the reference
     typedef float4 BT;
@@ -49,7 +49,7 @@ struct CgPreparePass {
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int) const {
         float g[3];
-        kernGrad(c, dx, dy, dz, fsqrt(r2), g[0], g[1], g[2]);
+        kernGrad(c, dx, dy, dz, geom(c, r2), g[0], g[1], g[2]);
         const float R[3] = {dx, dy, dz};
         float s;
         if (AF || bj.w >= 0.0f) {
@@ -94,7 +94,7 @@ struct CgPreparePass {
 // Bytes / particle: R posv 16 + m 4 + rho 4 + dinv 36 + p 16 -> W Ap 16.
 template <bool AF>
 struct CgApPass {
-    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr int BLOCK = 64, CAP = 288, GROUPS = 3;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 1;
     typedef float4 BT;
@@ -124,7 +124,7 @@ struct CgApPass {
                          const BT &bj, int) const {
         if (!AF && bj.w < 0.0f) return;
         float g[3];
-        kernGrad(c, dx, dy, dz, fsqrt(r2), g[0], g[1], g[2]);
+        kernGrad(c, dx, dy, dz, geom(c, r2), g[0], g[1], g[2]);
         const float m_ij = (o.m + a.w) * 0.5f;
         const float s = fdiv(fdiv(-c.cv * m_ij, bj.w), r2 + c.visc_eps);
         const float R[3] = {dx, dy, dz};

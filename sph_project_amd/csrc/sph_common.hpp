@@ -26,7 +26,7 @@
 struct Consts {
     int nx, ny, nz, G;
     float grid_size;        // f32(dh): cell size
-    float h, h2;            // support radius, squared
+    float h, h2, inv_h;     // support radius, squared, reciprocal (fast build)
     float kW, kG;           // cubic spline constants (base_solver.py:57, :81)
     float W0, Wd;           // kernel_W(0), kernel_W(particle diameter)
     float diameter2;
@@ -44,9 +44,10 @@ struct Consts {
 };
 
 // Device-side scalar block (zeroed / read back by the host)
+#define SPH_STAT_SLOTS 2048  // statistics are striped over many words: ~20k same-address atomics per launch cost >200 us
 struct DevScalars {
-    unsigned long long pairs;        // accepted pairs of the running step
-    unsigned long long fallback;     // LDS-overflow workgroups
+    unsigned long long pairs[SPH_STAT_SLOTS];     // accepted pairs of the running step (sum over slots)
+    unsigned long long fallback[SPH_STAT_SLOTS];  // neighbour runs that did not fit the LDS tile
     float wrench[2 * SPH_NOBJ * 3];  // rigid_body_forces, rigid_body_torques
     float red[8];                    // reduction results (errors, CG dots)
     int   flags[4];

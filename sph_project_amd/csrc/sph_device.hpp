@@ -14,6 +14,7 @@
 // (deterministic=1) the strict build reproduces the oracle's summation order.
 #pragma once
 #include "sph_common.hpp"
+#include <limits.h>
 
 #ifndef SPH_FAST
 #define SPH_FAST 0
@@ -44,10 +45,36 @@ __device__ __forceinline__ int cell_coord(float x, float gs, int n) {
     return c;
 }
 
+// Per-pair geometry shared by kernel_W / kernel_gradient.  Strict build: rn = sqrt(r2), q = rn / h (IEEE).
+// Fast build: one v_rsq_f32 gives 1/rn; rn = r2 * (1/rn), q = rn * (1/h), 1/(rn h) = (1/rn)(1/h).
+struct Geom { float rn, q, inv_rnh; };
+__device__ __forceinline__ Geom geom(const Consts &c, float r2) {
+    Geom g;
+#if SPH_FAST
+    const float rinv = __builtin_amdgcn_rsqf(fmaxf(r2, 1e-30f));
+    g.rn = r2 * rinv;
+    g.q = g.rn * c.inv_h;
+    g.inv_rnh = rinv * c.inv_h;
+#else
+    g.rn = __builtin_sqrtf(r2);
+    g.q = g.rn / c.h;
+    g.inv_rnh = 0.0f;  // unused
+#endif
+    return g;
+}
+
 // base_solver.py:57 kernel_W.  pow(1-q, 3.0) is evaluated as t*t*t (<= 2 ulp from powf).
-__device__ __forceinline__ float kernW(const Consts &c, float r) {
+__device__ __forceinline__ float kernW(const Consts &c, const Geom &g) {
     float res = 0.0f;
-    float q = fdiv(r, c.h);
+    const float q = g.q;
+#if SPH_FAST
+    // branch-free (accepted pairs have q < 1): both pieces evaluated, one v_cndmask
+    const float t = 1.0f - q;
+    const float lo = 1.0f - 6.0f * (q * q) * t;   // = 6q^3 - 6q^2 + 1
+    const float hi = 2.0f * (t * t * t);
+    res = c.kW * (q <= 0.5f ? lo : hi);
+    return q <= 1.0f ? res : 0.0f;
+#endif
     if (q <= 1.0f) {
         if (q <= 0.5f) {
             float q2 = q * q;
@@ -61,20 +88,29 @@ __device__ __forceinline__ float kernW(const Consts &c, float r) {
     return res;
 }
 
-// base_solver.py:81 kernel_gradient; R = x_i - x_j, rn = |R|
-__device__ __forceinline__ void kernGrad(const Consts &c, float dx, float dy, float dz, float rn,
+// base_solver.py:81 kernel_gradient; R = x_i - x_j
+__device__ __forceinline__ void kernGrad(const Consts &c, float dx, float dy, float dz, const Geom &g,
                                          float &gx, float &gy, float &gz) {
     gx = gy = gz = 0.0f;
-    float q = fdiv(rn, c.h);
-    if (rn > 1e-5f && q <= 1.0f) {
+    const float q = g.q;
+#if SPH_FAST
+    {
+        const float f = 1.0f - q;
+        float s = c.kG * (q <= 0.5f ? q * (3.0f * q - 2.0f) : -f * f);
+        s = (g.rn > 1e-5f && q <= 1.0f) ? s * g.inv_rnh : 0.0f;
+        gx = s * dx; gy = s * dy; gz = s * dz;
+        return;
+    }
+#endif
+    if (g.rn > 1e-5f && q <= 1.0f) {
         float s;
         if (q <= 0.5f) s = c.kG * q * (3.0f * q - 2.0f);
         else { float f = 1.0f - q; s = c.kG * (-f * f); }
 #if SPH_FAST
-        float inv = __builtin_amdgcn_rcpf(rn * c.h);
-        gx = s * (dx * inv); gy = s * (dy * inv); gz = s * (dz * inv);
+        const float si = s * g.inv_rnh;
+        gx = si * dx; gy = si * dy; gz = si * dz;
 #else
-        float den = rn * c.h;
+        float den = g.rn * c.h;
         gx = s * (dx / den); gy = s * (dy / den); gz = s * (dz / den);
 #endif
     }
@@ -240,28 +276,105 @@ k_scatter(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
 }
 
 // ------------------------------------------------------------------ generic neighbour pass
-template <bool LDS, class P>
-__device__ __forceinline__ void nbr_loop(const Consts &c, const int *__restrict__ cell_start, const P &p,
-                                         typename P::Own &own, int i, float xi, float yi, float zi,
-                                         int cx, int cy, int cz, const float4 *sA,
-                                         const typename P::BT *sB, const int *s_rs, const int *s_base,
-                                         unsigned &npairs) {
-    const int z0 = cz > 0 ? cz - 1 : 0;
-    const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
-    for (int k = 0; k < 9; ++k) {
-        const int xx = cx + k / 3 - 1, yy = cy + k % 3 - 1;
-        if (xx < 0 || xx >= c.nx || yy < 0 || yy >= c.ny) continue;
-        const int lin0 = (xx * c.ny + yy) * c.nz + z0;
-        const int js = cell_start[lin0];
-        const int je = cell_start[lin0 + (z1 - z0) + 1];
-        const int loff = LDS ? (s_base[k] - s_rs[k]) : 0;
+// One (ox, oy) run of one lane: candidates [js, je) of the sorted arrays; LDS index = j + loff.
+// LDS tile layout: two float2 arrays (x,y) and (z,w).  ds_read_b64 is serviced in two 32-lane groups
+// with a 64-bank modulus, so lanes of neighbouring cells (8 particles = 64 B apart) hit disjoint
+// banks and lanes of one cell broadcast: phase 1 costs 2 x 2 LDS cycles per candidate, conflict-free
+// for typical cell populations (a float4 tile read as b128/b96 is 2-way conflicted at 8 per cell).
+#define NBR_PAD 40   // phase 1 may read up to 32+7 slots past a lane's run (masked afterwards)
+typedef float v2f __attribute__((ext_vector_type(2)));
+// 8 candidates = 16 ds_read_b64 (x,y) / (z,w) from `a` + 8u and `a` + zw_off + 8u, one s_waitcnt at the end.
+template <int ZW_OFF>
+__device__ __forceinline__ void lds_load_chunk_imm(unsigned a, v2f (&xy)[8], v2f (&zw)[8]) {
+    asm volatile(
+        "ds_read_b64 %0, %16\n\tds_read_b64 %8, %16 offset:%17\n\t"
+        "ds_read_b64 %1, %16 offset:8\n\tds_read_b64 %9, %16 offset:%17+8\n\t"
+        "ds_read_b64 %2, %16 offset:16\n\tds_read_b64 %10, %16 offset:%17+16\n\t"
+        "ds_read_b64 %3, %16 offset:24\n\tds_read_b64 %11, %16 offset:%17+24\n\t"
+        "ds_read_b64 %4, %16 offset:32\n\tds_read_b64 %12, %16 offset:%17+32\n\t"
+        "ds_read_b64 %5, %16 offset:40\n\tds_read_b64 %13, %16 offset:%17+40\n\t"
+        "ds_read_b64 %6, %16 offset:48\n\tds_read_b64 %14, %16 offset:%17+48\n\t"
+        "ds_read_b64 %7, %16 offset:56\n\tds_read_b64 %15, %16 offset:%17+56\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(xy[0]), "=&v"(xy[1]), "=&v"(xy[2]), "=&v"(xy[3]), "=&v"(xy[4]), "=&v"(xy[5]), "=&v"(xy[6]), "=&v"(xy[7]),
+          "=&v"(zw[0]), "=&v"(zw[1]), "=&v"(zw[2]), "=&v"(zw[3]), "=&v"(zw[4]), "=&v"(zw[5]), "=&v"(zw[6]), "=&v"(zw[7])
+        : "v"(a), "n"(ZW_OFF)
+        : "memory");
+}
+typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+typedef __attribute__((address_space(3))) const int lds_ci32;
+__device__ __forceinline__ int lds_ld_i32(const int *p) { return *(lds_ci32 *)p; }
+__device__ __forceinline__ unsigned lds_addr(const float2 *p) { return (unsigned)(size_t)(lds_cu64 *)p; }
+__device__ __forceinline__ float2 lds_ld2a(unsigned byte_addr) {  // plain (schedulable) ds_read_b64 from an LDS byte address
+    const unsigned long long v = *(lds_cu64 *)(size_t)byte_addr;
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+// volatile 64-bit LDS load: keeps the backend from fusing neighbouring reads into ds_read2_b64
+// (16 B per lane at 8 cycles, 32-bank modulus) -- two plain ds_read_b64 cost 2 cycles each.
+__device__ __forceinline__ float2 lds_ld2(const float2 *p) {
+    typedef const volatile __attribute__((address_space(3))) unsigned long long *lds_u64;
+    const unsigned long long v = *(lds_u64)(p);
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+template <bool LDS, int ZW_OFF, class P>
+__device__ __forceinline__ void process_run(const Consts &c, const P &p, typename P::Own &own, int i, float xi,
+                                            float yi, float zi, int js, int je, int loff, const float2 *sXY,
+                                            const float2 *sZW, const typename P::BT *sB, int cap,
+                                            unsigned &npairs) {
+    if (LDS) {
+        for (int j0 = js; __any(j0 < je); j0 += 32) {  // wave-uniform trip count
+            int m = je - j0;
+            m = m < 0 ? 0 : (m > 32 ? 32 : m);
+            int base = j0 + loff;
+            base = base > cap ? cap : base;            // lanes already past their run stay inside the tile
+            // Phase 1.  The acceptance bit of every slot is shifted into `mask` from the right by
+            // v_cmp (-> VCC) + v_addc_co (mask = 2 mask + VCC): two VOPC/VOP2 instructions per slot, no
+            // SGPR-pair results, no shift constants.  After S pushes slot t sits at bit S-1-t.
+            unsigned mask = 0;
+            int S = 0;
+            for (int t0 = 0; __any(t0 < m); t0 += 8) {
+                // All 16 ds_read_b64 of the chunk are issued back to back from one base register with
+                // immediate offsets and waited for once (hand-placed: left to itself the scheduler keeps at most
+                // one candidate in flight, or fuses neighbours into ds_read2_b64 = 8 LDS cycles per 16 bytes).
+                v2f xy[8], zw[8];
+                lds_load_chunk_imm<ZW_OFF>(lds_addr(&sXY[base + t0]), xy, zw);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zw[u].x;
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                        : "+v"(mask) : "v"(r2), "v"(c.h2) : "vcc");  // not volatile: ordered by the dependence on mask
+                }
+                S += 8;
+            }
+            // drop slots past this lane's run (low S-m bits) and the lane's own particle
+            const int drop = S - m;
+            mask = drop >= 32 ? 0u : (mask >> drop) << drop;
+            const unsigned self = (unsigned)(i - j0);
+            if (self < (unsigned)m) mask &= ~(1u << (S - 1 - (int)self));   // p_i != p_j (base_container.py:559)
+            npairs += __popc(mask);
+            if (c.force_global == 2) mask = 0;  // debug: phase 1 only
+            while (mask) {
+                const int pos = 31 - __clz(mask);
+                mask &= ~(1u << pos);
+                const int t = S - 1 - pos;       // ascending t: same accumulation order as the reference
+                const float2 xy = sXY[base + t];
+                const float2 zw = sZW[base + t];
+                const float dx = xi - xy.x, dy = yi - xy.y, dz = zi - zw.x;
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                typename P::BT bj = typename P::BT();
+                if (P::HAS_B) bj = sB[base + t];
+                p.pair(c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, j0 + t);
+            }
+        }
+    } else {
         for (int j0 = js; j0 < je; j0 += 32) {
             const int m = (je - j0) < 32 ? (je - j0) : 32;
             unsigned mask = 0;
 #pragma unroll 4
             for (int t = 0; t < m; ++t) {
                 const int j = j0 + t;
-                const float4 a = LDS ? sA[j + loff] : p.loadA(j);
+                const float4 a = p.loadA(j);
                 const float dx = xi - a.x, dy = yi - a.y, dz = zi - a.z;
                 const float r2 = dx * dx + dy * dy + dz * dz;
                 const unsigned ok = (r2 < c.h2 && j != i) ? 1u : 0u;
@@ -272,26 +385,35 @@ __device__ __forceinline__ void nbr_loop(const Consts &c, const int *__restrict_
                 const int t = __ffs(mask) - 1;
                 mask &= mask - 1;
                 const int j = j0 + t;
-                const float4 a = LDS ? sA[j + loff] : p.loadA(j);
+                const float4 a = p.loadA(j);
                 const float dx = xi - a.x, dy = yi - a.y, dz = zi - a.z;
                 const float r2 = dx * dx + dy * dy + dz * dz;
                 typename P::BT bj = typename P::BT();
-                if (P::HAS_B) bj = LDS ? sB[j + loff] : p.loadB(j);
+                if (P::HAS_B) bj = p.loadB(j);
                 p.pair(c, own, dx, dy, dz, r2, a, bj, j);
             }
         }
     }
 }
 
+#define NBR_CS_SPAN 28
+#define NBR_BLOCK 64  // cell_start window cached in LDS per run: cells [first-1, last+1] (+ end) of the workgroup
+
 template <class P>
 __global__ void __launch_bounds__(P::BLOCK)
 k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevScalars *__restrict__ scal,
            int nblocks) {
     constexpr int BLOCK = P::BLOCK;
-    constexpr int CAP = P::CAP;
-    __shared__ float4 sA[CAP];
-    __shared__ typename P::BT sB[P::HAS_B ? CAP : 1];
-    __shared__ int s_rs[9], s_len[9], s_base[10], s_c[2], s_any;
+    constexpr int CAP = P::CAP;          // LDS particle slots per staging group
+    constexpr int GROUPS = P::GROUPS;    // 1: all nine runs staged at once; 3: one x-offset (3 runs) at a time
+    constexpr int RPG = 9 / GROUPS;
+    __shared__ float2 sT[2 * (CAP + NBR_PAD)];   // (x,y) slots followed by (z,w) slots: fixed byte distance
+    float2 *const sXY = sT;
+    float2 *const sZW = sT + (CAP + NBR_PAD);
+    constexpr int ZW_OFF = (CAP + NBR_PAD) * 8;
+    __shared__ typename P::BT sB[P::HAS_B ? CAP + NBR_PAD : 1];
+    __shared__ int s_cs[9][NBR_CS_SPAN + 4];
+    __shared__ int s_rs[9], s_len[9], s_loff[9], s_c[2], s_any, s_tot;
 
     const int tid = threadIdx.x;
     const int b = xcd_remap(blockIdx.x, nblocks);
@@ -303,7 +425,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     typename P::Own own;
     bool active = false;
-    int cx = 0, cy = 0, cz = 0;
+    int cx = 0, cy = 0, cz = 0, lin = 0;
     if (tid == 0) s_any = 0;
     __syncthreads();
     if (valid) {
@@ -311,7 +433,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         cx = cell_coord(pi.x, c.grid_size, c.nx);
         cy = cell_coord(pi.y, c.grid_size, c.ny);
         cz = cell_coord(pi.z, c.grid_size, c.nz);
-        const int lin = (cx * c.ny + cy) * c.nz + cz;
+        lin = (cx * c.ny + cy) * c.nz + cz;
         if (tid == 0) s_c[0] = lin;
         if (tid == nvalid - 1) s_c[1] = lin;
         active = p.begin(c, i, pi, own);
@@ -319,9 +441,12 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     }
     __syncthreads();
     if (s_any) {  // workgroup-uniform
+        const int cfirst = s_c[0], clast = s_c[1];
+        const int span = clast - cfirst;
+        const bool cs_lds = span <= NBR_CS_SPAN;  // workgroup-uniform
         if (tid < 9) {
             const int shift = (tid / 3 - 1) * c.ny * c.nz + (tid % 3 - 1) * c.nz;
-            int lo = s_c[0] + shift - 1, hi = s_c[1] + shift + 1;
+            int lo = cfirst + shift - 1, hi = clast + shift + 1;
             int rs = 0, re = 0;
             if (hi >= 0 && lo <= c.G - 1) {
                 lo = lo < 0 ? 0 : lo;
@@ -332,40 +457,79 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             s_rs[tid] = rs;
             s_len[tid] = re - rs;
         }
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0;
-            for (int k = 0; k < 9; ++k) { s_base[k] = acc; acc += s_len[k]; }
-            s_base[9] = acc;
+        if (cs_lds) {  // cache the cell_start window of every run: entry e <-> cell (cfirst + shift - 1 + e)
+            const int per = span + 4;
+            for (int t = tid; t < 9 * per; t += BLOCK) {
+                const int k = t / per, e = t - k * per;
+                int cell = cfirst + (k / 3 - 1) * c.ny * c.nz + (k % 3 - 1) * c.nz - 1 + e;
+                cell = cell < 0 ? 0 : (cell > c.G ? c.G : cell);
+                s_cs[k][e] = cell_start[cell];
+            }
         }
         __syncthreads();
-        const int total = s_base[9];
-        const bool use_lds = (total <= CAP) && !c.force_global;
+        // this lane's z window
+        const int z0 = cz > 0 ? cz - 1 : 0;
+        const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
         unsigned npairs = 0;
-        if (use_lds) {
-            int base[10];
-#pragma unroll
-            for (int k = 0; k < 10; ++k) base[k] = s_base[k];
-            for (int t = tid; t < total; t += BLOCK) {
-                int k = 0;
-#pragma unroll
-                for (int q = 1; q < 9; ++q) k += t >= base[q] ? 1 : 0;
-                const int j = s_rs[k] + (t - s_base[k]);
-                typename P::BT bj = typename P::BT();
-                sA[t] = p.stage(c, j, bj);
-                if (P::HAS_B) sB[t] = bj;
+        for (int g = 0; g < GROUPS; ++g) {
+            if (tid == 0) {
+                int acc = 0;
+                for (int k = g * RPG; k < g * RPG + RPG; ++k) {
+                    if (c.force_global != 1 && acc + s_len[k] <= CAP) { s_loff[k] = acc - s_rs[k]; acc += s_len[k]; }
+                    else { s_loff[k] = INT_MIN; if (s_len[k] > 0) atomicAdd(&scal->fallback[b & (SPH_STAT_SLOTS - 1)], 1ull); }
+                }
+                s_tot = acc;
             }
             __syncthreads();
-            if (active)
-                nbr_loop<true>(c, cell_start, p, own, i, pi.x, pi.y, pi.z, cx, cy, cz, sA, sB, s_rs, s_base, npairs);
-        } else {
-            if (tid == 0) atomicAdd(&scal->fallback, 1ull);
-            if (active)
-                nbr_loop<false>(c, cell_start, p, own, i, pi.x, pi.y, pi.z, cx, cy, cz, sA, sB, s_rs, s_base, npairs);
+            {   // stage the runs of this group that fit (coalesced: consecutive t -> consecutive j)
+                const int total = s_tot;
+                int rs_[RPG], lo_[RPG], ln_[RPG];
+#pragma unroll
+                for (int q = 0; q < RPG; ++q) { rs_[q] = s_rs[g * RPG + q]; lo_[q] = s_loff[g * RPG + q]; ln_[q] = s_len[g * RPG + q]; }
+                for (int t = tid; t < total; t += BLOCK) {
+                    int j = -1;
+#pragma unroll
+                    for (int q = 0; q < RPG; ++q) {
+                        if (lo_[q] != INT_MIN) { const int jj = t - lo_[q]; if (jj >= rs_[q] && jj < rs_[q] + ln_[q]) j = jj; }
+                    }
+                    typename P::BT bj = typename P::BT();
+                    const float4 a = p.stage(c, j, bj);
+                    sXY[t] = make_float2(a.x, a.y);
+                    sZW[t] = make_float2(a.z, a.w);
+                    if (P::HAS_B) sB[t] = bj;
+                }
+            }
+            __syncthreads();
+            if (active && c.force_global != 3) {  // 3 = debug: staging only
+#pragma unroll 1
+                for (int k = g * RPG; k < g * RPG + RPG; ++k) {
+                    const int xx = cx + k / 3 - 1, yy = cy + k % 3 - 1;
+                    if (xx < 0 || xx >= c.nx || yy < 0 || yy >= c.ny) continue;
+                    int js, je;
+                    if (cs_lds) {
+                        const int e = (lin - cfirst) + (z0 - cz) + 1;
+                        // explicit LDS loads: a plain s_cs[k][e] here gets merged with the global branch below
+                        // into ONE flat load through a generic pointer -- measured 200 us of a 280 us pass.
+                        js = lds_ld_i32(&s_cs[k][e]);
+                        je = lds_ld_i32(&s_cs[k][e + (z1 - z0) + 1]);
+                    } else {
+                        const int lin0 = (xx * c.ny + yy) * c.nz + z0;
+                        js = cell_start[lin0];
+                        je = cell_start[lin0 + (z1 - z0) + 1];
+                    }
+                    const int loff = s_loff[k];
+                    if (c.force_global == 6) { npairs += (unsigned)(je - js); continue; }  // debug: run setup only
+                    // s_loff is workgroup-uniform, so every lane of the wave takes the same branch (process_run uses __any)
+                    if (loff != INT_MIN) process_run<true, ZW_OFF>(c, p, own, i, pi.x, pi.y, pi.z, js, je, loff, sXY, sZW, sB, CAP, npairs);
+                    else process_run<false, ZW_OFF>(c, p, own, i, pi.x, pi.y, pi.z, js, je, 0, sXY, sZW, sB, CAP, npairs);
+                }
+            }
+            if (GROUPS > 1) __syncthreads();  // LDS is restaged by the next group
         }
         if (P::COUNT_PAIRS) {
             float fp = wave_sum((float)npairs);  // <= 64 * few hundred: exact in f32
-            if ((tid & 63) == 0 && fp > 0.0f) atomicAdd(&scal->pairs, (unsigned long long)fp * P::PAIR_WEIGHT);
+            if ((tid & 63) == 0 && fp > 0.0f)
+                atomicAdd(&scal->pairs[(b * (BLOCK / 64) + (tid >> 6)) & (SPH_STAT_SLOTS - 1)], (unsigned long long)fp * P::PAIR_WEIGHT);
         }
     }
     float red = 0.0f;

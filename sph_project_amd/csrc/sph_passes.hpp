@@ -17,7 +17,7 @@ __device__ __forceinline__ void add_wrench(DevScalars *scal, int obj, float fx, 
 // Algorithmic HBM bytes / particle: R posv 16 -> W rho 4 (+ rho_raw 4, prs 4, ptm 4 with EOS).
 template <bool AF, bool EOS>
 struct DensityPass {
-    static constexpr int BLOCK = 256, CAP = 4096;
+    static constexpr int BLOCK = 64, CAP = 288, GROUPS = 3;
     static constexpr bool HAS_B = false, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 1;
     static constexpr bool HAS_REDUCE = false;
@@ -35,7 +35,7 @@ struct DensityPass {
     }
     __device__ void pair(const Consts &c, Own &o, float, float, float, float r2, const float4 &a, const BT &,
                          int) const {
-        o.sum += a.w * kernW(c, fsqrt(r2));
+        o.sum += a.w * kernW(c, geom(c, r2));
     }
     __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
         float den = pi.w * c.W0;
@@ -62,7 +62,7 @@ struct DensityPass {
 // Bytes / particle: R posv 16 + velm 16 + rho_raw 4 -> W velm 16.
 template <bool AF>
 struct NonPressurePass {
-    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr int BLOCK = 64, CAP = 288, GROUPS = 3;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 2;  // surface tension (:210) + viscosity (:232) = two reference passes
     static constexpr bool HAS_REDUCE = false;
@@ -105,24 +105,29 @@ struct NonPressurePass {
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int j) const {
-        const float rn = fsqrt(r2);
+        const Geom g = geom(c, r2);
+#if SPH_FAST
+        const float rn2 = r2;               // base_solver.py:254 R.norm()**2
+#else
+        const float rn2 = g.rn * g.rn;
+#endif
         float gx, gy, gz;
         if (AF || bj.w >= 0.0f) {
             // surface tension
             const float cst = o.st_m * a.w;
-            const float w = r2 > c.diameter2 ? kernW(c, rn) : c.Wd;
+            const float w = r2 > c.diameter2 ? kernW(c, g) : c.Wd;
             o.sx -= (cst * dx) * w; o.sy -= (cst * dy) * w; o.sz -= (cst * dz) * w;
             if (skip_viscosity) return;
-            kernGrad(c, dx, dy, dz, rn, gx, gy, gz);
+            kernGrad(c, dx, dy, dz, g, gx, gy, gz);
             const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
             const float m_ij = (o.m + a.w) * 0.5f;
-            const float cc = fdiv(fdiv(c.cv * m_ij, bj.w), rn * rn + c.visc_eps) * v_xy;
+            const float cc = fdiv(fdiv(c.cv * m_ij, bj.w), rn2 + c.visc_eps) * v_xy;
             o.ax += cc * gx; o.ay += cc * gy; o.az += cc * gz;
         } else {
             if (skip_viscosity) return;
-            kernGrad(c, dx, dy, dz, rn, gx, gy, gz);
+            kernGrad(c, dx, dy, dz, g, gx, gy, gz);
             const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
-            const float cc = fdiv(fdiv(c.cvb * a.w, o.rho), rn * rn + c.visc_eps) * v_xy;
+            const float cc = fdiv(fdiv(c.cvb * a.w, o.rho), rn2 + c.visc_eps) * v_xy;
             const float acx = cc * gx, acy = cc * gy, acz = cc * gz;
             o.ax += acx; o.ay += acy; o.az += acz;
             if (bj.w == -2.0f) {  // dynamic rigid neighbour: base_solver.py:272-278
@@ -171,7 +176,7 @@ __device__ __forceinline__ void enforce_boundary(const Consts &c, float &x, floa
 // Bytes / particle: R posv 16 + velm 16 + ptm 4 -> W acc 16 + posv 16 + velm 16.
 template <bool AF>
 struct PressurePass {
-    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr int BLOCK = 64, CAP = 288, GROUPS = 3;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 1;
     static constexpr bool HAS_REDUCE = false;
@@ -205,9 +210,9 @@ struct PressurePass {
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int j) const {
-        const float rn = fsqrt(r2);
+        const Geom g = geom(c, r2);
         float gx, gy, gz;
-        kernGrad(c, dx, dy, dz, rn, gx, gy, gz);
+        kernGrad(c, dx, dy, dz, g, gx, gy, gz);
         if (AF || bj >= 0.0f) {
             const float cc = -a.w * (o.pt + bj);
             o.ax += cc * gx; o.ay += cc * gy; o.az += cc * gz;
@@ -243,7 +248,7 @@ struct PressurePass {
 // ---------------------------------------------------------------------------------------
 // base_solver.py:106 compute_rigid_particle_volume (+task :117).  i rigid, j same object.
 struct RigidVolumePass {
-    static constexpr int BLOCK = 256, CAP = 4096;
+    static constexpr int BLOCK = 64, CAP = 288, GROUPS = 3;
     static constexpr bool HAS_B = false, COUNT_PAIRS = false;
     static constexpr int PAIR_WEIGHT = 0;
     static constexpr bool HAS_REDUCE = false;
@@ -269,7 +274,7 @@ struct RigidVolumePass {
     }
     __device__ void pair(const Consts &c, Own &o, float, float, float, float r2, const float4 &a, const BT &,
                          int) const {
-        if (__float_as_int(a.w) == o.obj) o.sum += kernW(c, fsqrt(r2));
+        if (__float_as_int(a.w) == o.obj) o.sum += kernW(c, geom(c, r2));
     }
     __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
         const float V = 1.0f / o.sum;

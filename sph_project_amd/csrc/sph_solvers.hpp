@@ -8,7 +8,7 @@
 // Bytes / particle: R posv 16 -> W rho 4 + alpha 4.
 template <bool AF>
 struct DfsphDensityAlphaPass {
-    static constexpr int BLOCK = 256, CAP = 4096;
+    static constexpr int BLOCK = 64, CAP = 288, GROUPS = 3;
     static constexpr bool HAS_B = false, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 2;  // density pass + alpha pass of the reference
     typedef int BT;
@@ -29,11 +29,11 @@ struct DfsphDensityAlphaPass {
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a, const BT &,
                          int) const {
-        const float rn = fsqrt(r2);
+        const Geom g = geom(c, r2);
         const float V = fabsf(a.w);
-        o.sum += V * kernW(c, rn);
+        o.sum += V * kernW(c, g);
         float gx, gy, gz;
-        kernGrad(c, dx, dy, dz, rn, gx, gy, gz);
+        kernGrad(c, dx, dy, dz, g, gx, gy, gz);
         const float px = -V * gx, py = -V * gy, pz = -V * gz;
         if (AF || a.w > 0.0f) o.s3 += px * px + py * py + pz * pz;
         o.gx += px; o.gy += py; o.gz += pz;
@@ -57,7 +57,7 @@ struct DfsphDensityAlphaPass {
 // Bytes / particle: R posv 16 + velm 16 (+rho, alpha 8) -> W 8.
 template <bool AF, int MODE>
 struct DfsphRhoAdvPass {
-    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr int BLOCK = 64, CAP = 288, GROUPS = 3;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
     static constexpr int PAIR_WEIGHT = 1;
     typedef float4 BT;
@@ -77,7 +77,7 @@ struct DfsphRhoAdvPass {
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int) const {
         float gx, gy, gz;
-        kernGrad(c, dx, dy, dz, fsqrt(r2), gx, gy, gz);
+        kernGrad(c, dx, dy, dz, geom(c, r2), gx, gy, gz);
         o.sum += a.w * ((o.vx - bj.x) * gx + (o.vy - bj.y) * gy + (o.vz - bj.z) * gz);
         o.cnt += 1;
     }
@@ -105,7 +105,7 @@ struct DfsphRhoAdvPass {
 // Bytes / particle: R posv 16 + kappa 4 + rho 4 + velm 16 -> W velm 16.
 template <bool AF, int MODE>
 struct DfsphCorrectPass {
-    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr int BLOCK = 64, CAP = 288, GROUPS = 3;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 1;
     typedef float2 BT;
@@ -139,13 +139,13 @@ struct DfsphCorrectPass {
         if (AF || a.w > 0.0f) {
             const float ks = o.k + bj.x;
             if (fabsf(ks) > c.thr_kappa) {
-                kernGrad(c, dx, dy, dz, fsqrt(r2), gx, gy, gz);
+                kernGrad(c, dx, dy, dz, geom(c, r2), gx, gy, gz);
                 const float cc = fdiv(o.k, o.rho) + fdiv(bj.x, bj.y);
                 o.vx -= ((a.w * gx) * cc) * c.rho0; o.vy -= ((a.w * gy) * cc) * c.rho0; o.vz -= ((a.w * gz) * cc) * c.rho0;
             }
         } else {
             if (fabsf(o.k) > c.thr_kappa) {
-                kernGrad(c, dx, dy, dz, fsqrt(r2), gx, gy, gz);
+                kernGrad(c, dx, dy, dz, geom(c, r2), gx, gy, gz);
                 const float V = -a.w;
                 const float cc = fdiv(o.k, o.rho);
                 const float tx = ((V * gx) * cc) * c.rho0, ty = ((V * gy) * cc) * c.rho0, tz = ((V * gz) * cc) * c.rho0;
@@ -177,7 +177,7 @@ struct DfsphCorrectPass {
 // Bytes / particle: R posv 16 + ppos 16 + prs 4 + rho 4 -> W rho_star 4 + prs 4 + ptm 4.
 template <bool AF>
 struct PcisphRhoStarPass {
-    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr int BLOCK = 64, CAP = 288, GROUPS = 3;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
     static constexpr int PAIR_WEIGHT = 1;
     typedef float4 BT;
@@ -199,7 +199,7 @@ struct PcisphRhoStarPass {
     }
     __device__ void pair(const Consts &c, Own &o, float, float, float, float, const float4 &a, const BT &bj, int) const {
         const float dx = o.px - bj.x, dy = o.py - bj.y, dz = o.pz - bj.z;
-        o.sum += a.w * kernW(c, fsqrt(dx * dx + dy * dy + dz * dz));
+        o.sum += a.w * kernW(c, geom(c, dx * dx + dy * dy + dz * dz));
     }
     __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {
         const float star = o.sum * c.rho0;
@@ -219,7 +219,7 @@ struct PcisphRhoStarPass {
 // Bytes / particle: R posv 16 + velm 16 + ptm 4 + acc 16 -> W pacc 16 + ppos 16 (+pvel 16).
 template <bool AF>
 struct PcisphPressureAccelPass {
-    static constexpr int BLOCK = 128, CAP = 2048;
+    static constexpr int BLOCK = 64, CAP = 288, GROUPS = 3;
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 1;
     typedef float BT;
@@ -248,7 +248,7 @@ struct PcisphPressureAccelPass {
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int) const {
         float gx, gy, gz;
-        kernGrad(c, dx, dy, dz, fsqrt(r2), gx, gy, gz);
+        kernGrad(c, dx, dy, dz, geom(c, r2), gx, gy, gz);
         const float cc = (AF || bj >= 0.0f) ? -a.w * (o.pt + bj) : -a.w * o.pt;
         o.ax += cc * gx; o.ay += cc * gy; o.az += cc * gz;
     }

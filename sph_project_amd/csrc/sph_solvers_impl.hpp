@@ -52,7 +52,7 @@ template <int MODE> static void dfsph_rho_adv_t(State &s, int slot) {
         DfsphRhoAdvPass<false, MODE> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.alpha, out_adv, out_k, s.red_partial};
         launch_pass(s, p);
     }
-    if (s.c.n > 0) l_reduce_sum(s, slot, cdiv(s.c.n, 128));
+    if (s.c.n > 0) l_reduce_sum(s, slot, cdiv(s.c.n, NBR_BLOCK));
 }
 static void l_dfsph_rho_adv(State &s, int mode) { if (mode == 0) dfsph_rho_adv_t<0>(s, 0); else dfsph_rho_adv_t<1>(s, 1); }
 
@@ -98,7 +98,7 @@ static void l_pcisph_rho_star(State &s) {
         PcisphRhoStarPass<false> p{s.posv.cur(), s.ppos, s.meta.cur(), s.rho.cur(), s.rho_star, s.prs, s.ptm, s.red_partial};
         launch_pass(s, p);
     }
-    if (s.c.n > 0) l_reduce_sum(s, 2, cdiv(s.c.n, 128));
+    if (s.c.n > 0) l_reduce_sum(s, 2, cdiv(s.c.n, NBR_BLOCK));
 }
 
 static void l_pcisph_pressure_accel(State &s) {
