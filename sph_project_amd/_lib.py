@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsph_hip.so")
+LIB_PATH = os.environ.get("SPH_HIP_LIB", os.path.join(_HERE, "libsph_hip.so"))  # override: A/B builds only
 
 MAX_OBJECTS = 20
 MAT_FLUID, MAT_RIGID = 1, 2

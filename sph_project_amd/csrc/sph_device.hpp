@@ -146,15 +146,31 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ void __launch_bounds__(256)
 k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ cellid,
              int *__restrict__ rank, int *__restrict__ cell_count) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= c.n) return;
-    float4 p = posv[i];
-    int cx = cell_coord(p.x, c.grid_size, c.nx);
-    int cy = cell_coord(p.y, c.grid_size, c.ny);
-    int cz = cell_coord(p.z, c.grid_size, c.nz);
-    int lin = (cx * c.ny + cy) * c.nz + cz;
-    cellid[i] = lin;
-    rank[i] = atomicAdd(&cell_count[lin], 1);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < c.n;
+    int lin = -1 - lane;  // distinct dummy key for lanes past the end
+    if (valid) {
+        const float4 p = posv[i];
+        const int cx = cell_coord(p.x, c.grid_size, c.nx);
+        const int cy = cell_coord(p.y, c.grid_size, c.ny);
+        const int cz = cell_coord(p.z, c.grid_size, c.nz);
+        lin = (cx * c.ny + cy) * c.nz + cz;
+        cellid[i] = lin;
+    }
+    // The input is the previous step's sorted order, so lanes of one wave fall into a few runs of equal
+    // cell id.  One atomic per run (by its first lane) instead of one per particle: ~8x fewer L2 atomics.
+    const int prev = __shfl_up(lin, 1, 64);
+    const bool head = lane == 0 || lin != prev;
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long upto = hm & ((2ull << lane) - 1ull);          // heads at or below this lane
+    const int hl = 63 - __clzll(upto);
+    const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
+    const int len = above ? __ffsll(above) : 64 - lane;                      // run length if this lane is a head
+    int base = 0;
+    if (head && valid) base = atomicAdd(&cell_count[lin], len);
+    base = __shfl(base, hl, 64);
+    if (valid) rank[i] = base + (lane - hl);
 }
 
 // base_container.py:546 PrefixSumExecutor.run -- here an exclusive scan into cell_start[0..G],
@@ -396,8 +412,8 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
     }
 }
 
-#define NBR_CS_SPAN 28
-#define NBR_BLOCK 64  // cell_start window cached in LDS per run: cells [first-1, last+1] (+ end) of the workgroup
+#define NBR_CS_SPAN 124
+#define NBR_BLOCK 256  // cell_start window cached in LDS per run: cells [first-1, last+1] (+ end) of the workgroup
 
 template <class P>
 __global__ void __launch_bounds__(P::BLOCK)
