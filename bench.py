@@ -38,16 +38,18 @@ ALG_BYTES = {
 
 
 def c2_scene(method="wcsph", scale_z=1):
-    """block identical to data/scenes/final_scene0.json:55-59 of the reference."""
+    """block identical to data/scenes/final_scene0.json:55-59 of the reference.
+    scale_z = N (weak scaling over N GPUs): the block and the domain are N times as deep in z, i.e. N x 80 lattice
+    planes = N x 1,231,200 particles, so every z-slab holds one C2's worth of work."""
     dt = 4e-4 if method == "wcsph" else 6e-4
     return {
         "Configuration": {
-            "domainStart": [0.0, 0.0, 0.0], "domainEnd": [8.5, 8.0, 2.0 * scale_z], "addDomainBox": False,
+            "domainStart": [0.0, 0.0, 0.0], "domainEnd": [8.5, 8.0, 0.4 + 1.6 * scale_z], "addDomainBox": False,
             "particleRadius": 0.01, "density0": 1000, "simulationMethod": method, "viscosityMethod": "standard",
             "gravitation": [0.0, -9.81, 0.0], "timeStepSize": dt, "viscosity": 10.0,
         },
         "FluidBlocks": [{
-            "objectId": 0, "start": [0.09, 0.2, 0.2], "end": [1.7, 4.0, 1.8 + 2.0 * (scale_z - 1)],
+            "objectId": 0, "start": [0.09, 0.2, 0.2], "end": [1.7, 4.0, 0.2 + 1.6 * scale_z],
             "translation": [0.0, 0.0, 0.0], "scale": [1, 1, 1], "velocity": [0.0, -0.5, 0.0], "density": 1000.0,
             "color": [50, 100, 200], "entryTime": -1.0,
         }],
@@ -88,25 +90,62 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--all-kernels", action="store_true", help="also print the per-kernel HIP-event table (stderr)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = every z-slab gets one C2 block (N x 1.23 M particles); strong = the 1.23 M scene is split")
+    ap.add_argument("--replicas", action="store_true", help="N>1: independent copies instead of z-slab sharding (debug)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    use_gloo = bool(os.environ.get("SPH_BENCH_GLOO"))  # test rig: several ranks on ONE GPU (with SPH_COMM_TRANSPORT=shm)
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if use_gloo:
+            local_rank = 0
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def _reduce(x, op, dtype):
+        import torch
+        t = torch.tensor([x], device="cpu" if use_gloo else "cuda", dtype=dtype)
+        dist.all_reduce(t, op=op)
+        return t.item()
 
     method = "dfsph" if args.config == "c3" else "wcsph"
-    cfg = c1_scene(method) if args.config == "c1" else c2_scene(method)
+    sharded = world > 1 and not args.replicas and method == "wcsph"
+    scale_z = world if (sharded and args.scaling == "weak" and args.config == "c2") else 1
+    cfg = c1_scene(method) if args.config == "c1" else c2_scene(method, scale_z=scale_z)
     from tests import helpers as H  # scene -> container/solver exactly like run_simulation.py
+    slab_opt = None
+    n_global = None
+    if sharded:
+        import numpy as np
+        from sph_project_amd import _lib as L, slab
+        import ctypes
+        uid = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            assert L.load().sph_comm_unique_id(buf) == 0
+            uid[0] = buf.raw
+        dist.broadcast_object_list(uid, src=0)
+        _, geo, batches = H.scene_particles(cfg)
+        z = np.concatenate([b["pos"][:, 2] for b in batches])
+        nz = int(geo.grid_num[2])
+        cuts = slab.plan_slabs(np.bincount(slab.cell_layer(z, geo.dh, nz), minlength=nz), world)
+        slab_opt = dict(rank=rank, nranks=world, unique_id=uid[0], cuts=cuts)
+        n_global = int(sum((b["material"] == 1).sum() for b in batches))
+        del batches, z
     opts = dict(fast_math=0 if args.strict_math else 1, deterministic=0 if args.no_deterministic else 1,
                 force_global=int(os.environ.get('SPH_DEBUG_MODE', int(args.force_global))), device=local_rank if world > 1 else -1)
     if method != "wcsph":
         opts["fixed_iterations"] = 2
+    if slab_opt:
+        opts["slab"] = slab_opt
     container, solver = H.build_product(cfg, **opts)
     eng = container.engine
     solver.prepare()
@@ -118,7 +157,8 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if not use_gloo:
+                torch.cuda.synchronize()
 
     eng.step_async(args.warmup)
     fence()
@@ -145,13 +185,19 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(_reduce(elapsed, dist.ReduceOp.MAX, torch.float64))
 
     launches, ms = eng.profile_read(names.index(dom))
     stats = solver.stats()
-    n_total = n_fluid * world  # replicas: every rank advances its own copy
+    pairs = stats["pair_interactions"]
+    if sharded:
+        n_total = n_global  # every fluid particle is owned by exactly one rank
+        import torch
+        pairs = int(_reduce(pairs, dist.ReduceOp.SUM, torch.int64))
+        n_fluid = n_global // world  # per-launch share for the roofline leg
+    else:
+        n_total = n_fluid * world  # replicas: every rank advances its own copy
+        pairs = pairs * world
     value = n_total * args.steps / elapsed
     avg_s = (ms / max(launches, 1)) * 1e-3
     achieved = ALG_BYTES[dom] * n_fluid / avg_s / 1e9 if launches else None
@@ -166,16 +212,17 @@ def main():
     out = {
         "metric": "particle-updates/sec", "value": value, "unit": "particle-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": {"c1": "C1 8,000-particle cube dam break", "c2": "C2 1,231,200-particle dam break",
+            "workload": {"c1": "C1 8,000-particle cube dam break", "c2": "C2 1,231,200-particle dam break" + (f" x{scale_z} in z" if scale_z > 1 else ""),
                          "c3": "C3 1,231,200-particle dam break, 2+2 fixed DFSPH iterations"}[args.config],
             "method": method, "particles": int(n_total), "grid_cells": int(container.grid_num.prod()),
             "dt": cfg["Configuration"]["timeStepSize"], "math": "strict" if args.strict_math else "fast",
             "deterministic_sort": not args.no_deterministic,
-            "parallelism": "single-gpu" if world == 1 else f"replicas x{world} (slab sharding not built yet)",
-            "pair_interactions_per_step": int(stats["pair_interactions"]),
-            "pair_interactions_per_s": stats["pair_interactions"] * world * args.steps / elapsed,
+            "parallelism": "single-gpu" if world == 1 else
+                           (f"z-slab x{world}, RCCL halo exchange ({args.scaling} scaling)" if sharded else f"replicas x{world}"),
+            "pair_interactions_per_step": int(pairs),
+            "pair_interactions_per_s": pairs * args.steps / elapsed,
             "lds_fallback_blocks_last_step": int(stats["lds_fallback_blocks"]),
             "device": eng.device_info()["name"],
         },

@@ -92,6 +92,7 @@ typedef enum {
     SPH_F_PREDICTED_POS = 20,    /* f32[n][3] */
     SPH_F_CG_X = 21,             /* f32[n][3] base_solver.py:46 */
     SPH_F_ORIG_POSITION = 22,    /* f32[n][3] rigid_particle_original_positions */
+    SPH_F_GHOST = 23,            /* i32[n]    1 for ghost copies of a neighbour slab's particles (multi-GPU), else 0 */
     SPH_F_COUNT_
 } SphField;
 

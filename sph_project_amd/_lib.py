@@ -21,7 +21,7 @@ METHOD = {"wcsph": 0, "dfsph": 1, "pcisph": 2}
 (F_POSITION, F_VELOCITY, F_ACCELERATION, F_DENSITY, F_PRESSURE, F_REST_VOLUME, F_MASS, F_MATERIAL,
  F_OBJECT_ID, F_IS_DYNAMIC, F_COLOR, F_PARTICLE_ID, F_GRID_ID, F_DFSPH_ALPHA, F_DFSPH_KAPPA,
  F_DFSPH_KAPPA_V, F_DENSITY_STAR, F_DENSITY_DERIV, F_PRESSURE_ACCEL, F_PREDICTED_VEL, F_PREDICTED_POS,
- F_CG_X, F_ORIG_POSITION) = range(23)
+ F_CG_X, F_ORIG_POSITION, F_GHOST) = range(24)
 
 _FIELD_SPEC = {  # field -> (dtype, components)
     F_POSITION: (np.float32, 3), F_VELOCITY: (np.float32, 3), F_ACCELERATION: (np.float32, 3),
@@ -31,7 +31,7 @@ _FIELD_SPEC = {  # field -> (dtype, components)
     F_GRID_ID: (np.int32, 1), F_DFSPH_ALPHA: (np.float32, 1), F_DFSPH_KAPPA: (np.float32, 1),
     F_DFSPH_KAPPA_V: (np.float32, 1), F_DENSITY_STAR: (np.float32, 1), F_DENSITY_DERIV: (np.float32, 1),
     F_PRESSURE_ACCEL: (np.float32, 3), F_PREDICTED_VEL: (np.float32, 3), F_PREDICTED_POS: (np.float32, 3),
-    F_CG_X: (np.float32, 3), F_ORIG_POSITION: (np.float32, 3),
+    F_CG_X: (np.float32, 3), F_ORIG_POSITION: (np.float32, 3), F_GHOST: (np.int32, 1),
 }
 
 # enum SphPhase
@@ -238,6 +238,24 @@ class Engine:
         n, ms = C.c_int64(), C.c_double()
         self._chk(self.lib.sph_profile_read(self.h, int(kernel_id), C.byref(n), C.byref(ms)), "sph_profile_read")
         return n.value, ms.value
+
+    # -- multi-GPU (z-slab sharding)
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        self._chk(self.lib.sph_comm_unique_id(buf), "sph_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank, nranks, unique_id: bytes):
+        assert len(unique_id) == 128
+        self._chk(self.lib.sph_comm_init(self.h, int(rank), int(nranks), C.c_char_p(unique_id)), "sph_comm_init")
+
+    def comm_set_slab(self, z_lo, z_hi):
+        self._chk(self.lib.sph_comm_set_slab(self.h, int(z_lo), int(z_hi)), "sph_comm_set_slab")
+
+    def comm_get_slab(self):
+        v = [C.c_int() for _ in range(4)]
+        self._chk(self.lib.sph_comm_get_slab(self.h, *[C.byref(x) for x in v]), "sph_comm_get_slab")
+        return dict(z_lo=v[0].value, z_hi=v[1].value, n_owned=v[2].value, n_ghost=v[3].value)
 
     def device_info(self):
         name = C.create_string_buffer(256)

@@ -126,7 +126,7 @@ static void fill_consts(SphHandle *h) {
 static void refresh_counts(SphHandle *h) {
     h->st.c.n = h->n;
     h->st.has_emitter = h->prm.g_upper < 9999.0;
-    h->st.c.all_fluid = (h->n_nonfluid == 0 && !h->st.has_emitter) ? 1 : 0;
+    h->st.c.all_fluid = (h->n_nonfluid == 0 && !h->st.has_emitter && !h->st.slab_active) ? 1 : 0;
     h->st.has_rigid = h->n_nonfluid > 0;
 }
 
@@ -139,6 +139,8 @@ extern "C" const char *sph_kernel_name(int k) {
         "pcisph_pressure_accel", "cg_prepare", "cg_ap", "cg_vector", "misc", "halo"};
     return (k >= 0 && k < SPH_K_COUNT_) ? names[k] : "?";
 }
+
+static void slab_comm_destroy(SlabComm &c);
 
 extern "C" void sph_destroy(SphHandle *h) {
     if (!h) return;
@@ -242,6 +244,8 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     for (int o = 0; o < SPH_NOBJ; ++o) { h->pose_h.rot[o][0] = h->pose_h.rot[o][4] = h->pose_h.rot[o][8] = 1.0f; }
     memset(&h->last, 0, sizeof(h->last));
     s.has_dynamic_rigid = 0; s.has_rigid = 0;
+    s.slab_active = 0; s.xcur = 0; s.halo_cap = 0; s.z_lo = 0; s.z_hi = s.c.nz; s.has_down = s.has_up = 0;
+    s.xidx[0] = s.xidx[1] = nullptr; s.halo_counts = nullptr;
     s.visc_rho_raw = (p.method == SPH_METHOD_WCSPH);
     s.skip_viscosity = 0;
     refresh_counts(h);
@@ -438,6 +442,7 @@ static void step_begin(SphHandle *h) {
     if (h->pose_dirty) { ProfScope p(h, SPH_K_MISC); h->L->renew_rigid(s); h->pose_dirty = false; }
 }
 
+#include "sph_comm_api.hpp"
 #include "sph_steps.hpp"
 
 static int read_scalars(SphHandle *h) {
@@ -460,9 +465,13 @@ extern "C" int sph_prepare(SphHandle *h) {
     // compute_rigid_particle_volume (+ DFSPH.py:321 / PCISPH.py:188)
     { ProfScope p(h, SPH_K_MISC); h->L->prepare_emitter(s); h->L->renew_rigid(s); }
     h->pose_dirty = false;
-    ph_neighbor_search(h);
+    if (s.slab_active) { rc = slab_neighbor_search(h); if (rc) return rc; }
+    else ph_neighbor_search(h);
     h->rigid_volume_done = false;
     ph_rigid_volume(h);
+    if (s.slab_active && s.has_rigid) {  // ghost copies of boundary particles must carry the volumes just computed
+        rc = slab_neighbor_search(h); if (rc) return rc;
+    }
     rc = method_prepare(h); if (rc) return rc;
     rc = check_async(h); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(s.stream));
@@ -471,6 +480,7 @@ extern "C" int sph_prepare(SphHandle *h) {
 }
 
 static int step_once(SphHandle *h, bool allow_readback) {
+    if (h->st.slab_active && h->prm.method != SPH_METHOD_WCSPH) return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding: wcsph only");
     step_begin(h);
     int rc;
     switch (h->prm.method) {
@@ -606,13 +616,14 @@ extern "C" int sph_download(SphHandle *h, int field, void *dst, size_t bytes) {
         HIPCHK(h, hipMemcpy(dst, src, n * 4, hipMemcpyDeviceToHost));
         return SPH_OK;
     }
-    if (field == SPH_F_MATERIAL || field == SPH_F_OBJECT_ID || field == SPH_F_IS_DYNAMIC) {
+    if (field == SPH_F_MATERIAL || field == SPH_F_OBJECT_ID || field == SPH_F_IS_DYNAMIC || field == SPH_F_GHOST) {
         if (bytes != n * 4) return fail(h, SPH_ERR_INVALID, "download: size mismatch");
         std::vector<int> tmp(n);
         HIPCHK(h, hipMemcpy(tmp.data(), s.meta.cur(), n * 4, hipMemcpyDeviceToHost));
         int32_t *d = (int32_t *)dst;
         for (size_t i = 0; i < n; ++i)
-            d[i] = field == SPH_F_MATERIAL ? META_MAT(tmp[i]) : field == SPH_F_OBJECT_ID ? META_OBJ(tmp[i]) : META_DYN(tmp[i]);
+            d[i] = field == SPH_F_MATERIAL ? META_MAT(tmp[i]) : field == SPH_F_OBJECT_ID ? META_OBJ(tmp[i]) :
+                   field == SPH_F_GHOST ? META_GHOST(tmp[i]) : META_DYN(tmp[i]);
         return SPH_OK;
     }
     if (field == SPH_F_PARTICLE_ID) {
@@ -671,6 +682,11 @@ extern "C" int sph_upload(SphHandle *h, int field, const void *src, size_t bytes
         HIPCHK(h, hipMemcpy(vdst, tmp.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         return SPH_OK;
     }
+    if (field == SPH_F_PARTICLE_ID) {  // global ids when a scene is split over ranks
+        if (bytes != n * 4) return fail(h, SPH_ERR_INVALID, "upload: size mismatch");
+        HIPCHK(h, hipMemcpy(s.pid.cur(), src, n * 4, hipMemcpyHostToDevice));
+        return SPH_OK;
+    }
     float *fdst = nullptr;
     switch (field) {
         case SPH_F_DENSITY: fdst = s.rho.cur(); break;
@@ -684,5 +700,3 @@ extern "C" int sph_upload(SphHandle *h, int field, const void *src, size_t bytes
     }
     return fail(h, SPH_ERR_UNSUPPORTED, "upload: field %d is read-only", field);
 }
-
-#include "sph_comm_api.hpp"

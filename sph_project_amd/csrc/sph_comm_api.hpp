@@ -1,11 +1,268 @@
-// sph_comm_api.hpp -- multi-GPU entry points (included by sph_api.hip)
+// sph_comm_api.hpp -- multi-GPU entry points and the slab exchange orchestration (included by sph_api.hip)
 #pragma once
-extern "C" int sph_comm_unique_id(void *out128) { (void)out128; return SPH_ERR_UNSUPPORTED; }
-extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id128) {
-    (void)rank; (void)nranks; (void)id128;
-    return fail(h, SPH_ERR_UNSUPPORTED, "multi-GPU slab sharding is not built yet");
+#include <rccl/rccl.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <time.h>
+
+#define NCCLCHK(h, call)                                                                                   \
+    do {                                                                                                   \
+        ncclResult_t r_ = (call);                                                                          \
+        if (r_ != ncclSuccess) return fail((h), SPH_ERR_COMM, "%s failed: %s", #call, ncclGetErrorString(r_)); \
+    } while (0)
+
+static inline ShmMailbox *shm_mbox(SlabComm &c, int writer, int dir) {
+    char *base = (char *)c.shm_base + sizeof(ShmHeader);
+    const size_t stride = sizeof(ShmMailbox) + c.mbox_cap;
+    return (ShmMailbox *)(base + ((size_t)writer * 2 + dir) * stride);
 }
-extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) { (void)z_lo; (void)z_hi; return fail(h, SPH_ERR_UNSUPPORTED, "not built"); }
+
+static void slab_comm_destroy(SlabComm &c) {
+    if (c.kind == 1 && c.nccl) ncclCommDestroy((ncclComm_t)c.nccl);
+    if (c.kind == 2 && c.shm_base) {
+        ShmHeader *hd = (ShmHeader *)c.shm_base;
+        hd->detached.fetch_add(1);
+        munmap(c.shm_base, c.shm_size);
+        shm_unlink(c.shm_name.c_str());  // idempotent: first rank out removes the name
+    }
+    if (c.cnt_dev) hipFree(c.cnt_dev);
+    if (c.cnt_host) hipHostFree(c.cnt_host);
+    c = SlabComm();
+}
+
+extern "C" int sph_comm_unique_id(void *out128) {
+    if (!out128) return SPH_ERR_INVALID;
+    memset(out128, 0, 128);
+    const char *t = getenv("SPH_COMM_TRANSPORT");
+    if (!(t && !strcmp(t, "shm"))) {
+        ncclUniqueId id;
+        if (ncclGetUniqueId(&id) == ncclSuccess) { memcpy(out128, &id, sizeof(id) < 128 ? sizeof(id) : 128); return SPH_OK; }
+    }
+    int fd = open("/dev/urandom", O_RDONLY);
+    if (fd < 0) return SPH_ERR_COMM;
+    ssize_t got = read(fd, out128, 128);
+    close(fd);
+    return got == 128 ? SPH_OK : SPH_ERR_COMM;
+}
+
+static int shm_attach(SphHandle *h, SlabComm &c, size_t mbox_cap) {
+    char name[64];
+    snprintf(name, sizeof(name), "/sphhalo_%02x%02x%02x%02x%02x%02x%02x%02x", c.id[8], c.id[9], c.id[10], c.id[11], c.id[12],
+             c.id[13], c.id[14], c.id[15]);
+    c.shm_name = name;
+    c.mbox_cap = mbox_cap;
+    c.shm_size = sizeof(ShmHeader) + (size_t)c.nranks * 2 * (sizeof(ShmMailbox) + mbox_cap);
+    int fd = -1;
+    if (c.rank == 0) {
+        shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return fail(h, SPH_ERR_COMM, "shm_open(%s) failed", name);
+        if (ftruncate(fd, (off_t)c.shm_size) != 0) { close(fd); return fail(h, SPH_ERR_COMM, "ftruncate(%s) failed", name); }
+    } else {
+        for (int tries = 0; tries < 20000 && fd < 0; ++tries) {  // up to ~20 s for rank 0 to create it
+            fd = shm_open(name, O_RDWR, 0600);
+            if (fd >= 0) { struct stat st; if (fstat(fd, &st) != 0 || (size_t)st.st_size < c.shm_size) { close(fd); fd = -1; } }
+            if (fd < 0) usleep(1000);
+        }
+        if (fd < 0) return fail(h, SPH_ERR_COMM, "shm_open(%s): rank 0 never created the segment", name);
+    }
+    c.shm_base = mmap(nullptr, c.shm_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (c.shm_base == MAP_FAILED) { c.shm_base = nullptr; return fail(h, SPH_ERR_COMM, "mmap(%s) failed", name); }
+    ShmHeader *hd = (ShmHeader *)c.shm_base;
+    if (c.rank == 0) { hd->nranks = c.nranks; hd->mbox_cap = mbox_cap; }
+    hd->attached.fetch_add(1);
+    for (int tries = 0; hd->attached.load() < c.nranks; ++tries) {
+        if (tries > 60000) return fail(h, SPH_ERR_COMM, "shm transport: only %d of %d ranks attached", hd->attached.load(), c.nranks);
+        usleep(1000);
+    }
+    return SPH_OK;
+}
+
+extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id128) {
+    if (!h || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, SPH_ERR_INVALID, "comm_init: bad arguments");
+    if (h->comm.kind) return fail(h, SPH_ERR_INVALID, "comm_init: already initialised");
+    if (h->prm.method != SPH_METHOD_WCSPH || h->prm.viscosity_implicit)
+        return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding is built for WCSPH with explicit viscosity in this round");
+    HIPCHK(h, hipSetDevice(h->device));
+    State &s = h->st;
+    SlabComm &c = h->comm;
+    c.rank = rank; c.nranks = nranks;
+    memcpy(c.id, id128, 128);
+    // message capacity: a z-face holds nx*ny cells; allow 24 particles per cell and two layers (migrants + copies)
+    const size_t face = (size_t)s.c.nx * s.c.ny;
+    size_t cap = face * 24 * 2;
+    if (cap > (size_t)s.cap) cap = (size_t)s.cap;
+    if (cap < 1024) cap = 1024;
+    s.halo_cap = (int)cap;
+    for (int k = 0; k < 2; ++k) {
+        int rc = dalloc(h, &s.xidx[k], (size_t)s.cap); if (rc) return rc;
+        rc = dalloc(h, &s.sendbuf[k], 3 * cap); if (rc) return rc;
+        rc = dalloc(h, &s.recvbuf[k], 3 * cap); if (rc) return rc;
+    }
+    for (int k = 0; k < 8; ++k) { int rc = dalloc(h, &s.halo_tab[k], cap); if (rc) return rc; }
+    { int rc = dalloc(h, &s.halo_counts, 4); if (rc) return rc; }
+    HIPCHK(h, hipMalloc((void **)&c.cnt_dev, 4 * sizeof(int)));
+    HIPCHK(h, hipHostMalloc((void **)&c.cnt_host, 8 * sizeof(int), hipHostMallocDefault));
+    s.xcur = 0;
+    const char *t = getenv("SPH_COMM_TRANSPORT");
+    if (t && !strcmp(t, "shm")) {
+        int rc = shm_attach(h, c, cap * 48);
+        if (rc) return rc;
+        c.kind = 2;
+    } else {
+        ncclUniqueId id;
+        memset(&id, 0, sizeof(id));
+        memcpy(&id, id128, sizeof(id) < 128 ? sizeof(id) : 128);
+        ncclComm_t comm;
+        NCCLCHK(h, ncclCommInitRank(&comm, nranks, id, rank));
+        c.nccl = comm;
+        c.kind = 1;
+    }
+    s.slab_active = 1;
+    s.has_down = rank > 0; s.has_up = rank < nranks - 1;
+    s.z_lo = 0; s.z_hi = s.c.nz;
+    return SPH_OK;
+}
+
+extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
+    if (!h || !h->comm.kind) return fail(h, SPH_ERR_INVALID, "comm_set_slab: communicator not initialised");
+    if (z_lo < 0 || z_hi > h->st.c.nz || z_hi - z_lo < 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: a slab needs >= 2 cell layers inside the grid");
+    h->st.z_lo = z_lo; h->st.z_hi = z_hi;
+    return SPH_OK;
+}
+
 extern "C" int sph_comm_get_slab(SphHandle *h, int *z_lo, int *z_hi, int *n_owned, int *n_ghost) {
-    (void)z_lo; (void)z_hi; (void)n_owned; (void)n_ghost; return fail(h, SPH_ERR_UNSUPPORTED, "not built");
+    if (!h || !h->comm.kind) return fail(h, SPH_ERR_INVALID, "comm_get_slab: communicator not initialised");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (z_lo) *z_lo = h->st.z_lo;
+    if (z_hi) *z_hi = h->st.z_hi;
+    if (n_owned || n_ghost) {
+        HIPCHK(h, hipStreamSynchronize(h->st.stream));
+        std::vector<int> m((size_t)h->n);
+        HIPCHK(h, hipMemcpy(m.data(), h->st.meta.cur(), sizeof(int) * (size_t)h->n, hipMemcpyDeviceToHost));
+        int g = 0;
+        for (int v : m) g += META_GHOST(v);
+        if (n_ghost) *n_ghost = g;
+        if (n_owned) *n_owned = h->n - g;
+    }
+    return SPH_OK;
+}
+
+// ---- transport: one message to / from each neighbour.  bytes_recv[side] is filled in when sizes_known == false.
+static int shm_wait(std::atomic<uint64_t> &a, uint64_t want, SphHandle *h, const char *what) {
+    struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0; a.load(std::memory_order_acquire) < want; ++spins) {
+        if ((spins & 1023) == 1023) {
+            struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (t1.tv_sec - t0.tv_sec > 60) return fail(h, SPH_ERR_COMM, "shm transport: timed out waiting for %s", what);
+            usleep(50);
+        }
+    }
+    return SPH_OK;
+}
+
+static int comm_exchange(SphHandle *h, const void *send[2], const size_t bytes_send[2], void *recv[2], size_t bytes_recv[2],
+                         bool sizes_known) {
+    SlabComm &c = h->comm;
+    State &s = h->st;
+    const int peer[2] = {c.rank - 1, c.rank + 1};
+    const bool has[2] = {s.has_down != 0, s.has_up != 0};
+    if (c.kind == 2) {
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        const uint64_t t = ++c.seq;
+        for (int side = 0; side < 2; ++side) {
+            if (!has[side]) continue;
+            ShmMailbox *mb = shm_mbox(c, c.rank, side);
+            int rc = shm_wait(mb->seq_read, t - 1, h, "the previous message to be consumed"); if (rc) return rc;
+            if (bytes_send[side] > c.mbox_cap) return fail(h, SPH_ERR_CAPACITY, "halo message of %zu bytes exceeds the mailbox", bytes_send[side]);
+            if (bytes_send[side]) HIPCHK(h, hipMemcpy((char *)(mb + 1), send[side], bytes_send[side], hipMemcpyDeviceToHost));
+            mb->nbytes = bytes_send[side];
+            mb->seq_written.store(t, std::memory_order_release);
+        }
+        for (int side = 0; side < 2; ++side) {
+            if (!has[side]) { bytes_recv[side] = 0; continue; }
+            ShmMailbox *mb = shm_mbox(c, peer[side], 1 - side);  // the neighbour's message in my direction
+            int rc = shm_wait(mb->seq_written, t, h, "a neighbour's message"); if (rc) return rc;
+            const size_t nb = (size_t)mb->nbytes;
+            if (sizes_known && nb != bytes_recv[side]) return fail(h, SPH_ERR_COMM, "halo message size mismatch (%zu vs %zu)", nb, bytes_recv[side]);
+            bytes_recv[side] = nb;
+            if (nb) HIPCHK(h, hipMemcpy(recv[side], (char *)(mb + 1), nb, hipMemcpyHostToDevice));
+            mb->seq_read.store(t, std::memory_order_release);
+        }
+        return SPH_OK;
+    }
+    ncclComm_t comm = (ncclComm_t)c.nccl;
+    if (!sizes_known) {  // exchange the two message sizes first (device ints; ncclSend/Recv move device memory only)
+        c.cnt_host[0] = (int)bytes_send[0]; c.cnt_host[1] = (int)bytes_send[1]; c.cnt_host[2] = c.cnt_host[3] = 0;
+        HIPCHK(h, hipMemcpyAsync(c.cnt_dev, c.cnt_host, 4 * sizeof(int), hipMemcpyHostToDevice, s.stream));
+        NCCLCHK(h, ncclGroupStart());
+        for (int side = 0; side < 2; ++side) {
+            if (!has[side]) continue;
+            NCCLCHK(h, ncclSend(c.cnt_dev + side, 1, ncclInt32, peer[side], comm, s.stream));
+            NCCLCHK(h, ncclRecv(c.cnt_dev + 2 + side, 1, ncclInt32, peer[side], comm, s.stream));
+        }
+        NCCLCHK(h, ncclGroupEnd());
+        HIPCHK(h, hipMemcpyAsync(c.cnt_host + 4, c.cnt_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        bytes_recv[0] = has[0] ? (size_t)c.cnt_host[6] : 0;
+        bytes_recv[1] = has[1] ? (size_t)c.cnt_host[7] : 0;
+    }
+    NCCLCHK(h, ncclGroupStart());
+    for (int side = 0; side < 2; ++side) {
+        if (!has[side]) continue;
+        if (bytes_send[side]) NCCLCHK(h, ncclSend(send[side], bytes_send[side], ncclChar, peer[side], comm, s.stream));
+        if (bytes_recv[side]) NCCLCHK(h, ncclRecv(recv[side], bytes_recv[side], ncclChar, peer[side], comm, s.stream));
+    }
+    NCCLCHK(h, ncclGroupEnd());
+    return SPH_OK;
+}
+
+// replaces ph_neighbor_search in slab mode: migrate + ghost exchange, then the usual sort, then the slot tables
+static int slab_neighbor_search(SphHandle *h) {
+    State &s = h->st;
+    SlabComm &c = h->comm;
+    { ProfScope p(h, SPH_K_HALO); h->L->halo_classify_pack(s, h->n); }
+    HIPCHK(h, hipMemcpyAsync(c.cnt_host, s.halo_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(h, hipStreamSynchronize(s.stream));
+    const int kept = c.cnt_host[2];
+    for (int side = 0; side < 2; ++side) {
+        c.n_send[side] = c.cnt_host[side];
+        if (c.n_send[side] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "halo message of %d particles exceeds capacity %d", c.n_send[side], s.halo_cap);
+    }
+    const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
+    void *recv[2] = {s.recvbuf[0], s.recvbuf[1]};
+    const size_t bs[2] = {(size_t)c.n_send[0] * 48, (size_t)c.n_send[1] * 48};
+    size_t br[2] = {0, 0};
+    { ProfScope p(h, SPH_K_HALO); int rc = comm_exchange(h, send, bs, recv, br, false); if (rc) return rc; }
+    c.n_recv[0] = (int)(br[0] / 48); c.n_recv[1] = (int)(br[1] / 48);
+    if (c.n_recv[0] > s.halo_cap || c.n_recv[1] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "received halo exceeds capacity");
+    if ((long long)kept + c.n_recv[0] + c.n_recv[1] > s.cap)
+        return fail(h, SPH_ERR_CAPACITY, "slab holds %d + %d + %d particles, particle_max_num is %d", kept, c.n_recv[0], c.n_recv[1], s.cap);
+    { ProfScope p(h, SPH_K_HALO);
+      h->L->halo_unpack_append(s, 0, c.n_recv[0], kept);
+      h->L->halo_unpack_append(s, 1, c.n_recv[1], kept + c.n_recv[0]); }
+    h->n = kept + c.n_recv[0] + c.n_recv[1];
+    refresh_counts(h);
+    s.c.all_fluid = 0;  // ghosts are told apart through the meta word
+    ph_neighbor_search(h);
+    { ProfScope p(h, SPH_K_HALO); h->L->halo_build_tables(s); }
+    return SPH_OK;
+}
+
+// density / pressure of the ghosts after the density pass (SURVEY 8e message (3))
+static int slab_exchange_fields(SphHandle *h) {
+    State &s = h->st;
+    SlabComm &c = h->comm;
+    ProfScope p(h, SPH_K_HALO);
+    for (int side = 0; side < 2; ++side) h->L->halo_pack_fields(s, side, c.n_send[side], c.n_recv[side]);
+    const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
+    void *recv[2] = {s.recvbuf[0], s.recvbuf[1]};
+    const size_t bs[2] = {(size_t)(c.n_send[0] + c.n_recv[0]) * 16, (size_t)(c.n_send[1] + c.n_recv[1]) * 16};
+    size_t br[2] = {bs[0], bs[1]};
+    int rc = comm_exchange(h, send, bs, recv, br, true); if (rc) return rc;
+    for (int side = 0; side < 2; ++side) h->L->halo_unpack_fields(s, side, c.n_recv[side], c.n_send[side]);
+    return SPH_OK;
 }

@@ -21,6 +21,8 @@
 #define META_MAT(m) (((m) >> 8) & 0x3)
 #define META_DYN(m) (((m) >> 10) & 0x1)
 #define META_PACK(obj, mat, dyn) ((((obj) + 1) & 0xff) | (((mat) & 0x3) << 8) | (((dyn) & 1) << 10))
+#define META_GHOST(m) (((m) >> 11) & 0x1)   /* slab sharding: copy of a neighbour rank's boundary particle */
+#define META_ACTIVE_FLUID(m) ((((m) >> 8) & 0xB) == 1) /* material fluid and not a ghost */
 #define META_SET_MAT(m, mat) (((m) & ~(0x3 << 8)) | (((mat) & 0x3) << 8))
 
 struct Consts {
@@ -102,6 +104,14 @@ struct State {
     RigidPose *pose;     // device copy
     int has_dynamic_rigid;
     int has_rigid;
+    // z-slab sharding (sph_halo.hpp): exchange tables and message buffers
+    int *xidx[2];        // carried through the sort: (kind << 29) | index, see HALO_KIND_*
+    int xcur;
+    int *halo_tab[8];    // slot tables, index = kind - 1 (sph_halo.hpp HALO_*): send, ghost, echo-send, echo-ghost x {down, up}
+    float4 *sendbuf[2], *recvbuf[2];     // 3 float4 per particle record
+    int *halo_counts;    // device: [0..1] send counts, [2] kept count
+    int halo_cap;        // particles per message buffer
+    int slab_active, z_lo, z_hi, has_down, has_up;
     int has_emitter;     // gravitationUpper set (base_solver.py:18-23)
     int visc_rho_raw;    // viscosity reads rho_raw (WCSPH: density before the EOS clamp)
     int skip_viscosity;  // implicit viscosity: explicit term not part of the fused pass
@@ -130,6 +140,12 @@ struct Launch {
     void (*pcisph_init)(State &);
     void (*pcisph_rho_star)(State &);
     void (*pcisph_pressure_accel)(State &);
+    // z-slab sharding
+    void (*halo_classify_pack)(State &, int n);
+    void (*halo_unpack_append)(State &, int side, int count, int offset);
+    void (*halo_build_tables)(State &);
+    void (*halo_pack_fields)(State &, int side, int n_send, int n_recv);
+    void (*halo_unpack_fields)(State &, int side, int n_recv, int n_send);
     // implicit viscosity (CG)
     void (*cg_prepare)(State &);
     void (*cg_ap)(State &);

@@ -257,6 +257,7 @@ struct SortArrays {
     const int *meta_in, *pid_in;
     const unsigned *color_in;
     const float *rho_in;
+    const int *xidx_in; int *xidx_out;   // slab sharding only (else null)
     float4 *posv_out, *velm_out, *orig_out;
     int *meta_out, *pid_out;
     unsigned *color_out;
@@ -289,6 +290,7 @@ k_scatter(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
     a.color_out[d] = a.color_in[i];
     a.rho_out[d] = a.rho_in[i];
     if (a.orig_in) a.orig_out[d] = a.orig_in[i];
+    if (a.xidx_in) a.xidx_out[d] = a.xidx_in[i];
 }
 
 // ------------------------------------------------------------------ generic neighbour pass

@@ -16,6 +16,7 @@ namespace SPH_NS {
 #include "sph_passes.hpp"
 #include "sph_solvers.hpp"
 #include "sph_cg.hpp"
+#include "sph_halo.hpp"
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -47,6 +48,7 @@ void l_scatter_impl(State &s, bool stable) {
     a.color_in = s.color.cur(); a.color_out = s.color.alt();
     a.rho_in = s.rho.cur(); a.rho_out = s.rho.alt();
     a.orig_in = s.orig.cur(); a.orig_out = s.orig.alt();
+    a.xidx_in = s.slab_active ? s.xidx[s.xcur] : nullptr; a.xidx_out = s.slab_active ? s.xidx[1 - s.xcur] : nullptr;
     int *tmp_idx = (int *)s.red_partial;  // reused scratch (sized >= n ints by the allocator)
     if (stable) {
         hipLaunchKernelGGL(k_scatter_index, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
@@ -60,6 +62,7 @@ void l_scatter_impl(State &s, bool stable) {
     (void)tmp_idx;
     s.posv.flip(); s.velm.flip(); s.meta.flip(); s.pid.flip(); s.color.flip(); s.rho.flip();
     if (s.orig.cur()) s.orig.flip();
+    if (s.slab_active) s.xcur = 1 - s.xcur;
 }
 void l_scatter(State &s) { l_scatter_impl(s, false); }
 void l_scatter_stable(State &s) { l_scatter_impl(s, true); }
@@ -178,6 +181,7 @@ void l_prepare_emitter(State &s) {
 }
 
 #include "sph_solvers_impl.hpp"
+#include "sph_halo_impl.hpp"
 }  // namespace SPH_NS
 
 using namespace SPH_NS;
@@ -197,6 +201,9 @@ const Launch *SPH_LAUNCH_FN() {
         L.renew_rigid = l_renew_rigid;
         L.prepare_emitter = l_prepare_emitter;
         register_solver_launchers(L);
+        L.halo_classify_pack = l_halo_classify_pack; L.halo_unpack_append = l_halo_unpack_append;
+        L.halo_build_tables = l_halo_build_tables; L.halo_pack_fields = l_halo_pack_fields;
+        L.halo_unpack_fields = l_halo_unpack_fields;
         init = true;
     }
     return &L;

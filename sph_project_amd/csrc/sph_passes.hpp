@@ -31,7 +31,7 @@ struct DensityPass {
     __device__ float4 stage(const Consts &, int j, BT &) const { return posv[j]; }
     __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
         o.sum = 0.0f;
-        return AF || META_MAT(meta[i]) == 1;
+        return AF || META_ACTIVE_FLUID(meta[i]);
     }
     __device__ void pair(const Consts &c, Own &o, float, float, float, float r2, const float4 &a, const BT &,
                          int) const {
@@ -93,7 +93,7 @@ struct NonPressurePass {
     }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
     __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
-        if (!AF && META_MAT(meta[i]) != 1) return false;
+        if (!AF && !META_ACTIVE_FLUID(meta[i])) return false;
         float4 v = velm[i];
         if (visc_vel) { const float4 u = visc_vel[i]; v.x = u.x; v.y = u.y; v.z = u.z; }  // base_solver.py:464
         o.vx = v.x; o.vy = v.y; o.vz = v.z; o.m = v.w;
@@ -200,7 +200,7 @@ struct PressurePass {
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
     __device__ bool begin(const Consts &, int i, const float4 &pi, Own &o) const {
-        if (!AF) { const int m = meta[i]; if (META_MAT(m) != 1 || !META_DYN(m)) return false; }
+        if (!AF) { const int m = meta[i]; if (!META_ACTIVE_FLUID(m) || !META_DYN(m)) return false; }
         o.x = pi.x; o.y = pi.y; o.z = pi.z; o.m0 = rho0 * pi.w;
         o.pt = ptm[i]; o.p = prs[i];
         const float r = rho[i];
@@ -267,7 +267,7 @@ struct RigidVolumePass {
     __device__ float4 stage(const Consts &, int j, BT &) const { return stage_impl(j); }
     __device__ bool begin(const Consts &c, int i, const float4 &pi, Own &o) const {
         const int m = meta[i];
-        if (META_MAT(m) != 2 || !(pi.y <= c.g_upper)) return false;
+        if (META_MAT(m) != 2 || META_GHOST(m) || !(pi.y <= c.g_upper)) return false;
         o.obj = META_OBJ(m);
         o.sum = c.W0;
         return true;

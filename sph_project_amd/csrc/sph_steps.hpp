@@ -26,9 +26,11 @@ static int run_non_pressure(SphHandle *h) {
 
 static int wcsph_step(SphHandle *h) {
     State &s = h->st;
-    ph_neighbor_search(h);                                                    // WCSPH.py:28
+    if (s.slab_active) { int rc = slab_neighbor_search(h); if (rc) return rc; }   // + migration / ghost exchange
+    else ph_neighbor_search(h);                                               // WCSPH.py:28
     ph_rigid_volume(h);                                                       // base_solver.py:696 (see ph_rigid_volume)
     { ProfScope p(h, SPH_K_DENSITY); h->L->density(s, 1); }                   // :29 + :33 (EOS fused)
+    if (s.slab_active) { int rc = slab_exchange_fields(h); if (rc) return rc; }   // ghost rho, p
     int rc = run_non_pressure(h); if (rc) return rc;                          // :30-31
     { ProfScope p(h, SPH_K_PRESSURE_INTEGRATE); h->L->pressure_integrate(s); } // :34-36, :45
     return SPH_OK;

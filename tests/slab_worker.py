@@ -1,0 +1,54 @@
+"""One rank of a multi-process slab-sharded run (spawned by tests/test_hip_slab.py and usable by hand):
+python tests/slab_worker.py <rank> <nranks> <id_hex> <scene.json> <steps> <out.npz> [jitter seed]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from sph_project_amd import _lib as L  # noqa: E402
+from sph_project_amd import scene, slab  # noqa: E402
+from sph_project_amd.SPH.utils import SimConfig  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+
+def main():
+    rank, nranks = int(sys.argv[1]), int(sys.argv[2])
+    uid = bytes.fromhex(sys.argv[3])
+    cfg = json.load(open(sys.argv[4]))
+    steps = int(sys.argv[5])
+    out = sys.argv[6]
+    jitter, seed = (float(sys.argv[7]), int(sys.argv[8])) if len(sys.argv) > 8 else (0.0, 0)
+    # slab cuts from the z histogram of the initial lattice (every rank computes the same plan)
+    c, geo, batches = H.scene_particles(cfg)
+    pos = np.concatenate([b["pos"] for b in batches])
+    mat = np.concatenate([b["material"] for b in batches])
+    if jitter > 0:
+        fl = mat == 1
+        pos[fl] = H.perturb(pos[fl], jitter, seed)
+    nz = int(geo.grid_num[2])
+    hist = np.bincount(slab.cell_layer(pos[:, 2], geo.dh, nz), minlength=nz)
+    cuts = slab.plan_slabs(hist, nranks)
+    container, solver = H.build_product(cfg, slab=dict(rank=rank, nranks=nranks, unique_id=uid, cuts=cuts),
+                                        fast_math=int(os.environ.get("SPH_FAST", "0")))
+    if jitter > 0:  # same perturbed lattice on every rank: overwrite the positions of the particles kept here
+        container.insert_object()
+        ids = np.concatenate(container._global_ids)
+        container.engine.upload(L.F_POSITION, pos[ids])
+    solver.prepare()
+    for _ in range(steps):
+        solver.step()
+    e = container.engine
+    g = e.download(L.F_GHOST) == 1
+    info = e.comm_get_slab()
+    np.savez(out, ids=e.download(L.F_PARTICLE_ID)[~g], pos=e.download(L.F_POSITION)[~g], vel=e.download(L.F_VELOCITY)[~g],
+             rho=e.download(L.F_DENSITY)[~g], prs=e.download(L.F_PRESSURE)[~g], n_ghost=info["n_ghost"], cuts=np.array(cuts),
+             pairs=solver.stats()["pair_interactions"])
+    print(f"rank {rank}: slab {info['z_lo']}..{info['z_hi']} owned {info['n_owned']} ghosts {info['n_ghost']}")
+
+
+if __name__ == "__main__":
+    main()
