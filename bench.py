@@ -144,9 +144,24 @@ def main():
                 force_global=int(os.environ.get('SPH_DEBUG_MODE', int(args.force_global))), device=local_rank if world > 1 else -1)
     if method != "wcsph":
         opts["fixed_iterations"] = 2
+    container = solver = None
     if slab_opt:
-        opts["slab"] = slab_opt
-    container, solver = H.build_product(cfg, **opts)
+        # every rank must agree on the mode: if the communicator cannot be set up anywhere, all fall back to replicas
+        import torch
+        err = ""
+        try:
+            container, solver = H.build_product(cfg, slab=slab_opt, **opts)
+        except Exception as exc:  # noqa: BLE001
+            err = f"{type(exc).__name__}: {exc}"
+        if _reduce(0 if err else 1, dist.ReduceOp.MIN, torch.int64) == 0:
+            if rank == 0 or err:
+                print(f"[bench] rank {rank}: slab sharding unavailable ({err or 'failed on another rank'}); running replicas", file=sys.stderr)
+            container = solver = None
+            sharded = False
+            scale_z = 1
+            cfg = c2_scene(method) if args.config != "c1" else c1_scene(method)
+    if container is None:
+        container, solver = H.build_product(cfg, **opts)
     eng = container.engine
     solver.prepare()
     n_fluid = container.fluid_particle_num[None]
