@@ -50,6 +50,12 @@ SCENES = {
     "wcsph_compressed": (dam_break_scene(end=(0.126, 0.126, 0.126), particleSpacing=0.018, velocity=(0.1, -0.3, 0.0)), 0.002, 21, [1, 2, 4, 8]),
     "pcisph_compressed": (dam_break_scene(method="pcisph", end=(0.1, 0.116, 0.1), particleSpacing=0.0165), 0.0015, 22, [1, 2, 3]),
     "dfsph_compressed": (dam_break_scene(method="dfsph", end=(0.108, 0.126, 0.108), particleSpacing=0.0185, dt=6e-4), 0.002, 23, [1, 2, 3]),
+    # emitter hack (base_solver.py:18-23, :660-677): fluid above gravitationUpper is frozen as "rigid" and released
+    # when it crosses the threshold
+    "wcsph_emitter": (dam_break_scene(end=(0.12, 0.24, 0.12), translation=(0.1, 0.2, 0.1), velocity=(0.0, -2.5, 0.0),
+                                      gravitationUpper=0.33), 0.0, 0, [1, 10, 30]),
+    "dfsph_emitter": (dam_break_scene(method="dfsph", end=(0.12, 0.24, 0.12), translation=(0.1, 0.2, 0.1), dt=6e-4,
+                                      velocity=(0.0, -2.5, 0.0), gravitationUpper=0.33), 0.0, 0, [1, 10, 20]),
     "dfsph_box": (dam_break_scene(method="dfsph", domain_end=(0.32, 0.32, 0.32), start=(0.06, 0.06, 0.06),
                                   end=(0.14, 0.16, 0.14), translation=(0.0, 0.0, 0.0), add_domain_box=True, dt=6e-4,
                                   viscosity_b=0.3),
