@@ -10,6 +10,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <stdlib.h>
 #include <utility>
 
 static thread_local std::string g_create_error;
@@ -217,6 +218,8 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     CHK_CREATE(dalloc(h, &s.scan_partial, (size_t)s.scan_blocks + 1));
     CHK_CREATE(dalloc(h, &s.rho_raw, cap)); CHK_CREATE(dalloc(h, &s.prs, cap)); CHK_CREATE(dalloc(h, &s.ptm, cap));
     CHK_CREATE(dalloc(h, &s.acc, cap));
+    s.nbr_mask = nullptr; s.masks_valid = 0;
+    if (!getenv("SPH_NO_MASK_REUSE")) CHK_CREATE(dalloc(h, &s.nbr_mask, cap * 9));
     s.alpha = s.kappa = s.kappa_v = s.rho_star = s.rho_deriv = s.kappa_next = s.kappa_v_next = nullptr; s.kr = nullptr;
     s.pacc = s.pvel = s.ppos = s.acc_np = nullptr; s.np_acc_out = nullptr; s.np_visc_vel = nullptr;
     s.cg_p = s.cg_Ap = s.cg_x = s.cg_b = s.cg_r = s.cg_v0 = nullptr; s.cg_dinv = nullptr;
@@ -306,6 +309,7 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
     h->n_fluid += nfl;
     h->n_nonfluid += n - nfl;
     h->rigid_volume_done = false;
+    s.masks_valid = 0;
     refresh_counts(h);
     return SPH_OK;
 }
@@ -659,6 +663,7 @@ extern "C" int sph_upload(SphHandle *h, int field, const void *src, size_t bytes
     State &s = h->st;
     const size_t n = (size_t)h->n;
     HIPCHK(h, hipStreamSynchronize(s.stream));
+    s.masks_valid = 0;  // state edited from outside
     float4 *vdst = nullptr;
     bool w_only = false;
     switch (field) {

@@ -112,6 +112,8 @@ struct State {
     int *halo_counts;    // device: [0..1] send counts, [2] kept count
     int halo_cap;        // particles per message buffer
     int slab_active, z_lo, z_hi, has_down, has_up;
+    unsigned *nbr_mask;  // [9][cap]: acceptance mask of the first 32 candidates of every (particle, run), see process_run
+    int masks_valid;
     int has_emitter;     // gravitationUpper set (base_solver.py:18-23)
     int visc_rho_raw;    // viscosity reads rho_raw (WCSPH: density before the EOS clamp)
     int skip_viscosity;  // implicit viscosity: explicit term not part of the fused pass

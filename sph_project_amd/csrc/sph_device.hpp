@@ -334,48 +334,56 @@ __device__ __forceinline__ float2 lds_ld2(const float2 *p) {
     const unsigned long long v = *(lds_u64)(p);
     return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
-template <bool LDS, int ZW_OFF, class P>
+// MASKMODE: 0 = compute the acceptance masks; 1 = compute and store the first 32-candidate chunk of every run
+// (first neighbour pass after a sort); 2 = reuse the stored chunk (later passes over the same sorted positions:
+// phase 1 disappears).  Stored form: bit t = candidate js + t accepted.
+template <bool LDS, int ZW_OFF, int MASKMODE, class P>
 __device__ __forceinline__ void process_run(const Consts &c, const P &p, typename P::Own &own, int i, float xi,
                                             float yi, float zi, int js, int je, int loff, const float2 *sXY,
                                             const float2 *sZW, const typename P::BT *sB, int cap,
-                                            unsigned &npairs) {
+                                            unsigned &npairs, unsigned stored, unsigned *store_to) {
     if (LDS) {
-        for (int j0 = js; __any(j0 < je); j0 += 32) {  // wave-uniform trip count
+        int it = 0;
+        for (int j0 = js; __any(j0 < je); j0 += 32, ++it) {  // wave-uniform trip count
             int m = je - j0;
             m = m < 0 ? 0 : (m > 32 ? 32 : m);
             int base = j0 + loff;
             base = base > cap ? cap : base;            // lanes already past their run stay inside the tile
-            // Phase 1.  The acceptance bit of every slot is shifted into `mask` from the right by
-            // v_cmp (-> VCC) + v_addc_co (mask = 2 mask + VCC): two VOPC/VOP2 instructions per slot, no
-            // SGPR-pair results, no shift constants.  After S pushes slot t sits at bit S-1-t.
-            unsigned mask = 0;
-            int S = 0;
-            for (int t0 = 0; __any(t0 < m); t0 += 8) {
-                // All 16 ds_read_b64 of the chunk are issued back to back from one base register with
-                // immediate offsets and waited for once (hand-placed: left to itself the scheduler keeps at most
-                // one candidate in flight, or fuses neighbours into ds_read2_b64 = 8 LDS cycles per 16 bytes).
-                v2f xy[8], zw[8];
-                lds_load_chunk_imm<ZW_OFF>(lds_addr(&sXY[base + t0]), xy, zw);
+            unsigned nm;
+            if (MASKMODE == 2 && it == 0) {
+                nm = stored;
+            } else {
+                // Phase 1.  The acceptance bit of every slot is shifted into `mask` from the right by
+                // v_cmp (-> VCC) + v_addc_co (mask = 2 mask + VCC): two VOPC/VOP2 instructions per slot, no
+                // SGPR-pair results, no shift constants.  After S pushes slot t sits at bit S-1-t.
+                unsigned mask = 0;
+                int S = 0;
+                for (int t0 = 0; __any(t0 < m); t0 += 8) {
+                    // All 16 ds_read_b64 of the chunk are issued back to back from one base register with
+                    // immediate offsets and waited for once (hand-placed: left to itself the scheduler keeps at most
+                    // one candidate in flight, or fuses neighbours into ds_read2_b64 = 8 LDS cycles per 16 bytes).
+                    v2f xy[8], zw[8];
+                    lds_load_chunk_imm<ZW_OFF>(lds_addr(&sXY[base + t0]), xy, zw);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zw[u].x;
-                    const float r2 = dx * dx + dy * dy + dz * dz;
-                    asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                        : "+v"(mask) : "v"(r2), "v"(c.h2) : "vcc");  // not volatile: ordered by the dependence on mask
+                    for (int u = 0; u < 8; ++u) {
+                        const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zw[u].x;
+                        const float r2 = dx * dx + dy * dy + dz * dz;
+                        asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                            : "+v"(mask) : "v"(r2), "v"(c.h2) : "vcc");  // not volatile: ordered by the dependence on mask
+                    }
+                    S += 8;
                 }
-                S += 8;
+                nm = S > 0 ? __brev(mask) >> (32 - S) : 0u;          // bit t = slot t
+                nm &= m >= 32 ? 0xffffffffu : ((1u << m) - 1u);      // drop slots past this lane's run
+                const unsigned self = (unsigned)(i - j0);
+                if (self < 32u) nm &= ~(1u << self);                 // p_i != p_j (base_container.py:559)
+                if (MASKMODE == 1 && it == 0) *store_to = nm;
             }
-            // drop slots past this lane's run (low S-m bits) and the lane's own particle
-            const int drop = S - m;
-            mask = drop >= 32 ? 0u : (mask >> drop) << drop;
-            const unsigned self = (unsigned)(i - j0);
-            if (self < (unsigned)m) mask &= ~(1u << (S - 1 - (int)self));   // p_i != p_j (base_container.py:559)
-            npairs += __popc(mask);
-            if (c.force_global == 2) mask = 0;  // debug: phase 1 only
-            while (mask) {
-                const int pos = 31 - __clz(mask);
-                mask &= ~(1u << pos);
-                const int t = S - 1 - pos;       // ascending t: same accumulation order as the reference
+            npairs += __popc(nm);
+            if (c.force_global >= 2) nm = 0;  // debug: phase 1 only
+            while (nm) {
+                const int t = __ffs(nm) - 1;   // ascending t: same accumulation order as the reference
+                nm &= nm - 1;
                 const float2 xy = sXY[base + t];
                 const float2 zw = sZW[base + t];
                 const float dx = xi - xy.x, dy = yi - xy.y, dz = zi - zw.x;
@@ -386,6 +394,7 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
             }
         }
     } else {
+        if (MASKMODE == 1 && js >= je) *store_to = 0u;
         for (int j0 = js; j0 < je; j0 += 32) {
             const int m = (je - j0) < 32 ? (je - j0) : 32;
             unsigned mask = 0;
@@ -398,6 +407,7 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
                 const unsigned ok = (r2 < c.h2 && j != i) ? 1u : 0u;
                 mask |= ok << t;
             }
+            if (MASKMODE == 1 && j0 == js) *store_to = mask;
             npairs += __popc(mask);
             while (mask) {
                 const int t = __ffs(mask) - 1;
@@ -417,10 +427,10 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
 #define NBR_CS_SPAN 124
 #define NBR_BLOCK 256  // cell_start window cached in LDS per run: cells [first-1, last+1] (+ end) of the workgroup
 
-template <class P>
+template <class P, int MASKMODE>
 __global__ void __launch_bounds__(P::BLOCK)
 k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevScalars *__restrict__ scal,
-           int nblocks) {
+           int nblocks, unsigned *__restrict__ nbr_mask, int mask_stride) {
     constexpr int BLOCK = P::BLOCK;
     constexpr int CAP = P::CAP;          // LDS particle slots per staging group
     constexpr int GROUPS = P::GROUPS;    // 1: all nine runs staged at once; 3: one x-offset (3 runs) at a time
@@ -537,9 +547,16 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     }
                     const int loff = s_loff[k];
                     if (c.force_global == 6) { npairs += (unsigned)(je - js); continue; }  // debug: run setup only
+                    unsigned stored = 0;
+                    unsigned *mslot = nbr_mask + (size_t)k * mask_stride + i;
+                    if (MASKMODE == 2) stored = *mslot;
                     // s_loff is workgroup-uniform, so every lane of the wave takes the same branch (process_run uses __any)
-                    if (loff != INT_MIN) process_run<true, ZW_OFF>(c, p, own, i, pi.x, pi.y, pi.z, js, je, loff, sXY, sZW, sB, CAP, npairs);
-                    else process_run<false, ZW_OFF>(c, p, own, i, pi.x, pi.y, pi.z, js, je, 0, sXY, sZW, sB, CAP, npairs);
+                    if (loff != INT_MIN) process_run<true, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, je, loff, sXY, sZW, sB, CAP, npairs, stored, mslot);
+                    else {
+                        // tile overflow: candidates straight from L2; a stored chunk-0 mask is recomputed here, and when this
+                        // pass is the one that stores masks the slot gets the same bits the LDS path would have produced
+                        process_run<false, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, je, 0, sXY, sZW, sB, CAP, npairs, stored, mslot);
+                    }
                 }
             }
             if (GROUPS > 1) __syncthreads();  // LDS is restaged by the next group

@@ -61,26 +61,37 @@ void l_scatter_impl(State &s, bool stable) {
     }
     (void)tmp_idx;
     s.posv.flip(); s.velm.flip(); s.meta.flip(); s.pid.flip(); s.color.flip(); s.rho.flip();
+    s.masks_valid = 0;  // new order, new candidate runs
     if (s.orig.cur()) s.orig.flip();
     if (s.slab_active) s.xcur = 1 - s.xcur;
 }
 void l_scatter(State &s) { l_scatter_impl(s, false); }
 void l_scatter_stable(State &s) { l_scatter_impl(s, true); }
 
-template <class P> void launch_pass(State &s, const P &p) {
+// mask_mode: 0 compute, 1 compute + store (first pass after a sort), 2 reuse (see process_run)
+template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     const int n = s.c.n;
     if (n == 0) return;
     const int nb = cdiv(n, P::BLOCK);
-    hipLaunchKernelGGL((k_nbr_pass<P>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb);
+    if (!s.nbr_mask || s.c.force_global) mask_mode = 0;
+    if (mask_mode == 2 && !s.masks_valid) mask_mode = 0;
+    if (mask_mode == 1) {
+        hipLaunchKernelGGL((k_nbr_pass<P, 1>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap);
+        s.masks_valid = 1;
+    } else if (mask_mode == 2) {
+        hipLaunchKernelGGL((k_nbr_pass<P, 2>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap);
+    } else {
+        hipLaunchKernelGGL((k_nbr_pass<P, 0>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap);
+    }
 }
 
 void l_density(State &s, int eos) {
     if (s.c.all_fluid) {
-        if (eos) { DensityPass<true, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p); }
-        else { DensityPass<true, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p); }
+        if (eos) { DensityPass<true, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p, 1); }
+        else { DensityPass<true, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p, 1); }
     } else {
-        if (eos) { DensityPass<false, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p); }
-        else { DensityPass<false, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p); }
+        if (eos) { DensityPass<false, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p, 1); }
+        else { DensityPass<false, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p, 1); }
     }
 }
 
@@ -89,10 +100,10 @@ void l_non_pressure(State &s) {
     const float *rho_src = s.visc_rho_raw ? s.rho_raw : s.rho.cur();
     if (s.c.all_fluid) {
         NonPressurePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), rho_src, s.velm.alt(), s.scal, s.pose, s.c.rho0, s.skip_viscosity, s.np_acc_out, s.np_visc_vel};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     } else {
         NonPressurePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), rho_src, s.velm.alt(), s.scal, s.pose, s.c.rho0, s.skip_viscosity, s.np_acc_out, s.np_visc_vel};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     }
     s.velm.flip();
 }
@@ -120,12 +131,13 @@ k_emitter_advance(const Consts c, float4 *posv, const float4 *velm, int *meta, c
 void l_pressure_integrate(State &s) {
     if (s.c.all_fluid) {
         PressurePass<true> p{s.posv.cur(), s.meta.cur(), s.ptm, s.prs, s.rho.cur(), s.velm.cur(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, 1};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     } else {
         PressurePass<false> p{s.posv.cur(), s.meta.cur(), s.ptm, s.prs, s.rho.cur(), s.velm.cur(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, 1};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     }
     s.posv.flip();
+    s.masks_valid = 0;  // positions moved
     if (s.has_emitter && s.c.n > 0)
         hipLaunchKernelGGL(k_emitter_advance, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(),
                            s.velm.cur(), s.meta.cur(), s.pose);
@@ -162,6 +174,7 @@ k_renew_rigid(const Consts c, float4 *posv, float4 *velm, const float4 *orig, co
 
 void l_renew_rigid(State &s) {
     if (!s.has_dynamic_rigid || s.c.n == 0 || !s.orig.cur()) return;
+    s.masks_valid = 0;  // rigid particles move
     hipLaunchKernelGGL(k_renew_rigid, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(),
                        s.velm.cur(), s.orig.cur(), s.meta.cur(), s.pose);
 }

@@ -29,6 +29,7 @@ k_advect_boundary(const Consts c, float4 *posv, float4 *velm, int *meta, const R
 
 static void l_advect_boundary(State &s) {
     if (s.c.n == 0) return;
+    s.masks_valid = 0;  // positions move
     hipLaunchKernelGGL(k_advect_boundary, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(),
                        s.velm.cur(), s.meta.cur(), s.pose, s.c.all_fluid);
 }
@@ -38,8 +39,8 @@ static void l_reduce_sum(State &s, int slot, int nblocks) {
 }
 
 static void l_dfsph_density_alpha(State &s) {
-    if (s.c.all_fluid) { DfsphDensityAlphaPass<true> p{s.posv.cur(), s.meta.cur(), s.rho.cur(), s.alpha, s.red_partial}; launch_pass(s, p); }
-    else { DfsphDensityAlphaPass<false> p{s.posv.cur(), s.meta.cur(), s.rho.cur(), s.alpha, s.red_partial}; launch_pass(s, p); }
+    if (s.c.all_fluid) { DfsphDensityAlphaPass<true> p{s.posv.cur(), s.meta.cur(), s.rho.cur(), s.alpha, s.red_partial}; launch_pass(s, p, 1); }
+    else { DfsphDensityAlphaPass<false> p{s.posv.cur(), s.meta.cur(), s.rho.cur(), s.alpha, s.red_partial}; launch_pass(s, p, 1); }
 }
 
 template <int MODE> static void dfsph_rho_adv_t(State &s, int slot) {
@@ -47,10 +48,10 @@ template <int MODE> static void dfsph_rho_adv_t(State &s, int slot) {
     float *out_k = MODE == 0 ? s.kappa_v_next : s.kappa_next;
     if (s.c.all_fluid) {
         DfsphRhoAdvPass<true, MODE> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.alpha, out_adv, out_k, s.red_partial};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     } else {
         DfsphRhoAdvPass<false, MODE> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.alpha, out_adv, out_k, s.red_partial};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     }
     if (s.c.n > 0) l_reduce_sum(s, slot, cdiv(s.c.n, NBR_BLOCK));
 }
@@ -60,10 +61,10 @@ template <int MODE> static void dfsph_correct_t(State &s) {
     const float *kap = MODE == 0 ? s.kappa_v : s.kappa;
     if (s.c.all_fluid) {
         DfsphCorrectPass<true, MODE> p{s.posv.cur(), s.meta.cur(), kap, s.rho.cur(), s.velm.cur(), s.scal, s.pose, s.c.rho0, s.red_partial};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     } else {
         DfsphCorrectPass<false, MODE> p{s.posv.cur(), s.meta.cur(), kap, s.rho.cur(), s.velm.cur(), s.scal, s.pose, s.c.rho0, s.red_partial};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     }
 }
 static void l_dfsph_correct(State &s, int mode) { if (mode == 0) dfsph_correct_t<0>(s); else dfsph_correct_t<1>(s); }
@@ -93,10 +94,10 @@ static void l_pcisph_init(State &s) {
 static void l_pcisph_rho_star(State &s) {
     if (s.c.all_fluid) {
         PcisphRhoStarPass<true> p{s.posv.cur(), s.ppos, s.meta.cur(), s.rho.cur(), s.rho_star, s.prs, s.ptm, s.red_partial};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     } else {
         PcisphRhoStarPass<false> p{s.posv.cur(), s.ppos, s.meta.cur(), s.rho.cur(), s.rho_star, s.prs, s.ptm, s.red_partial};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     }
     if (s.c.n > 0) l_reduce_sum(s, 2, cdiv(s.c.n, NBR_BLOCK));
 }
@@ -104,21 +105,21 @@ static void l_pcisph_rho_star(State &s) {
 static void l_pcisph_pressure_accel(State &s) {
     if (s.c.all_fluid) {
         PcisphPressureAccelPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.ptm, s.acc_np, s.velm.alt(), s.pacc, s.pvel, s.ppos, s.c.rho0, s.red_partial};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     } else {
         PcisphPressureAccelPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.ptm, s.acc_np, s.velm.alt(), s.pacc, s.pvel, s.ppos, s.c.rho0, s.red_partial};
-        launch_pass(s, p);
+        launch_pass(s, p, 2);
     }
 }
 
 // ---- implicit viscosity
 static void l_cg_prepare(State &s) {
-    if (s.c.all_fluid) { CgPreparePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p); }
-    else { CgPreparePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p); }
+    if (s.c.all_fluid) { CgPreparePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p, 2); }
+    else { CgPreparePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p, 2); }
 }
 static void l_cg_ap(State &s) {
-    if (s.c.all_fluid) { CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, s.red_partial}; launch_pass(s, p); }
-    else { CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, s.red_partial}; launch_pass(s, p); }
+    if (s.c.all_fluid) { CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, s.red_partial}; launch_pass(s, p, 2); }
+    else { CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, s.red_partial}; launch_pass(s, p, 2); }
 }
 static void l_cg_prepare2(State &s) {
     if (s.c.n == 0) return;
