@@ -12,6 +12,8 @@ Fields are exposed as small views (`container.particle_positions.to_numpy()`,
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .. import _engine_fields as F
@@ -138,7 +140,7 @@ class BaseContainer:
         p.fixed_iterations = pd["fixed_iterations"]
         p.fast_math = int(engine_opts.get("fast_math", 0))
         p.device = int(engine_opts.get("device", -1))
-        p.force_global = int(engine_opts.get("force_global", 0))
+        p.force_global = int(engine_opts.get("force_global", os.environ.get("SPH_DEBUG_MODE", 0)))  # debug: 1 global path, 4 ordered path
         p.deterministic = int(engine_opts.get("deterministic", 1))
         self.params_dict = pd
         self.engine = F.lib.Engine(p)

@@ -220,6 +220,9 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     CHK_CREATE(dalloc(h, &s.acc, cap));
     s.nbr_mask = nullptr; s.masks_valid = 0;
     if (!getenv("SPH_NO_MASK_REUSE")) CHK_CREATE(dalloc(h, &s.nbr_mask, cap * 9));
+    s.lane_perm = nullptr; s.perm_n = -1;
+    CHK_CREATE(dalloc(h, &s.blk_hdr, (cap + 255) / 256 * 20));
+    if (s.nbr_mask && !getenv("SPH_NO_LANE_PERM")) CHK_CREATE(dalloc(h, &s.lane_perm, (cap + 255) / 256 * 256));
     s.alpha = s.kappa = s.kappa_v = s.rho_star = s.rho_deriv = s.kappa_next = s.kappa_v_next = nullptr; s.kr = nullptr;
     s.pacc = s.pvel = s.ppos = s.acc_np = nullptr; s.np_acc_out = nullptr; s.np_visc_vel = nullptr;
     s.cg_p = s.cg_Ap = s.cg_x = s.cg_b = s.cg_r = s.cg_v0 = nullptr; s.cg_dinv = nullptr;
@@ -310,6 +313,7 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
     h->n_nonfluid += n - nfl;
     h->rigid_volume_done = false;
     s.masks_valid = 0;
+    s.perm_n = -1;
     refresh_counts(h);
     return SPH_OK;
 }

@@ -21,6 +21,7 @@ __device__ __forceinline__ void mat3_inverse(const float *a, float *o) {
 template <bool AF>
 struct CgPreparePass {
     static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 2;  // A_ii pass + b_i pass of the reference
     typedef float4 BT;
@@ -95,6 +96,7 @@ struct CgPreparePass {
 template <bool AF>
 struct CgApPass {
     static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 1;
     typedef float4 BT;

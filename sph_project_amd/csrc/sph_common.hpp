@@ -114,6 +114,9 @@ struct State {
     int slab_active, z_lo, z_hi, has_down, has_up;
     unsigned *nbr_mask;  // [9][cap]: acceptance mask of the first 32 candidates of every (particle, run), see process_run
     int masks_valid;
+    unsigned char *lane_perm;  // [ceil(cap / 256) * 256]: lane -> particle map of every 256-particle workgroup (k_lane_perm)
+    int *blk_hdr;              // [ceil(cap / 256)][BLK_HDR_INTS]: cell span and candidate-run windows of every workgroup
+    int perm_n;                // particle count blk_hdr / lane_perm were built for (-1: none)
     int has_emitter;     // gravitationUpper set (base_solver.py:18-23)
     int visc_rho_raw;    // viscosity reads rho_raw (WCSPH: density before the EOS clamp)
     int skip_viscosity;  // implicit viscosity: explicit term not part of the fused pass

@@ -336,7 +336,40 @@ __device__ __forceinline__ float2 lds_ld2(const float2 *p) {
 }
 // MASKMODE: 0 = compute the acceptance masks; 1 = compute and store the first 32-candidate chunk of every run
 // (first neighbour pass after a sort); 2 = reuse the stored chunk (later passes over the same sorted positions:
-// phase 1 disappears).  Stored form: bit t = candidate js + t accepted.
+// phase 1 disappears).  Stored form: bit t = candidate js + t accepted (self already removed).
+
+// Phase 1 for the <= 32 candidates at tile slots [base, base + m).  Must be called by all lanes of the wave
+// (wave-uniform trip count; lanes without candidates pass m = 0).  Returns bit t = slot base + t accepted.
+template <int ZW_OFF>
+__device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int m, float xi, float yi, float zi,
+                                                float h2) {
+    // The acceptance bit of every slot is shifted into `mask` from the right by v_cmp (-> VCC) + v_addc_co
+    // (mask = 2 mask + VCC): two VOPC/VOP2 instructions per slot, no SGPR-pair results, no shift constants.
+    // After S pushes slot t sits at bit S-1-t.
+    unsigned mask = 0;
+    int S = 0;
+    for (int t0 = 0; __any(t0 < m); t0 += 8) {
+        // All 16 ds_read_b64 of the chunk are issued back to back from one base register with immediate
+        // offsets and waited for once (hand-placed: left to itself the scheduler keeps at most one candidate
+        // in flight, or fuses neighbours into ds_read2_b64 = 8 LDS cycles per 16 bytes).
+        v2f xy[8], zw[8];
+        lds_load_chunk_imm<ZW_OFF>(lds_addr(&sXY[base + t0]), xy, zw);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zw[u].x;
+            const float r2 = dx * dx + dy * dy + dz * dz;
+            asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                : "+v"(mask) : "v"(r2), "v"(h2) : "vcc");  // not volatile: ordered by the dependence on mask
+        }
+        S += 8;
+    }
+    unsigned nm = S > 0 ? __brev(mask) >> (32 - S) : 0u;   // bit t = slot t
+    nm &= m >= 32 ? 0xffffffffu : ((1u << m) - 1u);        // drop slots past this lane's run
+    return nm;
+}
+
+// Ordered path: lane i walks run [js, je) itself, 32 candidates at a time.  Used for the groups the balanced
+// path below does not take (tile overflow, runs longer than 32 candidates, sparse cell windows).
 template <bool LDS, int ZW_OFF, int MASKMODE, class P>
 __device__ __forceinline__ void process_run(const Consts &c, const P &p, typename P::Own &own, int i, float xi,
                                             float yi, float zi, int js, int je, int loff, const float2 *sXY,
@@ -351,36 +384,17 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
             base = base > cap ? cap : base;            // lanes already past their run stay inside the tile
             unsigned nm;
             if (MASKMODE == 2 && it == 0) {
-                nm = stored;
+                // a lane without candidates may sit here because of its wave neighbours: its slot was never written by
+                // the storing pass if no lane of *that* wave had candidates (wave composition differs with the lane
+                // permutation)
+                nm = m > 0 ? stored : 0u;
             } else {
-                // Phase 1.  The acceptance bit of every slot is shifted into `mask` from the right by
-                // v_cmp (-> VCC) + v_addc_co (mask = 2 mask + VCC): two VOPC/VOP2 instructions per slot, no
-                // SGPR-pair results, no shift constants.  After S pushes slot t sits at bit S-1-t.
-                unsigned mask = 0;
-                int S = 0;
-                for (int t0 = 0; __any(t0 < m); t0 += 8) {
-                    // All 16 ds_read_b64 of the chunk are issued back to back from one base register with
-                    // immediate offsets and waited for once (hand-placed: left to itself the scheduler keeps at most
-                    // one candidate in flight, or fuses neighbours into ds_read2_b64 = 8 LDS cycles per 16 bytes).
-                    v2f xy[8], zw[8];
-                    lds_load_chunk_imm<ZW_OFF>(lds_addr(&sXY[base + t0]), xy, zw);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zw[u].x;
-                        const float r2 = dx * dx + dy * dy + dz * dz;
-                        asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                            : "+v"(mask) : "v"(r2), "v"(c.h2) : "vcc");  // not volatile: ordered by the dependence on mask
-                    }
-                    S += 8;
-                }
-                nm = S > 0 ? __brev(mask) >> (32 - S) : 0u;          // bit t = slot t
-                nm &= m >= 32 ? 0xffffffffu : ((1u << m) - 1u);      // drop slots past this lane's run
+                nm = phase1_mask<ZW_OFF>(sXY, base, m, xi, yi, zi, c.h2);
                 const unsigned self = (unsigned)(i - j0);
                 if (self < 32u) nm &= ~(1u << self);                 // p_i != p_j (base_container.py:559)
                 if (MASKMODE == 1 && it == 0) *store_to = nm;
             }
             npairs += __popc(nm);
-            if (c.force_global >= 2) nm = 0;  // debug: phase 1 only
             while (nm) {
                 const int t = __ffs(nm) - 1;   // ascending t: same accumulation order as the reference
                 nm &= nm - 1;
@@ -424,142 +438,300 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
     }
 }
 
-#define NBR_CS_SPAN 124
-#define NBR_BLOCK 256  // cell_start window cached in LDS per run: cells [first-1, last+1] (+ end) of the workgroup
+// pair() receives the neighbour's sorted index j only where the functor needs it (rigid-body wrench):
+// P::USES_J = false lets the merged loop drop the bookkeeping.
+template <class P, class = void> struct PassUsesJ { static constexpr bool value = true; };
+template <class P> struct PassUsesJ<P, decltype((void)P::USES_J)> { static constexpr bool value = P::USES_J; };
+
+// Phase 2 of one staging group: the accepted candidates of the group's three runs (masks m0..m2, bit t = tile slot
+// base_q + t, byte offsets a_q = 8 base_q) are consumed in ONE loop, run after run in ascending order -- the
+// reference's accumulation order -- so a wave iterates max_lanes(sum of the three runs) times instead of
+// sum_runs max_lanes(run).  Together with the lane permutation (k_lane_perm) this removes most of the divergence
+// loss: C2 lattice 45 -> 26 iterations per wave, disordered dam break 96 -> 53 (tools/analysis/imbalance.py).
+template <class P, int ZW_OFF>
+__device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typename P::Own &own, float xi, float yi,
+                                              float zi, unsigned m0, unsigned m1, unsigned m2, unsigned a0,
+                                              unsigned a1, unsigned a2, const float2 *sXY,
+                                              const typename P::BT *sB, const int *s_loff3) {
+    constexpr bool UJ = PassUsesJ<P>::value;
+    int q0 = 0, q1 = 1, q2 = 2;
+    // non-empty runs first (order kept)
+    if (m0 == 0u) { m0 = m1; a0 = a1; q0 = q1; m1 = m2; a1 = a2; q1 = q2; m2 = 0u; }
+    if (m0 == 0u) { m0 = m1; a0 = a1; q0 = q1; m1 = 0u; }
+    if (m1 == 0u) { m1 = m2; a1 = a2; q1 = q2; m2 = 0u; }
+    unsigned cur = m0, ca = a0;
+    int cq = q0;
+    const unsigned tile = lds_addr(sXY);
+    while (cur) {
+        const int t = __ffs(cur) - 1;
+        cur &= cur - 1;
+        const unsigned ad = ca + ((unsigned)t << 3);
+        const float2 xy = lds_ld2a(tile + ad);
+        const float2 zw = lds_ld2a(tile + ad + ZW_OFF);
+        typename P::BT bj = typename P::BT();
+        if (P::HAS_B) bj = sB[ad >> 3];
+        const float dx = xi - xy.x, dy = yi - xy.y, dz = zi - zw.x;
+        const float r2 = dx * dx + dy * dy + dz * dz;
+        int j = 0;
+        if (UJ) j = (int)(ad >> 3) - s_loff3[cq];
+        p.pair(c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, j);
+        if (cur == 0u) { cur = m1; ca = a1; m1 = m2; a1 = a2; m2 = 0u; if (UJ) { cq = q1; q1 = q2; } }
+    }
+}
+
+// Per-workgroup data prepared once per sort (k_block_prep), read by every neighbour pass of the sort epoch:
+// header = cells of the first / last particle + the 9 candidate-run windows (start, length); lane permutation.
+#define BLK_HDR_INTS 20   // [0] first cell, [1] last cell, [2..10] run start, [11..19] run length
+#define NBR_CS_SPAN 124   // cell_start window cached in LDS per run: cells [first-1, last+1] (+ end) of the workgroup
+#define NBR_CS_PITCH (NBR_CS_SPAN + 4)
+#define NBR_BLOCK 256
+
+// Lane permutation of a workgroup (256 consecutive sorted particles): particles stably sorted by their x position
+// inside the cell.  The x-offset groups (-1, 0, +1) of the neighbour pass hold very different numbers of accepted
+// neighbours for particles in the low-x and the high-x part of a cell; putting like with like makes the 64 lanes
+// of a wave agree on their trip counts per group.  Any permutation is correct (every lane still walks its own
+// particle's neighbours in reference order); this one is only faster.  perm[b * 256 + lane] = particle of the lane.
+__global__ void __launch_bounds__(256)
+k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restrict__ cell_start,
+             int *__restrict__ blk_hdr, unsigned char *__restrict__ perm) {
+    __shared__ int s_cnt[4][64];
+    __shared__ int s_c[2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i0 = blockIdx.x * 256;
+    const int i = i0 + tid;
+    const int nvalid = (c.n - i0) < 256 ? (c.n - i0) : 256;
+    int key = 63;  // slots past the end go last
+    if (i < c.n) {
+        const float4 p = posv[i];
+        const int cx = cell_coord(p.x, c.grid_size, c.nx);
+        const int k = (int)((p.x / c.grid_size - (float)cx) * 62.0f);
+        key = k < 0 ? 0 : (k > 62 ? 62 : k);
+        if (tid == 0 || tid == nvalid - 1) {
+            const int cy = cell_coord(p.y, c.grid_size, c.ny);
+            const int cz = cell_coord(p.z, c.grid_size, c.nz);
+            const int lin = (cx * c.ny + cy) * c.nz + cz;
+            if (tid == 0) s_c[0] = lin;
+            if (tid == nvalid - 1) s_c[1] = lin;
+        }
+    }
+    (&s_cnt[0][0])[tid] = 0;
+    unsigned long long peers = ~0ull;   // lanes of this wave holding the same key
+#pragma unroll
+    for (int bit = 0; bit < 6; ++bit) {
+        const bool on = (key >> bit) & 1;
+        const unsigned long long bal = __ballot(on);
+        peers &= on ? bal : ~bal;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int rank_in_wave = __popcll(peers & below);
+    __syncthreads();
+    if ((peers & below) == 0ull) s_cnt[w][key] = __popcll(peers);
+    if (tid < 9) {
+        const int cfirst = s_c[0], clast = s_c[1];
+        const int shift = (tid / 3 - 1) * c.ny * c.nz + (tid % 3 - 1) * c.nz;
+        int lo = cfirst + shift - 1, hi = clast + shift + 1;
+        int rs = 0, re = 0;
+        if (clast >= cfirst && hi >= 0 && lo <= c.G - 1) {
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > c.G - 1 ? c.G - 1 : hi;
+            rs = cell_start[lo];
+            re = cell_start[hi + 1];
+        }
+        int *h = blk_hdr + (size_t)blockIdx.x * BLK_HDR_INTS;
+        if (tid == 0) { h[0] = cfirst; h[1] = clast; }
+        h[2 + tid] = rs;
+        h[11 + tid] = re - rs;
+    }
+    __syncthreads();
+    if (perm) {
+        const int tot = s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane];
+        const int incl = wave_incl_scan(tot);
+        int dest = __shfl(incl - tot, key, 64) + rank_in_wave;
+        for (int k = 0; k < w; ++k) dest += s_cnt[k][key];
+        perm[i0 + dest] = (unsigned char)tid;
+    }
+}
 
 template <class P, int MASKMODE>
 __global__ void __launch_bounds__(P::BLOCK)
 k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevScalars *__restrict__ scal,
-           int nblocks, unsigned *__restrict__ nbr_mask, int mask_stride) {
+           int nblocks, unsigned *__restrict__ nbr_mask, int mask_stride,
+           const int *__restrict__ blk_hdr, const unsigned char *__restrict__ lane_perm) {
     constexpr int BLOCK = P::BLOCK;
     constexpr int CAP = P::CAP;          // LDS particle slots per staging group
-    constexpr int GROUPS = P::GROUPS;    // 1: all nine runs staged at once; 3: one x-offset (3 runs) at a time
-    constexpr int RPG = 9 / GROUPS;
+    constexpr int GROUPS = 3, RPG = 3;   // one x-offset (3 runs) staged at a time
+    static_assert(P::GROUPS == 3 && BLOCK == 256 && CAP <= 4 * BLOCK, "staging is unrolled 4 slots per thread");
+    typedef typename P::Own Own;
+    typedef typename P::BT BT;
     __shared__ float2 sT[2 * (CAP + NBR_PAD)];   // (x,y) slots followed by (z,w) slots: fixed byte distance
     float2 *const sXY = sT;
     float2 *const sZW = sT + (CAP + NBR_PAD);
     constexpr int ZW_OFF = (CAP + NBR_PAD) * 8;
-    __shared__ typename P::BT sB[P::HAS_B ? CAP + NBR_PAD : 1];
-    __shared__ int s_cs[9][NBR_CS_SPAN + 4];
-    __shared__ int s_rs[9], s_len[9], s_loff[9], s_c[2], s_any, s_tot;
+    __shared__ BT sB[P::HAS_B ? CAP + NBR_PAD : 1];
+    __shared__ int s_cs[9][NBR_CS_PITCH];
+    __shared__ int s_loff[9];   // tile offset - run start of every run (INT_MIN: not staged)
 
     const int tid = threadIdx.x;
     const int b = xcd_remap(blockIdx.x, nblocks);
     const int i0 = b * BLOCK;
-    const int i = i0 + tid;
+    // which particle of the workgroup this lane owns for the whole pass
+    const int who = lane_perm ? (int)lane_perm[i0 + tid] : tid;
+    const int i = i0 + who;
     const bool valid = i < c.n;
-    const int nvalid = (c.n - i0) < BLOCK ? (c.n - i0) : BLOCK;
 
+    // workgroup header (uniform)
+    const int *hdr = blk_hdr + (size_t)b * BLK_HDR_INTS;
+    const int cfirst = hdr[0], clast = hdr[1];
+    const int span = clast - cfirst;
+    const bool cs_lds = span >= 0 && span <= NBR_CS_SPAN;
+    // in flight together: own particle, cell_start windows (entry e of run k <-> cell cfirst + shift_k - 1 + e)
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
-    typename P::Own own;
+    if (valid) pi = p.posv[i];
+    if (cs_lds && tid < span + 4) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            int cell = cfirst + (k / 3 - 1) * c.ny * c.nz + (k % 3 - 1) * c.nz - 1 + tid;
+            cell = cell < 0 ? 0 : (cell > c.G ? c.G : cell);
+            s_cs[k][tid] = cell_start[cell];
+        }
+    }
+    Own own;
     bool active = false;
     int cx = 0, cy = 0, cz = 0, lin = 0;
-    if (tid == 0) s_any = 0;
-    __syncthreads();
     if (valid) {
-        pi = p.posv[i];
         cx = cell_coord(pi.x, c.grid_size, c.nx);
         cy = cell_coord(pi.y, c.grid_size, c.ny);
         cz = cell_coord(pi.z, c.grid_size, c.nz);
         lin = (cx * c.ny + cy) * c.nz + cz;
-        if (tid == 0) s_c[0] = lin;
-        if (tid == nvalid - 1) s_c[1] = lin;
         active = p.begin(c, i, pi, own);
-        if (active) s_any = 1;
     }
-    __syncthreads();
-    if (s_any) {  // workgroup-uniform
-        const int cfirst = s_c[0], clast = s_c[1];
-        const int span = clast - cfirst;
-        const bool cs_lds = span <= NBR_CS_SPAN;  // workgroup-uniform
-        if (tid < 9) {
-            const int shift = (tid / 3 - 1) * c.ny * c.nz + (tid % 3 - 1) * c.nz;
-            int lo = cfirst + shift - 1, hi = clast + shift + 1;
-            int rs = 0, re = 0;
-            if (hi >= 0 && lo <= c.G - 1) {
-                lo = lo < 0 ? 0 : lo;
-                hi = hi > c.G - 1 ? c.G - 1 : hi;
-                rs = cell_start[lo];
-                re = cell_start[hi + 1];
-            }
-            s_rs[tid] = rs;
-            s_len[tid] = re - rs;
-        }
-        if (cs_lds) {  // cache the cell_start window of every run: entry e <-> cell (cfirst + shift - 1 + e)
-            const int per = span + 4;
-            for (int t = tid; t < 9 * per; t += BLOCK) {
-                const int k = t / per, e = t - k * per;
-                int cell = cfirst + (k / 3 - 1) * c.ny * c.nz + (k % 3 - 1) * c.nz - 1 + e;
-                cell = cell < 0 ? 0 : (cell > c.G ? c.G : cell);
-                s_cs[k][e] = cell_start[cell];
-            }
-        }
-        __syncthreads();
+    if (__syncthreads_or(active ? 1 : 0)) {  // workgroup-uniform; also publishes s_cs
         // this lane's z window
         const int z0 = cz > 0 ? cz - 1 : 0;
         const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
+        const int e0 = (lin - cfirst) + (z0 - cz) + 1;   // s_cs entry of (.., .., z0) in every run
+        const int e1 = e0 + (z1 - z0) + 1;
         unsigned npairs = 0;
-        for (int g = 0; g < GROUPS; ++g) {
-            if (tid == 0) {
-                int acc = 0;
-                for (int k = g * RPG; k < g * RPG + RPG; ++k) {
-                    if (c.force_global != 1 && acc + s_len[k] <= CAP) { s_loff[k] = acc - s_rs[k]; acc += s_len[k]; }
-                    else { s_loff[k] = INT_MIN; if (s_len[k] > 0) atomicAdd(&scal->fallback[b & (SPH_STAT_SLOTS - 1)], 1ull); }
-                }
-                s_tot = acc;
-            }
-            __syncthreads();
-            {   // stage the runs of this group that fit (coalesced: consecutive t -> consecutive j)
-                const int total = s_tot;
-                int rs_[RPG], lo_[RPG], ln_[RPG];
-#pragma unroll
-                for (int q = 0; q < RPG; ++q) { rs_[q] = s_rs[g * RPG + q]; lo_[q] = s_loff[g * RPG + q]; ln_[q] = s_len[g * RPG + q]; }
-                for (int t = tid; t < total; t += BLOCK) {
-                    int j = -1;
-#pragma unroll
-                    for (int q = 0; q < RPG; ++q) {
-                        if (lo_[q] != INT_MIN) { const int jj = t - lo_[q]; if (jj >= rs_[q] && jj < rs_[q] + ln_[q]) j = jj; }
-                    }
-                    typename P::BT bj = typename P::BT();
-                    const float4 a = p.stage(c, j, bj);
-                    sXY[t] = make_float2(a.x, a.y);
-                    sZW[t] = make_float2(a.z, a.w);
-                    if (P::HAS_B) sB[t] = bj;
-                }
-            }
-            __syncthreads();
-            if (active && c.force_global != 3) {  // 3 = debug: staging only
 #pragma unroll 1
-                for (int k = g * RPG; k < g * RPG + RPG; ++k) {
-                    const int xx = cx + k / 3 - 1, yy = cy + k % 3 - 1;
-                    if (xx < 0 || xx >= c.nx || yy < 0 || yy >= c.ny) continue;
-                    int js, je;
-                    if (cs_lds) {
-                        const int e = (lin - cfirst) + (z0 - cz) + 1;
-                        // explicit LDS loads: a plain s_cs[k][e] here gets merged with the global branch below
-                        // into ONE flat load through a generic pointer -- measured 200 us of a 280 us pass.
-                        js = lds_ld_i32(&s_cs[k][e]);
-                        je = lds_ld_i32(&s_cs[k][e + (z1 - z0) + 1]);
-                    } else {
-                        const int lin0 = (xx * c.ny + yy) * c.nz + z0;
-                        js = cell_start[lin0];
-                        je = cell_start[lin0 + (z1 - z0) + 1];
+        for (int g = 0; g < GROUPS; ++g) {
+            // tile plan of the group (uniform): the runs that fit are laid out back to back
+            int rs_[RPG], ln_[RPG], lo_[RPG];
+            int total = 0;
+            bool overflow = false;
+#pragma unroll
+            for (int q = 0; q < RPG; ++q) {
+                rs_[q] = hdr[2 + g * RPG + q];
+                ln_[q] = hdr[11 + g * RPG + q];
+                if (c.force_global != 1 && total + ln_[q] <= CAP) { lo_[q] = total - rs_[q]; total += ln_[q]; }
+                else { lo_[q] = INT_MIN; overflow = true; ln_[q] = ln_[q] > 0 ? ln_[q] : 0; }
+            }
+            if (tid < RPG) {
+                s_loff[g * RPG + tid] = tid == 0 ? lo_[0] : (tid == 1 ? lo_[1] : lo_[2]);
+                const int l = tid == 0 ? ln_[0] : (tid == 1 ? ln_[1] : ln_[2]);
+                const int o = tid == 0 ? lo_[0] : (tid == 1 ? lo_[1] : lo_[2]);
+                if (o == INT_MIN && l > 0) atomicAdd(&scal->fallback[b & (SPH_STAT_SLOTS - 1)], 1ull);
+            }
+            // stored masks of this group's runs: issued before the staging so that their latency hides behind it
+            unsigned mk[RPG] = {0u, 0u, 0u};
+            bool inr[RPG];
+#pragma unroll
+            for (int q = 0; q < RPG; ++q) {
+                const int k = g * RPG + q;
+                const int xx = cx + g - 1, yy = cy + q - 1;
+                inr[q] = active && xx >= 0 && xx < c.nx && yy >= 0 && yy < c.ny;
+                if (MASKMODE == 2 && inr[q]) mk[q] = nbr_mask[(size_t)k * mask_stride + i];
+            }
+            {   // stage the runs that fit: <= 4 slots per thread, all loads issued before the first LDS write
+                // (one global round trip per group); consecutive t -> consecutive j: coalesced
+                const int n0 = lo_[0] != INT_MIN ? ln_[0] : 0;
+                const int n01 = n0 + (lo_[1] != INT_MIN ? ln_[1] : 0);
+                float4 a_[4];
+                BT b_[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = tid + u * BLOCK;
+                    if (t < total) {
+                        const int j = t < n0 ? t - lo_[0] : (t < n01 ? t - lo_[1] : t - lo_[2]);
+                        a_[u] = p.stage(c, j, b_[u]);
                     }
-                    const int loff = s_loff[k];
-                    if (c.force_global == 6) { npairs += (unsigned)(je - js); continue; }  // debug: run setup only
-                    unsigned stored = 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = tid + u * BLOCK;
+                    if (t < total) {
+                        sXY[t] = make_float2(a_[u].x, a_[u].y);
+                        sZW[t] = make_float2(a_[u].z, a_[u].w);
+                        if (P::HAS_B) sB[t] = b_[u];
+                    }
+                }
+            }
+            __syncthreads();
+            // candidate sub-ranges of this lane's particle in the three runs
+            int js_[RPG], m_[RPG];
+            bool longrun = false;
+#pragma unroll
+            for (int q = 0; q < RPG; ++q) {
+                const int k = g * RPG + q;
+                js_[q] = 0; m_[q] = 0;
+                if (inr[q]) {
+                    if (cs_lds) {
+                        // explicit LDS loads: a plain s_cs[k][e] gets merged with the global branch into ONE flat load
+                        // through a generic pointer -- measured 200 us of a 280 us pass.
+                        js_[q] = lds_ld_i32(&s_cs[k][e0]);
+                        m_[q] = lds_ld_i32(&s_cs[k][e1]) - js_[q];
+                    } else {
+                        const int lin0 = ((cx + g - 1) * c.ny + (cy + q - 1)) * c.nz + z0;
+                        js_[q] = cell_start[lin0];
+                        m_[q] = cell_start[lin0 + (z1 - z0) + 1] - js_[q];
+                    }
+                    longrun = longrun || m_[q] > 32;
+                }
+            }
+            // the merged loop handles runs of <= 32 candidates out of the tile; anything else (tile overflow, a
+            // pile-up of > 32 particles in three cells, forced debug modes) walks its runs one by one, wave-uniformly
+            if (overflow || c.force_global != 0 || __any(longrun)) {
+#pragma unroll 1
+                for (int q = 0; q < RPG; ++q) {
+                    const int k = g * RPG + q;
+                    const int js = q == 0 ? js_[0] : (q == 1 ? js_[1] : js_[2]);
+                    const int m = q == 0 ? m_[0] : (q == 1 ? m_[1] : m_[2]);
+                    const bool in = q == 0 ? inr[0] : (q == 1 ? inr[1] : inr[2]);
+                    const int loff = q == 0 ? lo_[0] : (q == 1 ? lo_[1] : lo_[2]);
+                    if (!in) continue;
                     unsigned *mslot = nbr_mask + (size_t)k * mask_stride + i;
-                    if (MASKMODE == 2) stored = *mslot;
-                    // s_loff is workgroup-uniform, so every lane of the wave takes the same branch (process_run uses __any)
-                    if (loff != INT_MIN) process_run<true, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, je, loff, sXY, sZW, sB, CAP, npairs, stored, mslot);
+                    unsigned stored = 0;
+                    if (MASKMODE == 2) stored = q == 0 ? mk[0] : (q == 1 ? mk[1] : mk[2]);
+                    // loff is workgroup-uniform, so every lane of the wave takes the same branch (process_run uses __any)
+                    if (loff != INT_MIN) process_run<true, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, loff, sXY, sZW, sB, CAP, npairs, stored, mslot);
                     else {
                         // tile overflow: candidates straight from L2; a stored chunk-0 mask is recomputed here, and when this
                         // pass is the one that stores masks the slot gets the same bits the LDS path would have produced
-                        process_run<false, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, je, 0, sXY, sZW, sB, CAP, npairs, stored, mslot);
+                        process_run<false, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, 0, sXY, sZW, sB, CAP, npairs, stored, mslot);
                     }
                 }
+            } else {
+                // acceptance masks of the three runs, then one merged loop
+                unsigned ab[RPG];
+#pragma unroll
+                for (int q = 0; q < RPG; ++q) {
+                    const int k = g * RPG + q;
+                    const int base = inr[q] ? js_[q] + lo_[q] : 0;
+                    unsigned nm;
+                    if (MASKMODE == 2) {
+                        nm = m_[q] > 0 ? mk[q] : 0u;
+                    } else {
+                        nm = phase1_mask<ZW_OFF>(sXY, base, m_[q], pi.x, pi.y, pi.z, c.h2);
+                        const unsigned self = (unsigned)(i - js_[q]);
+                        if (self < 32u) nm &= ~(1u << self);      // p_i != p_j (base_container.py:559)
+                        if (MASKMODE == 1 && inr[q]) nbr_mask[(size_t)k * mask_stride + i] = nm;
+                    }
+                    mk[q] = nm;
+                    ab[q] = (unsigned)base << 3;
+                    npairs += __popc(nm);
+                }
+                merged_phase2<P, ZW_OFF>(c, p, own, pi.x, pi.y, pi.z, mk[0], mk[1], mk[2], ab[0], ab[1], ab[2], sXY, sB, &s_loff[g * RPG]);
             }
-            if (GROUPS > 1) __syncthreads();  // LDS is restaged by the next group
+            __syncthreads();  // LDS is restaged by the next group
         }
         if (P::COUNT_PAIRS) {
             float fp = wave_sum((float)npairs);  // <= 64 * few hundred: exact in f32
@@ -573,9 +745,13 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         else p.passive(c, i, pi);
     }
     if constexpr (P::HAS_REDUCE) {
-        // deterministic per-workgroup partial sum (fixed tree), finished by k_reduce_partials
+        // deterministic per-workgroup partial sum: particle order and a fixed tree (whatever the lane permutation),
+        // finished by k_reduce_partials
+        __shared__ float s_val[BLOCK];
         __shared__ float s_red[BLOCK / 64];
-        const float w = wave_sum(red);
+        s_val[who] = red;
+        __syncthreads();
+        const float w = wave_sum(s_val[tid]);
         if ((tid & 63) == 0) s_red[tid >> 6] = w;
         __syncthreads();
         if (tid == 0) {

@@ -37,6 +37,15 @@ void l_scan(State &s) {
                        s.cell_start, s.c.n);
 }
 
+// per-workgroup header + lane permutation of the neighbour passes (k_block_prep); valid until the order changes
+void l_block_prep(State &s) {
+    const int n = s.c.n;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_block_prep, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.cell_start,
+                       s.blk_hdr, s.lane_perm);
+    s.perm_n = n;
+}
+
 void l_scatter_impl(State &s, bool stable) {
     const int n = s.c.n;
     if (n == 0) return;
@@ -62,6 +71,7 @@ void l_scatter_impl(State &s, bool stable) {
     (void)tmp_idx;
     s.posv.flip(); s.velm.flip(); s.meta.flip(); s.pid.flip(); s.color.flip(); s.rho.flip();
     s.masks_valid = 0;  // new order, new candidate runs
+    l_block_prep(s);
     if (s.orig.cur()) s.orig.flip();
     if (s.slab_active) s.xcur = 1 - s.xcur;
 }
@@ -73,15 +83,19 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     const int n = s.c.n;
     if (n == 0) return;
     const int nb = cdiv(n, P::BLOCK);
-    if (!s.nbr_mask || s.c.force_global) mask_mode = 0;
+    if (!s.nbr_mask || s.c.force_global == 1) mask_mode = 0;
     if (mask_mode == 2 && !s.masks_valid) mask_mode = 0;
+    // lane permutation (k_lane_perm): only for the passes that reuse stored masks -- a pass that runs phase 1 keeps
+    // neighbouring lanes on neighbouring cells, which is what makes its LDS reads conflict-free
+    if (s.perm_n != n) l_block_prep(s);   // particles were appended since the last sort
+    const unsigned char *perm = (mask_mode == 2 && s.lane_perm) ? s.lane_perm : nullptr;
     if (mask_mode == 1) {
-        hipLaunchKernelGGL((k_nbr_pass<P, 1>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap);
+        hipLaunchKernelGGL((k_nbr_pass<P, 1>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap, s.blk_hdr, perm);
         s.masks_valid = 1;
     } else if (mask_mode == 2) {
-        hipLaunchKernelGGL((k_nbr_pass<P, 2>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap);
+        hipLaunchKernelGGL((k_nbr_pass<P, 2>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap, s.blk_hdr, perm);
     } else {
-        hipLaunchKernelGGL((k_nbr_pass<P, 0>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap);
+        hipLaunchKernelGGL((k_nbr_pass<P, 0>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap, s.blk_hdr, perm);
     }
 }
 

@@ -18,6 +18,7 @@ __device__ __forceinline__ void add_wrench(DevScalars *scal, int obj, float fx, 
 template <bool AF, bool EOS>
 struct DensityPass {
     static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = false, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 1;
     static constexpr bool HAS_REDUCE = false;
@@ -63,6 +64,7 @@ struct DensityPass {
 template <bool AF>
 struct NonPressurePass {
     static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 2;  // surface tension (:210) + viscosity (:232) = two reference passes
     static constexpr bool HAS_REDUCE = false;
@@ -177,6 +179,7 @@ __device__ __forceinline__ void enforce_boundary(const Consts &c, float &x, floa
 template <bool AF>
 struct PressurePass {
     static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 1;
     static constexpr bool HAS_REDUCE = false;
@@ -249,6 +252,7 @@ struct PressurePass {
 // base_solver.py:106 compute_rigid_particle_volume (+task :117).  i rigid, j same object.
 struct RigidVolumePass {
     static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = false;
     static constexpr bool HAS_B = false, COUNT_PAIRS = false;
     static constexpr int PAIR_WEIGHT = 0;
     static constexpr bool HAS_REDUCE = false;

@@ -9,6 +9,7 @@
 template <bool AF>
 struct DfsphDensityAlphaPass {
     static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = false, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 2;  // density pass + alpha pass of the reference
     typedef int BT;
@@ -58,6 +59,7 @@ struct DfsphDensityAlphaPass {
 template <bool AF, int MODE>
 struct DfsphRhoAdvPass {
     static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
     static constexpr int PAIR_WEIGHT = 1;
     typedef float4 BT;
@@ -106,6 +108,7 @@ struct DfsphRhoAdvPass {
 template <bool AF, int MODE>
 struct DfsphCorrectPass {
     static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 1;
     typedef float2 BT;
@@ -178,6 +181,7 @@ struct DfsphCorrectPass {
 template <bool AF>
 struct PcisphRhoStarPass {
     static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
     static constexpr int PAIR_WEIGHT = 1;
     typedef float4 BT;
@@ -220,6 +224,7 @@ struct PcisphRhoStarPass {
 template <bool AF>
 struct PcisphPressureAccelPass {
     static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 1;
     typedef float BT;

@@ -35,7 +35,7 @@ def test_sort_matches_reference_order(gpu):
     np.testing.assert_array_equal(e.download(L.F_PARTICLE_ID), H.oracle_ids(ref))
     np.testing.assert_array_equal(e.download(L.F_POSITION), ref.field("particle_positions"))
     np.testing.assert_array_equal(e.download(L.F_GRID_ID), ref.field("grid_ids"))
-
+    g = e.download(L.F_GRID_ID)
     assert np.all(np.diff(g) >= 0)
 
 
