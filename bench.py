@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 
 # Algorithmic HBM bytes per particle per launch (DESIGN.md "Kernels").
 ALG_BYTES = {
-    "hash_count": 16, "scatter": 60, "density": 24, "non_pressure": 44, "pressure_integrate": 60,
+    "hash_count": 16, "scatter": 60, "density": 24, "non_pressure": 44, "pressure_integrate": 60, "wcsph_forces": 96,
     "dfsph_density_alpha": 24, "dfsph_rho_adv": 36, "dfsph_correct": 48,
     "pcisph_rho_star": 40, "pcisph_pressure_accel": 64,
 }
@@ -165,7 +165,7 @@ def main():
     eng = container.engine
     solver.prepare()
     n_fluid = container.fluid_particle_num[None]
-    names = [eng.lib.sph_kernel_name(k).decode() for k in range(18)]
+    names = [eng.lib.sph_kernel_name(k).decode() for k in range(19)]
 
     def fence():
         eng.synchronize()
@@ -183,7 +183,7 @@ def main():
     eng.profile_reset()
     eng.step_async(5)
     eng.synchronize()
-    table = {names[k]: eng.profile_read(k) for k in range(18)}
+    table = {names[k]: eng.profile_read(k) for k in range(19)}
     table = {k: v for k, v in table.items() if v[0] > 0}
     dom = max((k for k in table if k in ALG_BYTES), key=lambda k: table[k][1])
     if args.all_kernels and rank == 0:

@@ -129,7 +129,7 @@ typedef enum {
     SPH_K_DFSPH_DENSITY_ALPHA = 7, SPH_K_DFSPH_RHO_ADV = 8, SPH_K_DFSPH_CORRECT = 9,
     SPH_K_REDUCE = 10, SPH_K_PCISPH_RHO_STAR = 11, SPH_K_PCISPH_PRESSURE_ACCEL = 12,
     SPH_K_CG_PREPARE = 13, SPH_K_CG_AP = 14, SPH_K_CG_VECTOR = 15, SPH_K_MISC = 16,
-    SPH_K_HALO = 17, SPH_K_COUNT_
+    SPH_K_HALO = 17, SPH_K_WCSPH_FORCES = 18, SPH_K_COUNT_
 } SphKernelId;
 
 /* --- lifetime -------------------------------------------------------------------------- */

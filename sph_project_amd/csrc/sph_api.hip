@@ -137,7 +137,7 @@ extern "C" const char *sph_kernel_name(int k) {
     static const char *names[SPH_K_COUNT_] = {
         "hash_count", "scan", "scatter", "density", "non_pressure", "pressure_integrate", "rigid_volume",
         "dfsph_density_alpha", "dfsph_rho_adv", "dfsph_correct", "reduce", "pcisph_rho_star",
-        "pcisph_pressure_accel", "cg_prepare", "cg_ap", "cg_vector", "misc", "halo"};
+        "pcisph_pressure_accel", "cg_prepare", "cg_ap", "cg_vector", "misc", "halo", "wcsph_forces"};
     return (k >= 0 && k < SPH_K_COUNT_) ? names[k] : "?";
 }
 

@@ -133,6 +133,7 @@ struct Launch {
     void (*density)(State &, int eos);
     void (*non_pressure)(State &);
     void (*pressure_integrate)(State &);
+    void (*wcsph_forces)(State &);              // non_pressure + pressure_integrate in one neighbour walk (WCSPH)
     void (*rigid_volume)(State &);
     void (*renew_rigid)(State &);
     void (*prepare_emitter)(State &);

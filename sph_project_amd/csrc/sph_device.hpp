@@ -116,6 +116,12 @@ __device__ __forceinline__ void kernGrad(const Consts &c, float dx, float dy, fl
     }
 }
 
+// element j of a uniform base pointer through a 32-bit byte offset: lets the backend use the SGPR-base + VGPR-offset
+// form of global_load (one address VGPR instead of two per load)
+template <class T> __device__ __forceinline__ T ldg_idx(const T *base, int j) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (unsigned)((unsigned)j * (unsigned)sizeof(T)));
+}
+
 // XCD-aware, bijective workgroup remap: consecutive tiles share neighbour runs, so keep them on
 // one XCD's L2 (dispatch places workgroup b on XCD b % 8).
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
@@ -322,6 +328,8 @@ __device__ __forceinline__ void lds_load_chunk_imm(unsigned a, v2f (&xy)[8], v2f
 typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
 typedef __attribute__((address_space(3))) const int lds_ci32;
 __device__ __forceinline__ int lds_ld_i32(const int *p) { return *(lds_ci32 *)p; }
+typedef __attribute__((address_space(3))) const unsigned short lds_cu16;
+__device__ __forceinline__ int lds_ld_u16(const unsigned short *p) { return (int)*(lds_cu16 *)p; }
 __device__ __forceinline__ unsigned lds_addr(const float2 *p) { return (unsigned)(size_t)(lds_cu64 *)p; }
 __device__ __forceinline__ float2 lds_ld2a(unsigned byte_addr) {  // plain (schedulable) ds_read_b64 from an LDS byte address
     const unsigned long long v = *(lds_cu64 *)(size_t)byte_addr;
@@ -334,15 +342,47 @@ __device__ __forceinline__ float2 lds_ld2(const float2 *p) {
     const unsigned long long v = *(lds_u64)(p);
     return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
+// Optional second per-candidate payload (P::HAS_C, P::CT): staged into its own LDS array; stage() and pair() of
+// such a functor take it as one more argument.
+template <class P, class = void> struct PassC { static constexpr bool value = false; typedef int type; };
+template <class P> struct PassC<P, decltype((void)P::HAS_C)> { static constexpr bool value = P::HAS_C; typedef typename P::CT type; };
+
+template <class P>
+__device__ __forceinline__ float4 pass_stage(const P &p, const Consts &c, int j, typename P::BT &bj, typename PassC<P>::type &cj) {
+    if constexpr (PassC<P>::value) return p.stage(c, j, bj, cj);
+    else return p.stage(c, j, bj);
+}
+template <class P>
+__device__ __forceinline__ void pass_pair(const P &p, const Consts &c, typename P::Own &own, float dx, float dy, float dz,
+                                          float r2, const float4 &a, const typename P::BT &bj,
+                                          const typename PassC<P>::type &cj, int j) {
+    if constexpr (PassC<P>::value) p.pair(c, own, dx, dy, dz, r2, a, bj, cj, j);
+    else p.pair(c, own, dx, dy, dz, r2, a, bj, j);
+}
+
 // MASKMODE: 0 = compute the acceptance masks; 1 = compute and store the first 32-candidate chunk of every run
 // (first neighbour pass after a sort); 2 = reuse the stored chunk (later passes over the same sorted positions:
 // phase 1 disappears).  Stored form: bit t = candidate js + t accepted (self already removed).
 
 // Phase 1 for the <= 32 candidates at tile slots [base, base + m).  Must be called by all lanes of the wave
 // (wave-uniform trip count; lanes without candidates pass m = 0).  Returns bit t = slot base + t accepted.
-template <int ZW_OFF>
+// LEAN: one candidate per iteration, few registers -- for the passes that reuse stored masks and only get here for
+// the rare candidates beyond a run's first 32 (keeps those kernels at 80 VGPRs = 6 waves per SIMD).
+template <int ZW_OFF, bool LEAN = false>
 __device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int m, float xi, float yi, float zi,
                                                 float h2) {
+    if (LEAN) {
+        unsigned nm = 0;
+        const unsigned tile = lds_addr(&sXY[base]);
+#pragma unroll 1
+        for (int t = 0; __any(t < m); ++t) {
+            const float2 xy = lds_ld2a(tile + 8u * t), zw = lds_ld2a(tile + 8u * t + ZW_OFF);
+            const float dx = xi - xy.x, dy = yi - xy.y, dz = zi - zw.x;
+            const float r2 = dx * dx + dy * dy + dz * dz;
+            nm |= (t < m && r2 < h2) ? 1u << t : 0u;
+        }
+        return nm;
+    }
     // The acceptance bit of every slot is shifted into `mask` from the right by v_cmp (-> VCC) + v_addc_co
     // (mask = 2 mask + VCC): two VOPC/VOP2 instructions per slot, no SGPR-pair results, no shift constants.
     // After S pushes slot t sits at bit S-1-t.
@@ -373,7 +413,8 @@ __device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int
 template <bool LDS, int ZW_OFF, int MASKMODE, class P>
 __device__ __forceinline__ void process_run(const Consts &c, const P &p, typename P::Own &own, int i, float xi,
                                             float yi, float zi, int js, int je, int loff, const float2 *sXY,
-                                            const float2 *sZW, const typename P::BT *sB, int cap,
+                                            const float2 *sZW, const typename P::BT *sB,
+                                            const typename PassC<P>::type *sC, int cap,
                                             unsigned &npairs, unsigned stored, unsigned *store_to) {
     if (LDS) {
         int it = 0;
@@ -389,7 +430,7 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
                 // permutation)
                 nm = m > 0 ? stored : 0u;
             } else {
-                nm = phase1_mask<ZW_OFF>(sXY, base, m, xi, yi, zi, c.h2);
+                nm = phase1_mask<ZW_OFF, MASKMODE == 2>(sXY, base, m, xi, yi, zi, c.h2);
                 const unsigned self = (unsigned)(i - j0);
                 if (self < 32u) nm &= ~(1u << self);                 // p_i != p_j (base_container.py:559)
                 if (MASKMODE == 1 && it == 0) *store_to = nm;
@@ -404,7 +445,9 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
                 const float r2 = dx * dx + dy * dy + dz * dz;
                 typename P::BT bj = typename P::BT();
                 if (P::HAS_B) bj = sB[base + t];
-                p.pair(c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, j0 + t);
+                typename PassC<P>::type cj = typename PassC<P>::type();
+                if (PassC<P>::value) cj = sC[base + t];
+                pass_pair(p, c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, cj, j0 + t);
             }
         }
     } else {
@@ -412,7 +455,7 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
         for (int j0 = js; j0 < je; j0 += 32) {
             const int m = (je - j0) < 32 ? (je - j0) : 32;
             unsigned mask = 0;
-#pragma unroll 4
+#pragma unroll(MASKMODE == 2 ? 1 : 4)
             for (int t = 0; t < m; ++t) {
                 const int j = j0 + t;
                 const float4 a = p.loadA(j);
@@ -427,12 +470,12 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
                 const int t = __ffs(mask) - 1;
                 mask &= mask - 1;
                 const int j = j0 + t;
-                const float4 a = p.loadA(j);
+                typename P::BT bj = typename P::BT();
+                typename PassC<P>::type cj = typename PassC<P>::type();
+                const float4 a = pass_stage(p, c, j, bj, cj);
                 const float dx = xi - a.x, dy = yi - a.y, dz = zi - a.z;
                 const float r2 = dx * dx + dy * dy + dz * dz;
-                typename P::BT bj = typename P::BT();
-                if (P::HAS_B) bj = p.loadB(j);
-                p.pair(c, own, dx, dy, dz, r2, a, bj, j);
+                pass_pair(p, c, own, dx, dy, dz, r2, a, bj, cj, j);
             }
         }
     }
@@ -452,7 +495,8 @@ template <class P, int ZW_OFF>
 __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typename P::Own &own, float xi, float yi,
                                               float zi, unsigned m0, unsigned m1, unsigned m2, unsigned a0,
                                               unsigned a1, unsigned a2, const float2 *sXY,
-                                              const typename P::BT *sB, const int *s_loff3) {
+                                              const typename P::BT *sB, const typename PassC<P>::type *sC,
+                                              const int *s_loff3) {
     constexpr bool UJ = PassUsesJ<P>::value;
     int q0 = 0, q1 = 1, q2 = 2;
     // non-empty runs first (order kept)
@@ -470,11 +514,13 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
         const float2 zw = lds_ld2a(tile + ad + ZW_OFF);
         typename P::BT bj = typename P::BT();
         if (P::HAS_B) bj = sB[ad >> 3];
+        typename PassC<P>::type cj = typename PassC<P>::type();
+        if (PassC<P>::value) cj = sC[ad >> 3];
         const float dx = xi - xy.x, dy = yi - xy.y, dz = zi - zw.x;
         const float r2 = dx * dx + dy * dy + dz * dz;
         int j = 0;
         if (UJ) j = (int)(ad >> 3) - s_loff3[cq];
-        p.pair(c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, j);
+        pass_pair(p, c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, cj, j);
         if (cur == 0u) { cur = m1; ca = a1; m1 = m2; a1 = a2; m2 = 0u; if (UJ) { cq = q1; q1 = q2; } }
     }
 }
@@ -552,8 +598,19 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
     }
 }
 
+// LDS bytes of k_nbr_pass<P, MASKMODE> (tile + cell_start windows + small change)
+template <class P, int MASKMODE> constexpr int nbr_lds_bytes() {
+    return (P::CAP + (MASKMODE == 2 ? 0 : NBR_PAD)) * (16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0)) + 9 * NBR_CS_PITCH * 2 + 64;
+}
+// Second launch bound = minimum waves per SIMD = workgroups per CU.  The passes are latency-bound between their
+// staging rounds, so occupancy is worth more than registers: the passes that reuse stored masks (no phase 1, lean
+// ordered path) ask for as many workgroups as their LDS footprint allows (<= 5, i.e. <= 96 VGPRs: at 6 the spills cost more than the occupancy gains), the others for 4.
+template <class P, int MASKMODE> constexpr int nbr_waves_per_simd() {
+    const int by_lds = 163840 / nbr_lds_bytes<P, MASKMODE>();
+    return MASKMODE != 2 ? 4 : (by_lds < 4 ? 4 : (by_lds > 5 ? 5 : by_lds));
+}
 template <class P, int MASKMODE>
-__global__ void __launch_bounds__(P::BLOCK)
+__global__ void __launch_bounds__(P::BLOCK, (nbr_waves_per_simd<P, MASKMODE>()))
 k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevScalars *__restrict__ scal,
            int nblocks, unsigned *__restrict__ nbr_mask, int mask_stride,
            const int *__restrict__ blk_hdr, const unsigned char *__restrict__ lane_perm) {
@@ -563,12 +620,15 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     static_assert(P::GROUPS == 3 && BLOCK == 256 && CAP <= 4 * BLOCK, "staging is unrolled 4 slots per thread");
     typedef typename P::Own Own;
     typedef typename P::BT BT;
-    __shared__ float2 sT[2 * (CAP + NBR_PAD)];   // (x,y) slots followed by (z,w) slots: fixed byte distance
+    constexpr int PAD = MASKMODE == 2 ? 0 : NBR_PAD;   // only the unrolled phase 1 reads past a run's end
+    __shared__ float2 sT[2 * (CAP + PAD)];   // (x,y) slots followed by (z,w) slots: fixed byte distance
     float2 *const sXY = sT;
-    float2 *const sZW = sT + (CAP + NBR_PAD);
-    constexpr int ZW_OFF = (CAP + NBR_PAD) * 8;
-    __shared__ BT sB[P::HAS_B ? CAP + NBR_PAD : 1];
-    __shared__ int s_cs[9][NBR_CS_PITCH];
+    float2 *const sZW = sT + (CAP + PAD);
+    constexpr int ZW_OFF = (CAP + PAD) * 8;
+    __shared__ BT sB[P::HAS_B ? CAP + PAD : 1];
+    typedef typename PassC<P>::type CT;
+    __shared__ CT sC[PassC<P>::value ? CAP + PAD : 1];
+    __shared__ unsigned short s_cs[9][NBR_CS_PITCH];   // cell_start - run start
     __shared__ int s_loff[9];   // tile offset - run start of every run (INT_MIN: not staged)
 
     const int tid = threadIdx.x;
@@ -583,7 +643,9 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     const int *hdr = blk_hdr + (size_t)b * BLK_HDR_INTS;
     const int cfirst = hdr[0], clast = hdr[1];
     const int span = clast - cfirst;
-    const bool cs_lds = span >= 0 && span <= NBR_CS_SPAN;
+    bool cs_lds = span >= 0 && span <= NBR_CS_SPAN;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cs_lds = cs_lds && hdr[11 + k] < 65536;   // windows are cached as 16-bit offsets
     // in flight together: own particle, cell_start windows (entry e of run k <-> cell cfirst + shift_k - 1 + e)
     float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) pi = p.posv[i];
@@ -592,7 +654,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         for (int k = 0; k < 9; ++k) {
             int cell = cfirst + (k / 3 - 1) * c.ny * c.nz + (k % 3 - 1) * c.nz - 1 + tid;
             cell = cell < 0 ? 0 : (cell > c.G ? c.G : cell);
-            s_cs[k][tid] = cell_start[cell];
+            s_cs[k][tid] = (unsigned short)(cell_start[cell] - hdr[2 + k]);
         }
     }
     Own own;
@@ -613,7 +675,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         const int e1 = e0 + (z1 - z0) + 1;
         unsigned npairs = 0;
 #pragma unroll 1
-        for (int g = 0; g < GROUPS; ++g) {
+        for (int g = 0; g < (c.force_global == 11 ? 0 : GROUPS); ++g) {
             // tile plan of the group (uniform): the runs that fit are laid out back to back
             int rs_[RPG], ln_[RPG], lo_[RPG];
             int total = 0;
@@ -631,37 +693,44 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                 const int o = tid == 0 ? lo_[0] : (tid == 1 ? lo_[1] : lo_[2]);
                 if (o == INT_MIN && l > 0) atomicAdd(&scal->fallback[b & (SPH_STAT_SLOTS - 1)], 1ull);
             }
-            // stored masks of this group's runs: issued before the staging so that their latency hides behind it
+            // stored masks of this group's runs ([run][particle] layout), issued before the staging so that their latency
+            // hides behind it; slots of out-of-range runs hold garbage and are dropped below
             unsigned mk[RPG] = {0u, 0u, 0u};
             bool inr[RPG];
 #pragma unroll
             for (int q = 0; q < RPG; ++q) {
-                const int k = g * RPG + q;
                 const int xx = cx + g - 1, yy = cy + q - 1;
                 inr[q] = active && xx >= 0 && xx < c.nx && yy >= 0 && yy < c.ny;
-                if (MASKMODE == 2 && inr[q]) mk[q] = nbr_mask[(size_t)k * mask_stride + i];
+                if (MASKMODE == 2 && active && c.force_global != 12) mk[q] = nbr_mask[(size_t)(g * RPG + q) * mask_stride + i];
             }
-            {   // stage the runs that fit: <= 4 slots per thread, all loads issued before the first LDS write
-                // (one global round trip per group); consecutive t -> consecutive j: coalesced
+            {   // stage the runs that fit: <= 4 slots per thread; the loads of a batch are all issued before its first
+                // LDS write (one global round trip per batch; wide records go in two batches to stay within 128 VGPRs);
+                // consecutive t -> consecutive j: coalesced
+                constexpr int SB = (P::HAS_B && sizeof(BT) >= 16) ? 2 : 4;
                 const int n0 = lo_[0] != INT_MIN ? ln_[0] : 0;
                 const int n01 = n0 + (lo_[1] != INT_MIN ? ln_[1] : 0);
-                float4 a_[4];
-                BT b_[4];
+#pragma unroll 1
+                for (int u0 = 0; u0 < 4 && u0 * BLOCK < total && c.force_global != 10; u0 += SB) {
+                    float4 a_[SB];
+                    BT b_[SB];
+                    CT c_[SB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = tid + u * BLOCK;
-                    if (t < total) {
-                        const int j = t < n0 ? t - lo_[0] : (t < n01 ? t - lo_[1] : t - lo_[2]);
-                        a_[u] = p.stage(c, j, b_[u]);
+                    for (int u = 0; u < SB; ++u) {
+                        const int t = tid + (u0 + u) * BLOCK;
+                        if (t < total) {
+                            const int j = t < n0 ? t - lo_[0] : (t < n01 ? t - lo_[1] : t - lo_[2]);
+                            a_[u] = pass_stage(p, c, j, b_[u], c_[u]);
+                        }
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = tid + u * BLOCK;
-                    if (t < total) {
-                        sXY[t] = make_float2(a_[u].x, a_[u].y);
-                        sZW[t] = make_float2(a_[u].z, a_[u].w);
-                        if (P::HAS_B) sB[t] = b_[u];
+                    for (int u = 0; u < SB; ++u) {
+                        const int t = tid + (u0 + u) * BLOCK;
+                        if (t < total) {
+                            sXY[t] = make_float2(a_[u].x, a_[u].y);
+                            sZW[t] = make_float2(a_[u].z, a_[u].w);
+                            if (P::HAS_B) sB[t] = b_[u];
+                            if (PassC<P>::value) sC[t] = c_[u];
+                        }
                     }
                 }
             }
@@ -677,8 +746,9 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     if (cs_lds) {
                         // explicit LDS loads: a plain s_cs[k][e] gets merged with the global branch into ONE flat load
                         // through a generic pointer -- measured 200 us of a 280 us pass.
-                        js_[q] = lds_ld_i32(&s_cs[k][e0]);
-                        m_[q] = lds_ld_i32(&s_cs[k][e1]) - js_[q];
+                        const int o0 = lds_ld_u16(&s_cs[k][e0]);
+                        js_[q] = rs_[q] + o0;
+                        m_[q] = lds_ld_u16(&s_cs[k][e1]) - o0;
                     } else {
                         const int lin0 = ((cx + g - 1) * c.ny + (cy + q - 1)) * c.nz + z0;
                         js_[q] = cell_start[lin0];
@@ -689,7 +759,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             }
             // the merged loop handles runs of <= 32 candidates out of the tile; anything else (tile overflow, a
             // pile-up of > 32 particles in three cells, forced debug modes) walks its runs one by one, wave-uniformly
-            if (overflow || c.force_global != 0 || __any(longrun)) {
+            if (overflow || c.force_global == 1 || c.force_global == 4 || __any(longrun)) {
 #pragma unroll 1
                 for (int q = 0; q < RPG; ++q) {
                     const int k = g * RPG + q;
@@ -702,11 +772,11 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     unsigned stored = 0;
                     if (MASKMODE == 2) stored = q == 0 ? mk[0] : (q == 1 ? mk[1] : mk[2]);
                     // loff is workgroup-uniform, so every lane of the wave takes the same branch (process_run uses __any)
-                    if (loff != INT_MIN) process_run<true, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, loff, sXY, sZW, sB, CAP, npairs, stored, mslot);
+                    if (loff != INT_MIN) process_run<true, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, loff, sXY, sZW, sB, sC, CAP, npairs, stored, mslot);
                     else {
                         // tile overflow: candidates straight from L2; a stored chunk-0 mask is recomputed here, and when this
                         // pass is the one that stores masks the slot gets the same bits the LDS path would have produced
-                        process_run<false, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, 0, sXY, sZW, sB, CAP, npairs, stored, mslot);
+                        process_run<false, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, 0, sXY, sZW, sB, sC, CAP, npairs, stored, mslot);
                     }
                 }
             } else {
@@ -729,7 +799,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     ab[q] = (unsigned)base << 3;
                     npairs += __popc(nm);
                 }
-                merged_phase2<P, ZW_OFF>(c, p, own, pi.x, pi.y, pi.z, mk[0], mk[1], mk[2], ab[0], ab[1], ab[2], sXY, sB, &s_loff[g * RPG]);
+                if (c.force_global < 9) merged_phase2<P, ZW_OFF>(c, p, own, pi.x, pi.y, pi.z, mk[0], mk[1], mk[2], ab[0], ab[1], ab[2], sXY, sB, sC, &s_loff[g * RPG]);
             }
             __syncthreads();  // LDS is restaged by the next group
         }
@@ -747,8 +817,9 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     if constexpr (P::HAS_REDUCE) {
         // deterministic per-workgroup partial sum: particle order and a fixed tree (whatever the lane permutation),
         // finished by k_reduce_partials
-        __shared__ float s_val[BLOCK];
-        __shared__ float s_red[BLOCK / 64];
+        float *const s_val = reinterpret_cast<float *>(sT);   // the tile is dead by now (barrier at the end of the last group)
+        float *const s_red = s_val + BLOCK;
+        __syncthreads();   // workgroups that skipped the group loop have no barrier behind their last tile access either
         s_val[who] = red;
         __syncthreads();
         const float w = wave_sum(s_val[tid]);

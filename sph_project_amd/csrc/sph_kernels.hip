@@ -157,6 +157,23 @@ void l_pressure_integrate(State &s) {
                            s.velm.cur(), s.meta.cur(), s.pose);
 }
 
+// WCSPH.py:30-36, 45 as one pass (see WcsphForcePass); same buffer choreography as the two passes it replaces
+void l_wcsph_forces(State &s) {
+    if (s.c.all_fluid) {
+        WcsphForcePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0};
+        launch_pass(s, p, 2);
+    } else {
+        WcsphForcePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0};
+        launch_pass(s, p, 2);
+    }
+    s.velm.flip();
+    s.posv.flip();
+    s.masks_valid = 0;  // positions moved
+    if (s.has_emitter && s.c.n > 0)
+        hipLaunchKernelGGL(k_emitter_advance, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(),
+                           s.velm.cur(), s.meta.cur(), s.pose);
+}
+
 void l_rigid_volume(State &s) {
     RigidVolumePass p{s.posv.cur(), s.velm.cur(), s.meta.cur()};
     launch_pass(s, p);
@@ -224,6 +241,7 @@ const Launch *SPH_LAUNCH_FN() {
         L.density = l_density;
         L.non_pressure = l_non_pressure;
         L.pressure_integrate = l_pressure_integrate;
+        L.wcsph_forces = l_wcsph_forces;
         L.rigid_volume = l_rigid_volume;
         L.renew_rigid = l_renew_rigid;
         L.prepare_emitter = l_prepare_emitter;

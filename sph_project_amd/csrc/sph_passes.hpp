@@ -79,11 +79,11 @@ struct NonPressurePass {
     __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage_impl(int j, BT &bj) const {
-        const float4 p = posv[j];
-        float4 v = velm[j];
+        const float4 p = ldg_idx(posv, j);
+        float4 v = ldg_idx(velm, j);
         if (visc_vel && (AF || META_MAT(meta[j]) == 1)) { const float4 u = visc_vel[j]; v.x = u.x; v.y = u.y; v.z = u.z; }
         float aw, bw;
-        if (AF) { aw = v.w; bw = rho_raw[j]; }
+        if (AF) { aw = v.w; bw = ldg_idx(rho_raw, j); }
         else {
             const int m = meta[j];
             const bool fl = META_MAT(m) == 1;
@@ -245,6 +245,135 @@ struct PressurePass {
     __device__ void passive(const Consts &, int i, const float4 &pi) const {
         acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (integrate) posv_out[i] = pi;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// WCSPH.py:30-36, 45: NonPressurePass + PressurePass in ONE neighbour walk.  The pressure acceleration
+// (base_solver.py:136) reads positions, densities and pressures only -- not the velocities the non-pressure update
+// (:643) has just written -- so both sums can be accumulated side by side; finish() then replays the reference's
+// update sequence (v* = v + dt a_np; v = v* + dt a_p; x += dt v; boundary) with the same roundings.
+// Per candidate: A = (x, y, z, m_j | rho0 V_j), B = (v_j, rho_raw_j | -1 static / -2 dynamic rigid), C = p_j / rho_j^2.
+// Bytes / particle: R posv 16 + velm 16 + rho_raw 4 + ptm 4 (+ own prs, rho 8) -> W acc 16 + posv 16 + velm 16.
+template <bool AF>
+struct WcsphForcePass {
+    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
+    static constexpr bool HAS_B = true, HAS_C = true, COUNT_PAIRS = true;
+    static constexpr int PAIR_WEIGHT = 3;  // surface tension (:210) + viscosity (:232) + pressure (:136)
+    static constexpr bool HAS_REDUCE = false;
+    typedef float4 BT;
+    typedef float CT;
+    struct Own {
+        float vx, vy, vz, m, rho, st_m, sx, sy, sz, ax, ay, az;   // non-pressure part (NonPressurePass::Own)
+        float pt, p, rho2, px, py, pz, x, y, z, m0;                // pressure part (PressurePass::Own)
+        int dyn;
+    };
+    const float4 *posv, *velm; const int *meta; const float *rho_raw, *ptm, *prs, *rho;
+    float4 *vel_out, *acc, *posv_out; DevScalars *scal; const RigidPose *pose; float rho0;
+
+    __device__ float4 loadA(int j) const { return posv[j]; }
+    __device__ float4 stage(const Consts &, int j, BT &bj, CT &cj) const {
+        const float4 p = ldg_idx(posv, j);
+        const float4 v = ldg_idx(velm, j);
+        if (AF) {
+            bj = make_float4(v.x, v.y, v.z, ldg_idx(rho_raw, j));
+            cj = ldg_idx(ptm, j);
+            return make_float4(p.x, p.y, p.z, v.w);
+        }
+        const int m = meta[j];
+        const bool fl = META_MAT(m) == 1;
+        bj = make_float4(v.x, v.y, v.z, fl ? rho_raw[j] : (META_DYN(m) ? -2.0f : -1.0f));
+        cj = fl ? ptm[j] : 0.0f;
+        return make_float4(p.x, p.y, p.z, fl ? v.w : rho0 * p.w);
+    }
+    __device__ bool begin(const Consts &c, int i, const float4 &pi, Own &o) const {
+        o.dyn = 1;
+        if (!AF) {
+            const int m = meta[i];
+            if (!META_ACTIVE_FLUID(m)) return false;
+            o.dyn = META_DYN(m);
+        }
+        const float4 v = velm[i];
+        o.vx = v.x; o.vy = v.y; o.vz = v.z; o.m = v.w;
+        o.rho = rho_raw[i];
+        o.st_m = fdiv(c.st, v.w);
+        o.sx = o.sy = o.sz = 0.0f;
+        o.ax = o.ay = o.az = 0.0f;
+        o.x = pi.x; o.y = pi.y; o.z = pi.z; o.m0 = rho0 * pi.w;
+        o.pt = ptm[i]; o.p = prs[i];
+        const float r = rho[i];
+        o.rho2 = r * r;
+        o.px = o.py = o.pz = 0.0f;
+        return true;
+    }
+    __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
+                         const BT &bj, const CT &cj, int j) const {
+        const Geom g = geom(c, r2);
+#if SPH_FAST
+        const float rn2 = r2;               // base_solver.py:254 R.norm()**2
+#else
+        const float rn2 = g.rn * g.rn;
+#endif
+        float gx, gy, gz;
+        kernGrad(c, dx, dy, dz, g, gx, gy, gz);
+        const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
+        if (AF || bj.w >= 0.0f) {
+            const float cst = o.st_m * a.w;                             // surface tension (:210)
+            const float w = r2 > c.diameter2 ? kernW(c, g) : c.Wd;
+            o.sx -= (cst * dx) * w; o.sy -= (cst * dy) * w; o.sz -= (cst * dz) * w;
+            const float m_ij = (o.m + a.w) * 0.5f;                      // viscosity (:232)
+            const float cc = fdiv(fdiv(c.cv * m_ij, bj.w), rn2 + c.visc_eps) * v_xy;
+            o.ax += cc * gx; o.ay += cc * gy; o.az += cc * gz;
+            const float cp = -a.w * (o.pt + cj);                        // pressure (:136)
+            o.px += cp * gx; o.py += cp * gy; o.pz += cp * gz;
+        } else {
+            const float cc = fdiv(fdiv(c.cvb * a.w, o.rho), rn2 + c.visc_eps) * v_xy;
+            const float acx = cc * gx, acy = cc * gy, acz = cc * gz;
+            o.ax += acx; o.ay += acy; o.az += acz;
+            const float cp = fdiv(-a.w * o.p, o.rho2);
+            o.px += cp * gx; o.py += cp * gy; o.pz += cp * gz;
+            if (bj.w == -2.0f) {  // dynamic rigid neighbour
+                const int obj = META_OBJ(meta[j]);
+                {   // base_solver.py:272-278
+                    const float fx = fdiv(-acx * o.m, c.rho0), fy = fdiv(-acy * o.m, c.rho0), fz = fdiv(-acz * o.m, c.rho0);
+                    const float rx = a.x - pose->com[obj][0], ry = a.y - pose->com[obj][1], rz = a.z - pose->com[obj][2];
+                    add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
+                }
+                if (AF || o.dyn) {   // base_solver.py:174-187 (torque about pos_i, sic)
+                    const float cf = fdiv(a.w * o.p, o.rho2);
+                    const float fx = (cf * gx) * o.m0, fy = (cf * gy) * o.m0, fz = (cf * gz) * o.m0;
+                    const float rx = o.x - pose->com[obj][0], ry = o.y - pose->com[obj][1], rz = o.z - pose->com[obj][2];
+                    add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
+                }
+            }
+        }
+    }
+    __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
+        // non-pressure update (:643 after :203-240)
+        float ax = c.gx, ay = c.gy, az = c.gz;
+        ax += o.sx; ay += o.sy; az += o.sz;
+        ax += fdiv(o.ax, c.rho0); ay += fdiv(o.ay, c.rho0); az += fdiv(o.az, c.rho0);
+        float vx = o.vx + c.dt * ax, vy = o.vy + c.dt * ay, vz = o.vz + c.dt * az;
+        if (!AF && !o.dyn) {   // PressurePass::begin() leaves such a particle alone
+            vel_out[i] = make_float4(vx, vy, vz, o.m);
+            acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            posv_out[i] = pi;
+            return 0.0f;
+        }
+        // pressure update, advection, boundary (:136, :643, :652, :575)
+        acc[i] = make_float4(o.px, o.py, o.pz, 0.0f);
+        vx = vx + c.dt * o.px; vy = vy + c.dt * o.py; vz = vz + c.dt * o.pz;
+        float x = pi.x + c.dt * vx, y = pi.y + c.dt * vy, z = pi.z + c.dt * vz;
+        enforce_boundary(c, x, y, z, vx, vy, vz);
+        posv_out[i] = make_float4(x, y, z, pi.w);
+        vel_out[i] = make_float4(vx, vy, vz, o.m);
+        return 0.0f;
+    }
+    __device__ void passive(const Consts &, int i, const float4 &pi) const {
+        vel_out[i] = velm[i];
+        acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        posv_out[i] = pi;
     }
 };
 

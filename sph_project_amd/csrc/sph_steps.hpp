@@ -31,6 +31,10 @@ static int wcsph_step(SphHandle *h) {
     ph_rigid_volume(h);                                                       // base_solver.py:696 (see ph_rigid_volume)
     { ProfScope p(h, SPH_K_DENSITY); h->L->density(s, 1); }                   // :29 + :33 (EOS fused)
     if (s.slab_active) { int rc = slab_exchange_fields(h); if (rc) return rc; }   // ghost rho, p
+    if (!h->prm.viscosity_implicit && !getenv("SPH_NO_FUSED_FORCES")) {
+        ProfScope p(h, SPH_K_WCSPH_FORCES); h->L->wcsph_forces(s);            // :30-31 + :34-36, :45 in one neighbour walk
+        return SPH_OK;
+    }
     int rc = run_non_pressure(h); if (rc) return rc;                          // :30-31
     { ProfScope p(h, SPH_K_PRESSURE_INTEGRATE); h->L->pressure_integrate(s); } // :34-36, :45
     return SPH_OK;
