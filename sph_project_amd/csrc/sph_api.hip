@@ -122,6 +122,7 @@ static void fill_consts(SphHandle *h) {
     c.thr_kappa = (float)1e-5 * c.dt;
     c.V0 = (float)p.V0;
     c.force_global = p.force_global;
+    c.stat_bank = 0;
 }
 
 static void refresh_counts(SphHandle *h) {
@@ -215,7 +216,9 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     CHK_CREATE(dalloc(h, &s.cell_count, G + 1)); CHK_CREATE(dalloc(h, &s.cell_start, G + 1));
     CHK_CREATE(dalloc(h, &s.cellid, cap)); CHK_CREATE(dalloc(h, &s.rank, cap)); CHK_CREATE(dalloc(h, &s.tmp_idx, cap));
     s.scan_blocks = (int)((G + 2047) / 2048);
+    if (s.scan_blocks < SPH_STAT_SLOTS / 256) s.scan_blocks = SPH_STAT_SLOTS / 256;   // k_scan_final also clears the statistics slots
     CHK_CREATE(dalloc(h, &s.scan_partial, (size_t)s.scan_blocks + 1));
+    s.cell_count_clean = 1;
     CHK_CREATE(dalloc(h, &s.rho_raw, cap)); CHK_CREATE(dalloc(h, &s.prs, cap)); CHK_CREATE(dalloc(h, &s.ptm, cap));
     CHK_CREATE(dalloc(h, &s.acc, cap));
     s.nbr_mask = nullptr; s.masks_valid = 0;
@@ -446,7 +449,7 @@ static void ph_rigid_volume(SphHandle *h) {
 
 static void step_begin(SphHandle *h) {
     State &s = h->st;
-    hipMemsetAsync(s.scal, 0, offsetof(DevScalars, wrench), s.stream);  // pairs + fallback
+    s.c.stat_bank = (int)(h->steps & 1);   // cleared by the previous step's scan kernel (k_scan_lookback)
     if (h->pose_dirty) { ProfScope p(h, SPH_K_MISC); h->L->renew_rigid(s); h->pose_dirty = false; }
 }
 
@@ -457,7 +460,8 @@ static int read_scalars(SphHandle *h) {
     HIPCHK(h, hipMemcpyAsync(h->scal_h, h->st.scal, sizeof(DevScalars), hipMemcpyDeviceToHost, h->st.stream));
     HIPCHK(h, hipStreamSynchronize(h->st.stream));
     unsigned long long pairs = 0, fb = 0;
-    for (int k = 0; k < SPH_STAT_SLOTS; ++k) { pairs += h->scal_h->pairs[k]; fb += h->scal_h->fallback[k]; }
+    const int bank = h->steps > 0 ? (int)((h->steps - 1) & 1) : 0;   // bank of the last completed step
+    for (int k = 0; k < SPH_STAT_SLOTS; ++k) { pairs += h->scal_h->pairs[bank][k]; fb += h->scal_h->fallback[bank][k]; }
     h->last.pair_interactions = (int64_t)pairs;
     h->last.lds_fallback_blocks = (int64_t)fb;
     return SPH_OK;
@@ -481,6 +485,9 @@ extern "C" int sph_prepare(SphHandle *h) {
         rc = slab_neighbor_search(h); if (rc) return rc;
     }
     rc = method_prepare(h); if (rc) return rc;
+    // the passes above counted into statistics bank 0, which the first step uses as well
+    HIPCHK(h, hipMemsetAsync(s.scal, 0, sizeof(unsigned long long) * SPH_STAT_SLOTS, s.stream));
+    HIPCHK(h, hipMemsetAsync((char *)s.scal + offsetof(DevScalars, fallback), 0, sizeof(unsigned long long) * SPH_STAT_SLOTS, s.stream));
     rc = check_async(h); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(s.stream));
     h->prepared = true;

@@ -43,13 +43,15 @@ struct Consts {
     int   n;                // particle_num
     int   all_fluid;        // no rigid / emitter particles in the container
     int   force_global;
+    int   stat_bank;        // DevScalars bank the running step counts into (step parity)
 };
 
 // Device-side scalar block (zeroed / read back by the host)
 #define SPH_STAT_SLOTS 2048  // statistics are striped over many words: ~20k same-address atomics per launch cost >200 us
 struct DevScalars {
-    unsigned long long pairs[SPH_STAT_SLOTS];     // accepted pairs of the running step (sum over slots)
-    unsigned long long fallback[SPH_STAT_SLOTS];  // neighbour runs that did not fit the LDS tile
+    // two banks: step k counts into bank k & 1 while its scan kernel clears the other one for step k + 1
+    unsigned long long pairs[2][SPH_STAT_SLOTS];     // accepted pairs of a step (sum over slots)
+    unsigned long long fallback[2][SPH_STAT_SLOTS];  // neighbour runs that did not fit the LDS tile
     float wrench[2 * SPH_NOBJ * 3];  // rigid_body_forces, rigid_body_torques
     float red[8];                    // reduction results (errors, CG dots)
     int   flags[4];
@@ -85,6 +87,7 @@ struct State {
     int *tmp_idx;        // stable-sort scratch (source index per sorted slot)
     int *scan_partial;   // block sums
     int scan_blocks;
+    int cell_count_clean;              // cell_count is all zero (the scan clears it behind itself)
     // per-step scratch
     float *rho_raw, *prs, *ptm;
     float4 *acc;

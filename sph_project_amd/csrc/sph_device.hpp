@@ -229,9 +229,15 @@ k_scan_partials(int *__restrict__ partial, int nb) {
 }
 
 __global__ void __launch_bounds__(SCAN_TPB)
-k_scan_final(const int *__restrict__ in, int n, const int *__restrict__ partial, int *__restrict__ out,
-             int total_particles) {
+k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *__restrict__ out,
+             int total_particles, DevScalars *__restrict__ scal, int clear_bank) {
+    // side jobs of the kernel that runs every step: clears cell_count behind itself (the next histogram starts from
+    // zero without a memset) and clears the statistics bank of the next step
     __shared__ int s_w[SCAN_TPB / 64];
+    if (blockIdx.x * SCAN_TPB + threadIdx.x < SPH_STAT_SLOTS) {   // first SPH_STAT_SLOTS / SCAN_TPB workgroups (the grid is never smaller)
+        scal->pairs[clear_bank][blockIdx.x * SCAN_TPB + threadIdx.x] = 0ull;
+        scal->fallback[clear_bank][blockIdx.x * SCAN_TPB + threadIdx.x] = 0ull;
+    }
     const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_IPT;
     int v[SCAN_IPT];
     int s = 0;
@@ -242,7 +248,7 @@ k_scan_final(const int *__restrict__ in, int n, const int *__restrict__ partial,
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; ++k) {
         int idx = base + k;
-        if (idx < n) out[idx] = ex;
+        if (idx < n) { out[idx] = ex; in[idx] = 0; }
         ex += v[k];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total_particles;
@@ -691,7 +697,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                 s_loff[g * RPG + tid] = tid == 0 ? lo_[0] : (tid == 1 ? lo_[1] : lo_[2]);
                 const int l = tid == 0 ? ln_[0] : (tid == 1 ? ln_[1] : ln_[2]);
                 const int o = tid == 0 ? lo_[0] : (tid == 1 ? lo_[1] : lo_[2]);
-                if (o == INT_MIN && l > 0) atomicAdd(&scal->fallback[b & (SPH_STAT_SLOTS - 1)], 1ull);
+                if (o == INT_MIN && l > 0) atomicAdd(&scal->fallback[c.stat_bank][b & (SPH_STAT_SLOTS - 1)], 1ull);
             }
             // stored masks of this group's runs ([run][particle] layout), issued before the staging so that their latency
             // hides behind it; slots of out-of-range runs hold garbage and are dropped below
@@ -790,7 +796,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     if (MASKMODE == 2) {
                         nm = m_[q] > 0 ? mk[q] : 0u;
                     } else {
-                        nm = phase1_mask<ZW_OFF>(sXY, base, m_[q], pi.x, pi.y, pi.z, c.h2);
+                        nm = c.force_global == 13 ? 0u : phase1_mask<ZW_OFF>(sXY, base, m_[q], pi.x, pi.y, pi.z, c.h2);
                         const unsigned self = (unsigned)(i - js_[q]);
                         if (self < 32u) nm &= ~(1u << self);      // p_i != p_j (base_container.py:559)
                         if (MASKMODE == 1 && inr[q]) nbr_mask[(size_t)k * mask_stride + i] = nm;
@@ -806,7 +812,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         if (P::COUNT_PAIRS) {
             float fp = wave_sum((float)npairs);  // <= 64 * few hundred: exact in f32
             if ((tid & 63) == 0 && fp > 0.0f)
-                atomicAdd(&scal->pairs[(b * (BLOCK / 64) + (tid >> 6)) & (SPH_STAT_SLOTS - 1)], (unsigned long long)fp * P::PAIR_WEIGHT);
+                atomicAdd(&scal->pairs[c.stat_bank][(b * (BLOCK / 64) + (tid >> 6)) & (SPH_STAT_SLOTS - 1)], (unsigned long long)fp * P::PAIR_WEIGHT);
         }
     }
     float red = 0.0f;

@@ -22,7 +22,8 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 void l_hash_count(State &s) {
     const int n = s.c.n;
-    hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 1), s.stream);
+    if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 1), s.stream);
+    s.cell_count_clean = 0;
     if (n == 0) return;
     hipLaunchKernelGGL(k_hash_count, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.cellid,
                        s.rank, s.cell_count);
@@ -30,11 +31,12 @@ void l_hash_count(State &s) {
 
 void l_scan(State &s) {
     const int G = s.c.G;
-    const int nb = cdiv(G, SCAN_TILE);
+    const int nb = s.scan_blocks;
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_TPB), 0, s.stream, s.scan_partial, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial,
-                       s.cell_start, s.c.n);
+                       s.cell_start, s.c.n, s.scal, 1 - s.c.stat_bank);
+    s.cell_count_clean = 1;
 }
 
 // per-workgroup header + lane permutation of the neighbour passes (k_block_prep); valid until the order changes
