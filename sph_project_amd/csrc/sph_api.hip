@@ -415,7 +415,8 @@ extern "C" int sph_device_info(SphHandle *h, char *name256, int *cu_count, int64
     if (!h) return SPH_ERR_INVALID;
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
-    if (name256) { snprintf(name256, 256, "%s (%s)", prop.name, prop.gcnArchName); }
+    // some driver stacks leave prop.name empty: report the architecture string alone then
+    if (name256) { if (prop.name[0]) snprintf(name256, 256, "%s (%s)", prop.name, prop.gcnArchName); else snprintf(name256, 256, "%s, %d CUs", prop.gcnArchName, prop.multiProcessorCount); }
     if (cu_count) *cu_count = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
     return SPH_OK;

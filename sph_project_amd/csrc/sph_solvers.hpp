@@ -62,14 +62,17 @@ struct DfsphRhoAdvPass {
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
     static constexpr int PAIR_WEIGHT = 1;
-    typedef float4 BT;
+    struct BT { float x, y, z; };   // v_j: 12 bytes keep the staging of a group in one batch of loads
     struct Own { float vx, vy, vz, sum; int cnt; };
     const float4 *posv, *velm; const int *meta; const float *rho, *alpha;
     float *out_adv, *out_kappa; float *red_out;
 
     __device__ float4 loadA(int j) const { return posv[j]; }
-    __device__ BT loadB(int j) const { return velm[j]; }
-    __device__ float4 stage(const Consts &, int j, BT &bj) const { bj = velm[j]; return posv[j]; }
+    __device__ float4 stage(const Consts &, int j, BT &bj) const {
+        const float4 v = ldg_idx(velm, j);
+        bj.x = v.x; bj.y = v.y; bj.z = v.z;
+        return ldg_idx(posv, j);
+    }
     __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
         if (!AF && META_MAT(meta[i]) != 1) return false;
         const float4 v = velm[i];
@@ -184,17 +187,20 @@ struct PcisphRhoStarPass {
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
     static constexpr int PAIR_WEIGHT = 1;
-    typedef float4 BT;
+    struct BT { float x, y, z; };   // predicted position of a fluid neighbour / current position of a rigid one
     struct Own { float px, py, pz, sum; };
     const float4 *posv, *ppos; const int *meta; const float *rho;
     float *rho_star, *prs, *ptm; float *red_out;
 
     __device__ float4 loadA(int j) const { return posv[j]; }
-    __device__ BT loadB(int j) const {
-        if (!AF && META_MAT(meta[j]) != 1) return posv[j];
-        return ppos[j];
+    __device__ float4 stage(const Consts &, int j, BT &bj) const {
+        const float4 p = ldg_idx(posv, j);
+        float4 q;
+        if (!AF && META_MAT(meta[j]) != 1) q = p;
+        else q = ldg_idx(ppos, j);
+        bj.x = q.x; bj.y = q.y; bj.z = q.z;
+        return p;
     }
-    __device__ float4 stage(const Consts &, int j, BT &bj) const { bj = loadB(j); return posv[j]; }
     __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
         if (!AF && META_MAT(meta[i]) != 1) return false;
         const float4 q = ppos[i];
