@@ -222,7 +222,8 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     CHK_CREATE(dalloc(h, &s.rho_raw, cap)); CHK_CREATE(dalloc(h, &s.prs, cap)); CHK_CREATE(dalloc(h, &s.ptm, cap));
     CHK_CREATE(dalloc(h, &s.acc, cap));
     s.nbr_mask = nullptr; s.masks_valid = 0;
-    if (!getenv("SPH_NO_MASK_REUSE")) CHK_CREATE(dalloc(h, &s.nbr_mask, cap * 9));
+    s.nbr_mask_hi = nullptr;
+    if (!getenv("SPH_NO_MASK_REUSE")) { CHK_CREATE(dalloc(h, &s.nbr_mask, cap * 9)); CHK_CREATE(dalloc(h, &s.nbr_mask_hi, cap * 9)); }
     s.lane_perm = nullptr; s.perm_n = -1;
     CHK_CREATE(dalloc(h, &s.blk_hdr, (cap + 255) / 256 * 20));
     if (s.nbr_mask && !getenv("SPH_NO_LANE_PERM")) CHK_CREATE(dalloc(h, &s.lane_perm, (cap + 255) / 256 * 256));

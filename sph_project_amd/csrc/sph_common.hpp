@@ -116,6 +116,7 @@ struct State {
     int halo_cap;        // particles per message buffer
     int slab_active, z_lo, z_hi, has_down, has_up;
     unsigned *nbr_mask;  // [9][cap]: acceptance mask of the first 32 candidates of every (particle, run), see process_run
+    unsigned *nbr_mask_hi;  // [9][cap]: candidates 32..63 of the runs that have them
     int masks_valid;
     unsigned char *lane_perm;  // [ceil(cap / 256) * 256]: lane -> particle map of every 256-particle workgroup (k_lane_perm)
     int *blk_hdr;              // [ceil(cap / 256)][BLK_HDR_INTS]: cell span and candidate-run windows of every workgroup

@@ -421,7 +421,8 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
                                             float yi, float zi, int js, int je, int loff, const float2 *sXY,
                                             const float2 *sZW, const typename P::BT *sB,
                                             const typename PassC<P>::type *sC, int cap,
-                                            unsigned &npairs, unsigned stored, unsigned *store_to) {
+                                            unsigned &npairs, unsigned stored, unsigned stored_hi, unsigned *store_to,
+                                            unsigned *store_hi) {
     if (LDS) {
         int it = 0;
         for (int j0 = js; __any(j0 < je); j0 += 32, ++it) {  // wave-uniform trip count
@@ -430,16 +431,17 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
             int base = j0 + loff;
             base = base > cap ? cap : base;            // lanes already past their run stay inside the tile
             unsigned nm;
-            if (MASKMODE == 2 && it == 0) {
+            if (MASKMODE == 2 && it < 2) {
                 // a lane without candidates may sit here because of its wave neighbours: its slot was never written by
                 // the storing pass if no lane of *that* wave had candidates (wave composition differs with the lane
                 // permutation)
-                nm = m > 0 ? stored : 0u;
+                nm = m > 0 ? (it == 0 ? stored : stored_hi) : 0u;
             } else {
                 nm = phase1_mask<ZW_OFF, MASKMODE == 2>(sXY, base, m, xi, yi, zi, c.h2);
                 const unsigned self = (unsigned)(i - j0);
                 if (self < 32u) nm &= ~(1u << self);                 // p_i != p_j (base_container.py:559)
                 if (MASKMODE == 1 && it == 0) *store_to = nm;
+                if (MASKMODE == 1 && it == 1 && m > 0) *store_hi = nm;
             }
             npairs += __popc(nm);
             while (nm) {
@@ -471,6 +473,7 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
                 mask |= ok << t;
             }
             if (MASKMODE == 1 && j0 == js) *store_to = mask;
+            if (MASKMODE == 1 && j0 == js + 32) *store_hi = mask;
             npairs += __popc(mask);
             while (mask) {
                 const int t = __ffs(mask) - 1;
@@ -497,23 +500,24 @@ template <class P> struct PassUsesJ<P, decltype((void)P::USES_J)> { static const
 // reference's accumulation order -- so a wave iterates max_lanes(sum of the three runs) times instead of
 // sum_runs max_lanes(run).  Together with the lane permutation (k_lane_perm) this removes most of the divergence
 // loss: C2 lattice 45 -> 26 iterations per wave, disordered dam break 96 -> 53 (tools/analysis/imbalance.py).
-template <class P, int ZW_OFF>
+template <class P, int ZW_OFF, class M>   // M = unsigned (runs of <= 32 candidates) or unsigned long long (<= 64)
 __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typename P::Own &own, float xi, float yi,
-                                              float zi, unsigned m0, unsigned m1, unsigned m2, unsigned a0,
+                                              float zi, M m0, M m1, M m2, unsigned a0,
                                               unsigned a1, unsigned a2, const float2 *sXY,
                                               const typename P::BT *sB, const typename PassC<P>::type *sC,
                                               const int *s_loff3) {
     constexpr bool UJ = PassUsesJ<P>::value;
     int q0 = 0, q1 = 1, q2 = 2;
     // non-empty runs first (order kept)
-    if (m0 == 0u) { m0 = m1; a0 = a1; q0 = q1; m1 = m2; a1 = a2; q1 = q2; m2 = 0u; }
-    if (m0 == 0u) { m0 = m1; a0 = a1; q0 = q1; m1 = 0u; }
-    if (m1 == 0u) { m1 = m2; a1 = a2; q1 = q2; m2 = 0u; }
-    unsigned cur = m0, ca = a0;
+    if (m0 == 0) { m0 = m1; a0 = a1; q0 = q1; m1 = m2; a1 = a2; q1 = q2; m2 = 0; }
+    if (m0 == 0) { m0 = m1; a0 = a1; q0 = q1; m1 = 0; }
+    if (m1 == 0) { m1 = m2; a1 = a2; q1 = q2; m2 = 0; }
+    M cur = m0;
+    unsigned ca = a0;
     int cq = q0;
     const unsigned tile = lds_addr(sXY);
     while (cur) {
-        const int t = __ffs(cur) - 1;
+        const int t = (sizeof(M) == 8 ? __ffsll((long long)cur) : __ffs((int)cur)) - 1;
         cur &= cur - 1;
         const unsigned ad = ca + ((unsigned)t << 3);
         const float2 xy = lds_ld2a(tile + ad);
@@ -527,7 +531,7 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
         int j = 0;
         if (UJ) j = (int)(ad >> 3) - s_loff3[cq];
         pass_pair(p, c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, cj, j);
-        if (cur == 0u) { cur = m1; ca = a1; m1 = m2; a1 = a2; m2 = 0u; if (UJ) { cq = q1; q1 = q2; } }
+        if (cur == 0) { cur = m1; ca = a1; m1 = m2; a1 = a2; m2 = 0; if (UJ) { cq = q1; q1 = q2; } }
     }
 }
 
@@ -605,21 +609,25 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
 }
 
 // LDS bytes of k_nbr_pass<P, MASKMODE> (tile + cell_start windows + small change)
+// debug (build with -DSPH_TIMELINE, run with SPH_DEBUG_MODE=20): shader-clock stamps of workgroup phases, thread 0, slot k of 16 per workgroup
+#ifdef SPH_TIMELINE
+#define NBR_STAMP(k) do { if (timeline && threadIdx.x == 0) timeline[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NBR_STAMP(k) do { } while (0)
+#endif
 template <class P, int MASKMODE> constexpr int nbr_lds_bytes() {
     return (P::CAP + (MASKMODE == 2 ? 0 : NBR_PAD)) * (16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0)) + 9 * NBR_CS_PITCH * 2 + 64;
 }
-// Second launch bound = minimum waves per SIMD = workgroups per CU.  The passes are latency-bound between their
-// staging rounds, so occupancy is worth more than registers: the passes that reuse stored masks (no phase 1, lean
-// ordered path) ask for as many workgroups as their LDS footprint allows (<= 5, i.e. <= 96 VGPRs: at 6 the spills cost more than the occupancy gains), the others for 4.
-template <class P, int MASKMODE> constexpr int nbr_waves_per_simd() {
-    const int by_lds = 163840 / nbr_lds_bytes<P, MASKMODE>();
-    return MASKMODE != 2 ? 4 : (by_lds < 4 ? 4 : (by_lds > 5 ? 5 : by_lds));
-}
+// Second launch bound = minimum waves per SIMD = workgroups per CU: 4, i.e. <= 128 VGPRs.  Five (<= 96 VGPRs) fits
+// the LDS footprint of most mask-reusing passes and was 10-15 % faster while they compiled without spills; with the
+// two-word (64-candidate) masks they no longer do, and spilled code at 5 is slower than clean code at 4 (DFSPH C3: 1.53 vs 1.43 ms).
+template <class P, int MASKMODE> constexpr int nbr_waves_per_simd() { return 4; }
 template <class P, int MASKMODE>
 __global__ void __launch_bounds__(P::BLOCK, (nbr_waves_per_simd<P, MASKMODE>()))
 k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevScalars *__restrict__ scal,
-           int nblocks, unsigned *__restrict__ nbr_mask, int mask_stride,
-           const int *__restrict__ blk_hdr, const unsigned char *__restrict__ lane_perm) {
+           int nblocks, unsigned *__restrict__ nbr_mask, unsigned *__restrict__ nbr_mask_hi, int mask_stride,
+           const int *__restrict__ blk_hdr, const unsigned char *__restrict__ lane_perm,
+           unsigned long long *__restrict__ timeline) {
     constexpr int BLOCK = P::BLOCK;
     constexpr int CAP = P::CAP;          // LDS particle slots per staging group
     constexpr int GROUPS = 3, RPG = 3;   // one x-offset (3 runs) staged at a time
@@ -638,6 +646,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     __shared__ int s_loff[9];   // tile offset - run start of every run (INT_MIN: not staged)
 
     const int tid = threadIdx.x;
+    NBR_STAMP(0);
     const int b = xcd_remap(blockIdx.x, nblocks);
     const int i0 = b * BLOCK;
     // which particle of the workgroup this lane owns for the whole pass
@@ -674,6 +683,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         active = p.begin(c, i, pi, own);
     }
     if (__syncthreads_or(active ? 1 : 0)) {  // workgroup-uniform; also publishes s_cs
+        NBR_STAMP(1);
         // this lane's z window
         const int z0 = cz > 0 ? cz - 1 : 0;
         const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
@@ -699,54 +709,15 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                 const int o = tid == 0 ? lo_[0] : (tid == 1 ? lo_[1] : lo_[2]);
                 if (o == INT_MIN && l > 0) atomicAdd(&scal->fallback[c.stat_bank][b & (SPH_STAT_SLOTS - 1)], 1ull);
             }
-            // stored masks of this group's runs ([run][particle] layout), issued before the staging so that their latency
-            // hides behind it; slots of out-of-range runs hold garbage and are dropped below
-            unsigned mk[RPG] = {0u, 0u, 0u};
+            // candidate sub-ranges of this lane's particle in the three runs (from the cached cell_start windows)
             bool inr[RPG];
-#pragma unroll
-            for (int q = 0; q < RPG; ++q) {
-                const int xx = cx + g - 1, yy = cy + q - 1;
-                inr[q] = active && xx >= 0 && xx < c.nx && yy >= 0 && yy < c.ny;
-                if (MASKMODE == 2 && active && c.force_global != 12) mk[q] = nbr_mask[(size_t)(g * RPG + q) * mask_stride + i];
-            }
-            {   // stage the runs that fit: <= 4 slots per thread; the loads of a batch are all issued before its first
-                // LDS write (one global round trip per batch; wide records go in two batches to stay within 128 VGPRs);
-                // consecutive t -> consecutive j: coalesced
-                constexpr int SB = (P::HAS_B && sizeof(BT) >= 16) ? 2 : 4;
-                const int n0 = lo_[0] != INT_MIN ? ln_[0] : 0;
-                const int n01 = n0 + (lo_[1] != INT_MIN ? ln_[1] : 0);
-#pragma unroll 1
-                for (int u0 = 0; u0 < 4 && u0 * BLOCK < total && c.force_global != 10; u0 += SB) {
-                    float4 a_[SB];
-                    BT b_[SB];
-                    CT c_[SB];
-#pragma unroll
-                    for (int u = 0; u < SB; ++u) {
-                        const int t = tid + (u0 + u) * BLOCK;
-                        if (t < total) {
-                            const int j = t < n0 ? t - lo_[0] : (t < n01 ? t - lo_[1] : t - lo_[2]);
-                            a_[u] = pass_stage(p, c, j, b_[u], c_[u]);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < SB; ++u) {
-                        const int t = tid + (u0 + u) * BLOCK;
-                        if (t < total) {
-                            sXY[t] = make_float2(a_[u].x, a_[u].y);
-                            sZW[t] = make_float2(a_[u].z, a_[u].w);
-                            if (P::HAS_B) sB[t] = b_[u];
-                            if (PassC<P>::value) sC[t] = c_[u];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            // candidate sub-ranges of this lane's particle in the three runs
             int js_[RPG], m_[RPG];
-            bool longrun = false;
+            bool wide = false, longrun = false;
 #pragma unroll
             for (int q = 0; q < RPG; ++q) {
                 const int k = g * RPG + q;
+                const int xx = cx + g - 1, yy = cy + q - 1;
+                inr[q] = active && xx >= 0 && xx < c.nx && yy >= 0 && yy < c.ny;
                 js_[q] = 0; m_[q] = 0;
                 if (inr[q]) {
                     if (cs_lds) {
@@ -756,15 +727,77 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                         js_[q] = rs_[q] + o0;
                         m_[q] = lds_ld_u16(&s_cs[k][e1]) - o0;
                     } else {
-                        const int lin0 = ((cx + g - 1) * c.ny + (cy + q - 1)) * c.nz + z0;
+                        const int lin0 = (xx * c.ny + yy) * c.nz + z0;
                         js_[q] = cell_start[lin0];
                         m_[q] = cell_start[lin0 + (z1 - z0) + 1] - js_[q];
                     }
-                    longrun = longrun || m_[q] > 32;
+                    wide = wide || m_[q] > 32;
+                    longrun = longrun || m_[q] > 64;
                 }
             }
-            // the merged loop handles runs of <= 32 candidates out of the tile; anything else (tile overflow, a
-            // pile-up of > 32 particles in three cells, forced debug modes) walks its runs one by one, wave-uniformly
+            // stored masks of this group's runs ([run][particle] layout; second word only for runs beyond 32 candidates),
+            // issued before the staging so that their latency hides behind it
+            unsigned mk[RPG] = {0u, 0u, 0u}, mh[RPG] = {0u, 0u, 0u};
+            if (MASKMODE == 2 && c.force_global != 12) {
+#pragma unroll
+                for (int q = 0; q < RPG; ++q) {
+                    if (m_[q] > 0) mk[q] = nbr_mask[(size_t)(g * RPG + q) * mask_stride + i];
+                    if (m_[q] > 32) mh[q] = nbr_mask_hi[(size_t)(g * RPG + q) * mask_stride + i];
+                }
+            }
+            // stage the runs that fit: <= 4 slots per thread; the loads of a batch are all issued before its first LDS
+            // write (one global round trip per batch; wide records go in two batches to stay within the VGPR budget);
+            // consecutive t -> consecutive j: coalesced
+            constexpr int SB = (P::HAS_B && sizeof(BT) >= 16) ? 2 : 4;
+            const int n0 = lo_[0] != INT_MIN ? ln_[0] : 0;
+            const int n01 = n0 + (lo_[1] != INT_MIN ? ln_[1] : 0);
+            float4 a_[SB];
+            BT b_[SB];
+            CT c_[SB];
+            const bool do_stage = c.force_global != 10;
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int t = tid + u * BLOCK;
+                if (t < total && do_stage) {
+                    const int j = t < n0 ? t - lo_[0] : (t < n01 ? t - lo_[1] : t - lo_[2]);
+                    a_[u] = pass_stage(p, c, j, b_[u], c_[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int t = tid + u * BLOCK;
+                if (t < total && do_stage) {
+                    sXY[t] = make_float2(a_[u].x, a_[u].y);
+                    sZW[t] = make_float2(a_[u].z, a_[u].w);
+                    if (P::HAS_B) sB[t] = b_[u];
+                    if (PassC<P>::value) sC[t] = c_[u];
+                }
+            }
+            if (SB < 4 && SB * BLOCK < total && do_stage) {   // second batch of a wide record
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int t = tid + (SB + u) * BLOCK;
+                    if (t < total) {
+                        const int j = t < n0 ? t - lo_[0] : (t < n01 ? t - lo_[1] : t - lo_[2]);
+                        a_[u] = pass_stage(p, c, j, b_[u], c_[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int t = tid + (SB + u) * BLOCK;
+                    if (t < total) {
+                        sXY[t] = make_float2(a_[u].x, a_[u].y);
+                        sZW[t] = make_float2(a_[u].z, a_[u].w);
+                        if (P::HAS_B) sB[t] = b_[u];
+                        if (PassC<P>::value) sC[t] = c_[u];
+                    }
+                }
+            }
+            __syncthreads();
+            NBR_STAMP(2 + g * 4);
+            // the merged loop handles runs of <= 64 candidates out of the tile (one or two mask words per run); anything
+            // else (tile overflow, a pile-up of > 64 particles in three cells, forced debug modes) walks its runs one by
+            // one, wave-uniformly
             if (overflow || c.force_global == 1 || c.force_global == 4 || __any(longrun)) {
 #pragma unroll 1
                 for (int q = 0; q < RPG; ++q) {
@@ -775,39 +808,58 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     const int loff = q == 0 ? lo_[0] : (q == 1 ? lo_[1] : lo_[2]);
                     if (!in) continue;
                     unsigned *mslot = nbr_mask + (size_t)k * mask_stride + i;
-                    unsigned stored = 0;
-                    if (MASKMODE == 2) stored = q == 0 ? mk[0] : (q == 1 ? mk[1] : mk[2]);
+                    unsigned *mslot_hi = nbr_mask_hi + (size_t)k * mask_stride + i;
+                    unsigned stored = 0, stored_hi = 0;
+                    if (MASKMODE == 2) { stored = q == 0 ? mk[0] : (q == 1 ? mk[1] : mk[2]); stored_hi = q == 0 ? mh[0] : (q == 1 ? mh[1] : mh[2]); }
                     // loff is workgroup-uniform, so every lane of the wave takes the same branch (process_run uses __any)
-                    if (loff != INT_MIN) process_run<true, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, loff, sXY, sZW, sB, sC, CAP, npairs, stored, mslot);
+                    if (loff != INT_MIN) process_run<true, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, loff, sXY, sZW, sB, sC, CAP, npairs, stored, stored_hi, mslot, mslot_hi);
                     else {
-                        // tile overflow: candidates straight from L2; a stored chunk-0 mask is recomputed here, and when this
-                        // pass is the one that stores masks the slot gets the same bits the LDS path would have produced
-                        process_run<false, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, 0, sXY, sZW, sB, sC, CAP, npairs, stored, mslot);
+                        // tile overflow: candidates straight from L2; stored masks are recomputed there, and when this pass
+                        // is the one that stores masks the slots get the same bits the LDS path would have produced
+                        process_run<false, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, 0, sXY, sZW, sB, sC, CAP, npairs, stored, stored_hi, mslot, mslot_hi);
                     }
                 }
             } else {
                 // acceptance masks of the three runs, then one merged loop
+                const bool anywide = __any(wide);   // wave-uniform: some run in this wave has more than 32 candidates
                 unsigned ab[RPG];
 #pragma unroll
                 for (int q = 0; q < RPG; ++q) {
                     const int k = g * RPG + q;
                     const int base = inr[q] ? js_[q] + lo_[q] : 0;
-                    unsigned nm;
+                    unsigned nm, nh = 0u;
                     if (MASKMODE == 2) {
-                        nm = m_[q] > 0 ? mk[q] : 0u;
+                        nm = mk[q]; nh = mh[q];   // zero where the run is empty / has no second chunk (not loaded)
                     } else {
-                        nm = c.force_global == 13 ? 0u : phase1_mask<ZW_OFF>(sXY, base, m_[q], pi.x, pi.y, pi.z, c.h2);
+                        const int mlo = m_[q] < 32 ? m_[q] : 32;
+                        nm = c.force_global == 13 ? 0u : phase1_mask<ZW_OFF>(sXY, base, mlo, pi.x, pi.y, pi.z, c.h2);
+                        if (anywide) nh = phase1_mask<ZW_OFF>(sXY, m_[q] > 32 ? base + 32 : 0, m_[q] > 32 ? m_[q] - 32 : 0, pi.x, pi.y, pi.z, c.h2);
                         const unsigned self = (unsigned)(i - js_[q]);
                         if (self < 32u) nm &= ~(1u << self);      // p_i != p_j (base_container.py:559)
-                        if (MASKMODE == 1 && inr[q]) nbr_mask[(size_t)k * mask_stride + i] = nm;
+                        else if (self < 64u) nh &= ~(1u << (self - 32u));
+                        if (MASKMODE == 1 && inr[q]) {
+                            nbr_mask[(size_t)k * mask_stride + i] = nm;
+                            if (m_[q] > 32) nbr_mask_hi[(size_t)k * mask_stride + i] = nh;
+                        }
                     }
-                    mk[q] = nm;
+                    mk[q] = nm; mh[q] = nh;
                     ab[q] = (unsigned)base << 3;
-                    npairs += __popc(nm);
+                    npairs += __popc(nm) + __popc(nh);
                 }
-                if (c.force_global < 9) merged_phase2<P, ZW_OFF>(c, p, own, pi.x, pi.y, pi.z, mk[0], mk[1], mk[2], ab[0], ab[1], ab[2], sXY, sB, sC, &s_loff[g * RPG]);
+                NBR_STAMP(3 + g * 4);
+                if (c.force_global < 9 || c.force_global >= 20) {
+                    if (anywide) {   // 64-bit masks: same loop, same order, a few more VALU per iteration
+                        typedef unsigned long long u64;
+                        merged_phase2<P, ZW_OFF, u64>(c, p, own, pi.x, pi.y, pi.z, (u64)mk[0] | ((u64)mh[0] << 32), (u64)mk[1] | ((u64)mh[1] << 32),
+                                                      (u64)mk[2] | ((u64)mh[2] << 32), ab[0], ab[1], ab[2], sXY, sB, sC, &s_loff[g * RPG]);
+                    } else {
+                        merged_phase2<P, ZW_OFF, unsigned>(c, p, own, pi.x, pi.y, pi.z, mk[0], mk[1], mk[2], ab[0], ab[1], ab[2], sXY, sB, sC, &s_loff[g * RPG]);
+                    }
+                }
             }
+            NBR_STAMP(4 + g * 4);
             __syncthreads();  // LDS is restaged by the next group
+            NBR_STAMP(5 + g * 4);
         }
         if (P::COUNT_PAIRS) {
             float fp = wave_sum((float)npairs);  // <= 64 * few hundred: exact in f32
@@ -815,11 +867,13 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                 atomicAdd(&scal->pairs[c.stat_bank][(b * (BLOCK / 64) + (tid >> 6)) & (SPH_STAT_SLOTS - 1)], (unsigned long long)fp * P::PAIR_WEIGHT);
         }
     }
+    NBR_STAMP(14);
     float red = 0.0f;
     if (valid) {
         if (active) red = p.finish(c, i, pi, own);
         else p.passive(c, i, pi);
     }
+    NBR_STAMP(15);
     if constexpr (P::HAS_REDUCE) {
         // deterministic per-workgroup partial sum: particle order and a fixed tree (whatever the lane permutation),
         // finished by k_reduce_partials

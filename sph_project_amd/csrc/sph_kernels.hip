@@ -12,6 +12,8 @@
 #endif
 
 // every kernel lives in a per-build namespace so the strict and fast objects can be linked together
+#include <vector>
+#include <cstdio>
 namespace SPH_NS {
 #include "sph_passes.hpp"
 #include "sph_solvers.hpp"
@@ -91,13 +93,38 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     // neighbouring lanes on neighbouring cells, which is what makes its LDS reads conflict-free
     if (s.perm_n != n) l_block_prep(s);   // particles were appended since the last sort
     const unsigned char *perm = (mask_mode == 2 && s.lane_perm) ? s.lane_perm : nullptr;
+    unsigned long long *tl = (s.c.force_global == 20 && (size_t)nb * 16 * 8 <= (size_t)s.cap * 4) ? (unsigned long long *)s.tmp_idx : nullptr;
+    if (tl) hipMemsetAsync(tl, 0, (size_t)nb * 16 * 8, s.stream);
     if (mask_mode == 1) {
-        hipLaunchKernelGGL((k_nbr_pass<P, 1>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap, s.blk_hdr, perm);
+        hipLaunchKernelGGL((k_nbr_pass<P, 1>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl);
         s.masks_valid = 1;
     } else if (mask_mode == 2) {
-        hipLaunchKernelGGL((k_nbr_pass<P, 2>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap, s.blk_hdr, perm);
+        hipLaunchKernelGGL((k_nbr_pass<P, 2>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl);
     } else {
-        hipLaunchKernelGGL((k_nbr_pass<P, 0>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.cap, s.blk_hdr, perm);
+        hipLaunchKernelGGL((k_nbr_pass<P, 0>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl);
+    }
+    if (tl) {   // debug: mean shader-clock deltas between the phase stamps of k_nbr_pass (tmp_idx is free between sorts)
+        static int shown = 0;
+        hipStreamSynchronize(s.stream);
+        std::vector<unsigned long long> hbuf((size_t)nb * 16);
+        hipMemcpy(hbuf.data(), tl, hbuf.size() * 8, hipMemcpyDeviceToHost);
+        if (shown++ % 8 < 2) {
+            // stamps: 0 start, 1 after prologue barrier, per group g: 2+4g tile staged, 3+4g masks ready (merged path only),
+            // 4+4g group computed, 5+4g end-of-group barrier passed; 14 after the loop, 15 after finish()
+            double d[16] = {0}; double cnt[16] = {0};
+            unsigned long long tmin = ~0ull, tmax = 0;
+            for (int b = 0; b < nb; ++b) {
+                const unsigned long long *t = &hbuf[(size_t)b * 16];
+                int prev = 0;
+                for (int k = 1; k < 16; ++k) if (t[k]) { d[k] += (double)(t[k] - t[prev]); cnt[k] += 1; prev = k; }
+                if (t[0] && t[0] < tmin) tmin = t[0];
+                if (t[15] > tmax) tmax = t[15];
+            }
+            double life = 0; for (int b = 0; b < nb; ++b) life += (double)(hbuf[(size_t)b * 16 + 15] - hbuf[(size_t)b * 16]);
+            fprintf(stderr, "timeline mode %d BT %d: kernel %.1f kclk, workgroup lifetime %.1f kclk; mean clk per stamp:", mask_mode, (int)sizeof(typename P::BT), (tmax - tmin) * 1e-3, life / nb * 1e-3);
+            for (int k = 1; k < 16; ++k) fprintf(stderr, " [%d]%.0f", k, cnt[k] ? d[k] / cnt[k] : 0.0);
+            fprintf(stderr, "\n");
+        }
     }
 }
 
