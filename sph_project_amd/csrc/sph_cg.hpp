@@ -20,7 +20,7 @@ __device__ __forceinline__ void mat3_inverse(const float *a, float *o) {
 // Bytes / particle: R posv 16 + velm 16 + rho 4 + cg_x 16 -> W dinv 36 + b 16 + p 16 + x 16 + v0 16 (+ zero fills).
 template <bool AF>
 struct CgPreparePass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 2;  // A_ii pass + b_i pass of the reference
@@ -95,7 +95,7 @@ struct CgPreparePass {
 // Bytes / particle: R posv 16 + m 4 + rho 4 + dinv 36 + p 16 -> W Ap 16.
 template <bool AF>
 struct CgApPass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 1;

@@ -608,6 +608,15 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
     }
 }
 
+// LDS particle slots per staging group.  All instantiations run 4 workgroups per CU (see nbr_waves_per_simd), so each
+// may use a quarter of the 160 KB: the tile gets what is left after the cell windows, up to 1280 slots (5 per thread).
+// A rest-density workgroup needs ~3 x 34 cells x 8 = 816; moving fluid piles up to 900-1000, and every overflow sends
+// a whole group down the ordered path.
+template <class P> constexpr int nbr_tile_cap() {
+    const int per_slot = 16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0);
+    const int slots = (40960 - 9 * NBR_CS_PITCH * 2 - 256) / per_slot - NBR_PAD;
+    return slots > 1280 ? 1280 : slots / 8 * 8;
+}
 // LDS bytes of k_nbr_pass<P, MASKMODE> (tile + cell_start windows + small change)
 // debug (build with -DSPH_TIMELINE, run with SPH_DEBUG_MODE=20): shader-clock stamps of workgroup phases, thread 0, slot k of 16 per workgroup
 #ifdef SPH_TIMELINE
@@ -616,7 +625,7 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
 #define NBR_STAMP(k) do { } while (0)
 #endif
 template <class P, int MASKMODE> constexpr int nbr_lds_bytes() {
-    return (P::CAP + (MASKMODE == 2 ? 0 : NBR_PAD)) * (16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0)) + 9 * NBR_CS_PITCH * 2 + 64;
+    return (nbr_tile_cap<P>() + (MASKMODE == 2 ? 0 : NBR_PAD)) * (16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0)) + 9 * NBR_CS_PITCH * 2 + 64;
 }
 // Second launch bound = minimum waves per SIMD = workgroups per CU: 4, i.e. <= 128 VGPRs.  Five (<= 96 VGPRs) fits
 // the LDS footprint of most mask-reusing passes and was 10-15 % faster while they compiled without spills; with the
@@ -629,9 +638,10 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
            const int *__restrict__ blk_hdr, const unsigned char *__restrict__ lane_perm,
            unsigned long long *__restrict__ timeline) {
     constexpr int BLOCK = P::BLOCK;
-    constexpr int CAP = P::CAP;          // LDS particle slots per staging group
+    constexpr int CAP = nbr_tile_cap<P>();   // LDS particle slots per staging group
+    constexpr int NS = (CAP + BLOCK - 1) / BLOCK;   // tile slots staged per thread
     constexpr int GROUPS = 3, RPG = 3;   // one x-offset (3 runs) staged at a time
-    static_assert(P::GROUPS == 3 && BLOCK == 256 && CAP <= 4 * BLOCK, "staging is unrolled 4 slots per thread");
+    static_assert(P::GROUPS == 3 && BLOCK == 256, "lane permutation is stored as one byte per particle");
     typedef typename P::Own Own;
     typedef typename P::BT BT;
     constexpr int PAD = MASKMODE == 2 ? 0 : NBR_PAD;   // only the unrolled phase 1 reads past a run's end
@@ -748,35 +758,17 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             // stage the runs that fit: <= 4 slots per thread; the loads of a batch are all issued before its first LDS
             // write (one global round trip per batch; wide records go in two batches to stay within the VGPR budget);
             // consecutive t -> consecutive j: coalesced
-            constexpr int SB = (P::HAS_B && sizeof(BT) >= 16) ? 2 : 4;
+            constexpr int SB = (P::HAS_B && sizeof(BT) >= 16) ? 2 : NS;   // slots per batch
             const int n0 = lo_[0] != INT_MIN ? ln_[0] : 0;
             const int n01 = n0 + (lo_[1] != INT_MIN ? ln_[1] : 0);
-            float4 a_[SB];
-            BT b_[SB];
-            CT c_[SB];
-            const bool do_stage = c.force_global != 10;
-#pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                const int t = tid + u * BLOCK;
-                if (t < total && do_stage) {
-                    const int j = t < n0 ? t - lo_[0] : (t < n01 ? t - lo_[1] : t - lo_[2]);
-                    a_[u] = pass_stage(p, c, j, b_[u], c_[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                const int t = tid + u * BLOCK;
-                if (t < total && do_stage) {
-                    sXY[t] = make_float2(a_[u].x, a_[u].y);
-                    sZW[t] = make_float2(a_[u].z, a_[u].w);
-                    if (P::HAS_B) sB[t] = b_[u];
-                    if (PassC<P>::value) sC[t] = c_[u];
-                }
-            }
-            if (SB < 4 && SB * BLOCK < total && do_stage) {   // second batch of a wide record
+#pragma unroll 1
+            for (int u0 = 0; u0 < NS && u0 * BLOCK < total && c.force_global != 10; u0 += SB) {
+                float4 a_[SB];
+                BT b_[SB];
+                CT c_[SB];
 #pragma unroll
                 for (int u = 0; u < SB; ++u) {
-                    const int t = tid + (SB + u) * BLOCK;
+                    const int t = tid + (u0 + u) * BLOCK;
                     if (t < total) {
                         const int j = t < n0 ? t - lo_[0] : (t < n01 ? t - lo_[1] : t - lo_[2]);
                         a_[u] = pass_stage(p, c, j, b_[u], c_[u]);
@@ -784,7 +776,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                 }
 #pragma unroll
                 for (int u = 0; u < SB; ++u) {
-                    const int t = tid + (SB + u) * BLOCK;
+                    const int t = tid + (u0 + u) * BLOCK;
                     if (t < total) {
                         sXY[t] = make_float2(a_[u].x, a_[u].y);
                         sZW[t] = make_float2(a_[u].z, a_[u].w);

@@ -17,7 +17,7 @@ __device__ __forceinline__ void add_wrench(DevScalars *scal, int obj, float fx, 
 // Algorithmic HBM bytes / particle: R posv 16 -> W rho 4 (+ rho_raw 4, prs 4, ptm 4 with EOS).
 template <bool AF, bool EOS>
 struct DensityPass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = false, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 1;
@@ -63,7 +63,7 @@ struct DensityPass {
 // Bytes / particle: R posv 16 + velm 16 + rho_raw 4 -> W velm 16.
 template <bool AF>
 struct NonPressurePass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 2;  // surface tension (:210) + viscosity (:232) = two reference passes
@@ -178,7 +178,7 @@ __device__ __forceinline__ void enforce_boundary(const Consts &c, float &x, floa
 // Bytes / particle: R posv 16 + velm 16 + ptm 4 -> W acc 16 + posv 16 + velm 16.
 template <bool AF>
 struct PressurePass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 1;
@@ -257,7 +257,7 @@ struct PressurePass {
 // Bytes / particle: R posv 16 + velm 16 + rho_raw 4 + ptm 4 (+ own prs, rho 8) -> W acc 16 + posv 16 + velm 16.
 template <bool AF>
 struct WcsphForcePass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, HAS_C = true, COUNT_PAIRS = true;
     static constexpr int PAIR_WEIGHT = 3;  // surface tension (:210) + viscosity (:232) + pressure (:136)
@@ -380,7 +380,7 @@ struct WcsphForcePass {
 // ---------------------------------------------------------------------------------------
 // base_solver.py:106 compute_rigid_particle_volume (+task :117).  i rigid, j same object.
 struct RigidVolumePass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = false;
     static constexpr bool HAS_B = false, COUNT_PAIRS = false;
     static constexpr int PAIR_WEIGHT = 0;

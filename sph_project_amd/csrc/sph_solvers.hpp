@@ -8,7 +8,7 @@
 // Bytes / particle: R posv 16 -> W rho 4 + alpha 4.
 template <bool AF>
 struct DfsphDensityAlphaPass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = false, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 2;  // density pass + alpha pass of the reference
@@ -58,7 +58,7 @@ struct DfsphDensityAlphaPass {
 // Bytes / particle: R posv 16 + velm 16 (+rho, alpha 8) -> W 8.
 template <bool AF, int MODE>
 struct DfsphRhoAdvPass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
     static constexpr int PAIR_WEIGHT = 1;
@@ -110,7 +110,7 @@ struct DfsphRhoAdvPass {
 // Bytes / particle: R posv 16 + kappa 4 + rho 4 + velm 16 -> W velm 16.
 template <bool AF, int MODE>
 struct DfsphCorrectPass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 1;
@@ -183,7 +183,7 @@ struct DfsphCorrectPass {
 // Bytes / particle: R posv 16 + ppos 16 + prs 4 + rho 4 -> W rho_star 4 + prs 4 + ptm 4.
 template <bool AF>
 struct PcisphRhoStarPass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
     static constexpr int PAIR_WEIGHT = 1;
@@ -229,7 +229,7 @@ struct PcisphRhoStarPass {
 // Bytes / particle: R posv 16 + velm 16 + ptm 4 + acc 16 -> W pacc 16 + ppos 16 (+pvel 16).
 template <bool AF>
 struct PcisphPressureAccelPass {
-    static constexpr int BLOCK = 256, CAP = 928, GROUPS = 3;
+    static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
     static constexpr int PAIR_WEIGHT = 1;
