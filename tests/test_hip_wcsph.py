@@ -123,6 +123,36 @@ def test_lds_tile_equals_global_path(gpu):
     assert out[0][1]["lds_fallback_blocks"] < out[1][1]["lds_fallback_blocks"]
 
 
+@pytest.mark.parametrize("spacing,label", [(0.0185, "runs of ~30 candidates: some second mask words"),
+                                           (0.0165, "runs of ~43 candidates: every wave takes the 64-bit merged loop"),
+                                           (0.0140, "runs of ~70 candidates: beyond two mask words, ordered path")])
+def test_all_neighbour_paths_agree(gpu, spacing, label):
+    """The merged loop (one or two mask words per run, lane permutation), the ordered LDS path (mode 4) and the
+    direct-from-L2 path (mode 1) visit the same pairs in the same order: bitwise identical states and pair counts,
+    whatever the number of candidates per run.  Against the oracle: pair counts identical, drift within tolerance."""
+    cfg = H.dam_break_scene(end=(0.2, 0.2, 0.2), particleSpacing=spacing, dt=1e-4)
+    out = []
+    dh = None
+    for fg in (0, 4, 1):
+        container, solver = H.build_product(cfg, jitter=0.002, seed=11, force_global=fg)
+        solver.prepare()
+        for _ in range(3):
+            solver.step()
+        out.append((_state(container), solver.stats()))
+        dh = container.dh
+    for other in out[1:]:
+        for k in ("x", "v", "rho", "p", "a"):
+            np.testing.assert_array_equal(out[0][0][k], other[0][k])
+        assert out[0][1]["pair_interactions"] == other[1]["pair_interactions"]
+    ref = H.build_oracle(cfg, jitter=0.002, seed=11)
+    ref.prepare()
+    ref.step(3)
+    assert out[0][1]["pair_interactions"] == ref.last_pairs
+    d = H.drift(out[0][0]["x"], _ref_state(ref)["x"], dh)
+    print(label, "drift max %.3e" % d.max())
+    assert d.max() <= 1e-5
+
+
 def test_static_domain_box(gpu):
     """addDomainBox: static rigid boundary particles (base_container.py:192, base_solver.py:106)."""
     cfg = H.dam_break_scene(domain_end=(0.6, 0.6, 0.6), end=(0.2, 0.2, 0.2), translation=(0.06, 0.06, 0.06),
