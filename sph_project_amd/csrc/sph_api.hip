@@ -225,6 +225,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.nbr_mask_hi = nullptr;
     if (!getenv("SPH_NO_MASK_REUSE")) { CHK_CREATE(dalloc(h, &s.nbr_mask, cap * 9)); CHK_CREATE(dalloc(h, &s.nbr_mask_hi, cap * 9)); }
     s.lane_perm = nullptr; s.perm_n = -1;
+    s.loop_flag = nullptr; s.loop_slot = 0; s.loop_kind = 0; s.loop_denom = 1.0f; s.loop_thr = 0.0;
     CHK_CREATE(dalloc(h, &s.blk_hdr, (cap + 255) / 256 * 20));
     if (s.nbr_mask && !getenv("SPH_NO_LANE_PERM")) CHK_CREATE(dalloc(h, &s.lane_perm, (cap + 255) / 256 * 256));
     s.alpha = s.kappa = s.kappa_v = s.rho_star = s.rho_deriv = s.kappa_next = s.kappa_v_next = nullptr; s.kr = nullptr;

@@ -189,7 +189,9 @@ k_cg_prepare2(int n, const int *meta, int all_fluid, const float *dinv, const fl
 
 // :394 compute_cg_alpha, partial sums of |r|^2 and p.Ap
 __global__ void __launch_bounds__(256)
-k_cg_dots(int n, const int *meta, int all_fluid, const float4 *r, const float4 *p, const float4 *Ap, float *part_a, float *part_b) {
+k_cg_dots(int n, const int *meta, int all_fluid, const float4 *r, const float4 *p, const float4 *Ap, float *part_a, float *part_b,
+          const int *stop_flag) {
+    if (stop_flag && *stop_flag) return;
     int i = blockIdx.x * 256 + threadIdx.x;
     float num = 0.f, den = 0.f;
     if (i < n && is_fluid(meta, i, all_fluid)) {
@@ -200,9 +202,13 @@ k_cg_dots(int n, const int *meta, int all_fluid, const float4 *r, const float4 *
     block_sum2(num, den, part_a, part_b);
 }
 
-// finishes a two-sum reduction; mode 0: alpha = num/den (:403); mode 1: beta = num/den, err = sqrt(num) (:427-431)
+// finishes a two-sum reduction; mode 0: alpha = num/den (:403); mode 1: beta = num/den, err = sqrt(num) (:427-431).
+// Inside a device-controlled loop (looped) mode 1 also counts the iteration and raises the stop flag when the
+// reference's `while tol > 1e-6` (:445) would leave the loop; the update_p that follows in the same iteration is then
+// skipped, which only touches cg_p -- re-initialised by the next solve (:318).
 __global__ void __launch_bounds__(256)
-k_cg_scalars(const float *part_a, const float *part_b, int nb, DevScalars *scal, int mode) {
+k_cg_scalars(const float *part_a, const float *part_b, int nb, DevScalars *scal, int mode, int looped, float tol) {
+    if (looped && scal->flags[0]) return;
     __shared__ float s_a[4], s_b[4];
     float a = 0.f, b = 0.f;
     for (int k = threadIdx.x; k < nb; k += 256) { a += part_a[k]; b += part_b[k]; }
@@ -214,14 +220,19 @@ k_cg_scalars(const float *part_a, const float *part_b, int nb, DevScalars *scal,
         const float den = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
         const float q = den > 1e-18f ? num / den : 0.0f;
         if (mode == 0) scal->red[4] = q;                       // cg_alpha
-        else { scal->red[5] = q; scal->red[3] = __builtin_sqrtf(num); }  // cg_beta, cg_error
+        else {
+            const float err = __builtin_sqrtf(num);
+            scal->red[5] = q; scal->red[3] = err;  // cg_beta, cg_error
+            if (looped) { scal->flags[1] += 1; if (!(err > tol)) scal->flags[0] = 1; }
+        }
     }
 }
 
 // :409 update_cg_x + :415 update_cg_r_and_beta (partials of |new_r|^2 and |r|^2)
 __global__ void __launch_bounds__(256)
 k_cg_update_xr(int n, const int *meta, int all_fluid, const DevScalars *scal, float4 *x, float4 *r, const float4 *p,
-               const float4 *Ap, float *part_a, float *part_b) {
+               const float4 *Ap, float *part_a, float *part_b, const int *stop_flag) {
+    if (stop_flag && *stop_flag) return;
     int i = blockIdx.x * 256 + threadIdx.x;
     float num = 0.f, den = 0.f;
     if (i < n && is_fluid(meta, i, all_fluid)) {
@@ -240,7 +251,8 @@ k_cg_update_xr(int n, const int *meta, int all_fluid, const DevScalars *scal, fl
 
 // :434 update_p
 __global__ void __launch_bounds__(256)
-k_cg_update_p(int n, const int *meta, int all_fluid, const DevScalars *scal, const float4 *r, float4 *p) {
+k_cg_update_p(int n, const int *meta, int all_fluid, const DevScalars *scal, const float4 *r, float4 *p, const int *stop_flag) {
+    if (stop_flag && *stop_flag) return;
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n || !is_fluid(meta, i, all_fluid)) return;
     const float beta = scal->red[5];

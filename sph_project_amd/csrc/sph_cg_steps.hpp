@@ -11,7 +11,15 @@ static int implicit_viscosity_non_pressure(SphHandle *h) {
     float tol = 1000.0f;
     int itr = 0;
     const int max_itr = fixed > 0 ? fixed : 1000;
-    while ((fixed > 0 || tol > 1e-6f) && itr < max_itr) {                          // :445 conjugate_gradient_loop
+    if (fixed <= 0) {   // :445 conjugate_gradient_loop, stop test on the device (see device_loop)
+        int launched = 0;
+        int rc = device_loop(h, max_itr, 3, 3, 1.0f, 1e-6, [&]() {
+            { ProfScope p(h, SPH_K_CG_AP); h->L->cg_ap(s); }
+            { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_alpha(s); h->L->cg_update_xr(s); h->L->cg_update_p(s); }
+        }, &itr, &launched, &tol);
+        if (rc) return rc;
+    }
+    while (fixed > 0 && itr < max_itr) {
         { ProfScope p(h, SPH_K_CG_AP); h->L->cg_ap(s); }
         { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_alpha(s); h->L->cg_update_xr(s); h->L->cg_update_p(s); }
         itr++;

@@ -118,6 +118,12 @@ struct State {
     unsigned *nbr_mask;  // [9][cap]: acceptance mask of the first 32 candidates of every (particle, run), see process_run
     unsigned *nbr_mask_hi;  // [9][cap]: candidates 32..63 of the runs that have them
     int masks_valid;
+    // device-controlled solver loops (sph_steps.hpp device_loop): every kernel of an iteration starts with a look at
+    // scal->flags[0] (stop) when loop_flag is set; the iteration's reduction kernel evaluates the stop criterion itself
+    const int *loop_flag;    // null outside such a loop
+    int loop_slot;           // reduction slot the criterion applies to
+    int loop_kind;           // 1: (double)(sum / denom) <= thr   2: (sum / denom) < (float)thr   3: CG, !(err > thr)
+    float loop_denom; double loop_thr;
     unsigned char *lane_perm;  // [ceil(cap / 256) * 256]: lane -> particle map of every 256-particle workgroup (k_lane_perm)
     int *blk_hdr;              // [ceil(cap / 256)][BLK_HDR_INTS]: cell span and candidate-run windows of every workgroup
     int perm_n;                // particle count blk_hdr / lane_perm were built for (-1: none)

@@ -636,7 +636,8 @@ __global__ void __launch_bounds__(P::BLOCK, (nbr_waves_per_simd<P, MASKMODE>()))
 k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevScalars *__restrict__ scal,
            int nblocks, unsigned *__restrict__ nbr_mask, unsigned *__restrict__ nbr_mask_hi, int mask_stride,
            const int *__restrict__ blk_hdr, const unsigned char *__restrict__ lane_perm,
-           unsigned long long *__restrict__ timeline) {
+           unsigned long long *__restrict__ timeline, const int *__restrict__ stop_flag) {
+    if (stop_flag && *stop_flag) return;   // iteration launched past the convergence of a device-controlled loop
     constexpr int BLOCK = P::BLOCK;
     constexpr int CAP = nbr_tile_cap<P>();   // LDS particle slots per staging group
     constexpr int NS = (CAP + BLOCK - 1) / BLOCK;   // tile slots staged per thread
@@ -886,14 +887,25 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     }
 }
 
-// sums partial[0..n) in a fixed order into scal->red[slot]
+// sums partial[0..n) in a fixed order into scal->red[slot].  Inside a device-controlled loop (kind != 0) it also counts
+// the iteration and raises the stop flag when the solver's criterion is met (DFSPH.py:150/:239, PCISPH.py:122).
 __global__ void __launch_bounds__(256)
-k_reduce_partials(const float *__restrict__ partial, int n, DevScalars *__restrict__ scal, int slot) {
+k_reduce_partials(const float *__restrict__ partial, int n, DevScalars *__restrict__ scal, int slot, int kind,
+                  float denom, double thr) {
+    if (kind && scal->flags[0]) return;
     __shared__ float s_w[4];
     float t = 0.0f;
     for (int k = threadIdx.x; k < n; k += 256) t += partial[k];
     t = wave_sum(t);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
     __syncthreads();
-    if (threadIdx.x == 0) scal->red[slot] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (threadIdx.x == 0) {
+        const float sum = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        scal->red[slot] = sum;
+        if (kind) {
+            const float avg = denom > 0.0f ? sum / denom : 0.0f;
+            scal->flags[1] += 1;
+            if (kind == 1 ? ((double)avg <= thr) : (avg < (float)thr)) scal->flags[0] = 1;
+        }
+    }
 }

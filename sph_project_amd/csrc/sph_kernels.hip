@@ -96,12 +96,12 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     unsigned long long *tl = (s.c.force_global == 20 && (size_t)nb * 16 * 8 <= (size_t)s.cap * 4) ? (unsigned long long *)s.tmp_idx : nullptr;
     if (tl) hipMemsetAsync(tl, 0, (size_t)nb * 16 * 8, s.stream);
     if (mask_mode == 1) {
-        hipLaunchKernelGGL((k_nbr_pass<P, 1>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl);
+        hipLaunchKernelGGL((k_nbr_pass<P, 1>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag);
         s.masks_valid = 1;
     } else if (mask_mode == 2) {
-        hipLaunchKernelGGL((k_nbr_pass<P, 2>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl);
+        hipLaunchKernelGGL((k_nbr_pass<P, 2>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag);
     } else {
-        hipLaunchKernelGGL((k_nbr_pass<P, 0>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl);
+        hipLaunchKernelGGL((k_nbr_pass<P, 0>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag);
     }
     if (tl) {   // debug: mean shader-clock deltas between the phase stamps of k_nbr_pass (tmp_idx is free between sorts)
         static int shown = 0;

@@ -35,7 +35,9 @@ static void l_advect_boundary(State &s) {
 }
 
 static void l_reduce_sum(State &s, int slot, int nblocks) {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s.stream, s.red_partial, nblocks, s.scal, slot);
+    const int kind = (s.loop_flag && s.loop_slot == slot) ? s.loop_kind : 0;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s.stream, s.red_partial, nblocks, s.scal, slot, kind,
+                       s.loop_denom, s.loop_thr);
 }
 
 static void l_dfsph_density_alpha(State &s) {
@@ -99,7 +101,8 @@ static void l_pcisph_rho_star(State &s) {
         PcisphRhoStarPass<false> p{s.posv.cur(), s.ppos, s.meta.cur(), s.rho.cur(), s.rho_star, s.prs, s.ptm, s.red_partial};
         launch_pass(s, p, 2);
     }
-    if (s.c.n > 0) l_reduce_sum(s, 2, cdiv(s.c.n, NBR_BLOCK));
+    // the partial sums are finished by l_pcisph_pressure_accel: the criterion (PCISPH.py:122) is tested after the whole
+    // iteration, so inside a device-controlled loop the stop flag must not rise before the second pass has run
 }
 
 static void l_pcisph_pressure_accel(State &s) {
@@ -110,6 +113,7 @@ static void l_pcisph_pressure_accel(State &s) {
         PcisphPressureAccelPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.ptm, s.acc_np, s.velm.alt(), s.pacc, s.pvel, s.ppos, s.c.rho0, s.red_partial};
         launch_pass(s, p, 2);
     }
+    if (s.c.n > 0) l_reduce_sum(s, 2, cdiv(s.c.n, NBR_BLOCK));   // density error of this iteration's rho* pass
 }
 
 // ---- implicit viscosity
@@ -129,19 +133,19 @@ static void l_cg_alpha(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
     float *pa = s.red_partial, *pb = s.red_partial + s.red_blocks;
-    hipLaunchKernelGGL(k_cg_dots, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_r, s.cg_p, s.cg_Ap, pa, pb);
-    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 0);
+    hipLaunchKernelGGL(k_cg_dots, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_r, s.cg_p, s.cg_Ap, pa, pb, s.loop_flag);
+    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 0, s.loop_flag ? 1 : 0, (float)s.loop_thr);
 }
 static void l_cg_update_xr(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
     float *pa = s.red_partial, *pb = s.red_partial + s.red_blocks;
-    hipLaunchKernelGGL(k_cg_update_xr, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap, pa, pb);
-    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 1);
+    hipLaunchKernelGGL(k_cg_update_xr, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap, pa, pb, s.loop_flag);
+    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 1, s.loop_flag ? 1 : 0, (float)s.loop_thr);
 }
 static void l_cg_update_p(State &s) {
     if (s.c.n == 0) return;
-    hipLaunchKernelGGL(k_cg_update_p, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_r, s.cg_p);
+    hipLaunchKernelGGL(k_cg_update_p, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_r, s.cg_p, s.loop_flag);
 }
 static void l_cg_prepare_guess(State &s) {
     if (s.c.n == 0) return;

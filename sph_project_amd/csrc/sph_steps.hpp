@@ -13,6 +13,38 @@ static int read_red(SphHandle *h, int slot, float *out) {
 
 static int implicit_viscosity_non_pressure(SphHandle *h);
 
+// Solver loop with the stop test on the device.  `body` launches one iteration; its last reduction kernel evaluates
+// the reference's criterion (kind / denom / thr, see State::loop_kind), counts the iteration and raises
+// scal->flags[0]; every kernel of a later iteration starts with a look at that flag and returns.  Iterations go out in
+// growing batches (2, 4, 8, 8, ...) with ONE flag read-back per batch instead of one error read-back per iteration
+// (the reference, and this code before, synchronise with the host every iteration).  The state after the loop is the
+// state after exactly the iteration the reference would have stopped at.
+template <class F>
+static int device_loop(SphHandle *h, int max_itr, int slot, int kind, float denom, double thr, F body, int *executed,
+                       int *launched, float *last_val) {
+    State &s = h->st;
+    HIPCHK(h, hipMemsetAsync(&s.scal->flags[0], 0, 2 * sizeof(int), s.stream));
+    s.loop_flag = &s.scal->flags[0];
+    s.loop_slot = slot; s.loop_kind = kind; s.loop_denom = denom; s.loop_thr = thr;
+    int n_launched = 0, batch = 2, rc = SPH_OK;
+    while (n_launched < max_itr) {
+        const int nb = batch < max_itr - n_launched ? batch : max_itr - n_launched;
+        for (int k = 0; k < nb; ++k) body();
+        n_launched += nb;
+        hipError_t e = hipMemcpyAsync(h->scal_h->flags, s.scal->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h->scal_h->red[slot], &s.scal->red[slot], sizeof(float), hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+        if (e != hipSuccess) { rc = fail(h, SPH_ERR_HIP, "solver loop read-back failed: %s", hipGetErrorString(e)); break; }
+        if (h->scal_h->flags[0]) break;
+        if (batch < 8) batch *= 2;
+    }
+    s.loop_flag = nullptr;
+    *executed = h->scal_h->flags[1];
+    *launched = n_launched;
+    *last_val = h->scal_h->red[slot];
+    return rc;
+}
+
 // base_solver.py:190 compute_non_pressure_acceleration + :643 update_fluid_velocity
 static int run_non_pressure(SphHandle *h) {
     if (h->prm.viscosity_implicit) {
@@ -48,6 +80,19 @@ static int dfsph_divergence(SphHandle *h, bool allow_readback) {
     { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 0); }
     int itr = 0;
     float avg = 0.0f;
+    if (fixed <= 0 && allow_readback) {
+        const double eta = 0.001 * h->prm.density_0 / (double)s.c.dt;  // :150
+        int launched = 0; float sum = 0.0f;
+        int rc = device_loop(h, max_itr, 0, 1, (float)h->n, eta, [&]() {
+            std::swap(s.kappa_v, s.kappa_v_next);
+            { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 0); }
+            { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 0); }
+        }, &itr, &launched, &sum);
+        if (rc) return rc;
+        if ((launched - itr) & 1) std::swap(s.kappa_v, s.kappa_v_next);   // iterations past the stop did not run
+        h->last.iter_divergence = itr; h->last.err_divergence = sum / (float)h->n;
+        return SPH_OK;
+    }
     while (itr < 1 || itr < max_itr) {
         std::swap(s.kappa_v, s.kappa_v_next);  // DFSPH.py:133 compute_kappa_v: value of the last density-derivative pass
         { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 0); }
@@ -72,6 +117,18 @@ static int dfsph_density(SphHandle *h, bool allow_readback) {
     { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 1); }
     int itr = 0;
     float avg = 0.0f;
+    if (fixed <= 0 && allow_readback) {
+        int launched = 0; float sum = 0.0f;
+        int rc = device_loop(h, max_itr, 1, 1, (float)h->n, 0.0001, [&]() {   // :239
+            std::swap(s.kappa, s.kappa_next);
+            { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 1); }
+            { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 1); }
+        }, &itr, &launched, &sum);
+        if (rc) return rc;
+        if ((launched - itr) & 1) std::swap(s.kappa, s.kappa_next);
+        h->last.iter_density = itr; h->last.err_density = sum / (float)h->n;
+        return SPH_OK;
+    }
     while (itr < 1 || itr < max_itr) {
         std::swap(s.kappa, s.kappa_next);      // DFSPH.py:218 compute_kappa
         { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 1); }
@@ -105,6 +162,16 @@ static int pcisph_refine(SphHandle *h, bool allow_readback) {
     const int max_itr = fixed > 0 ? fixed : 1000;
     int itr = 0;
     float err = 100.0f;
+    if (fixed <= 0 && allow_readback) {
+        int launched = 0; float sum = 0.0f;
+        int rc = device_loop(h, max_itr, 2, 2, (float)h->n_fluid, 0.001, [&]() {   // PCISPH.py:43-46, :122
+            { ProfScope p(h, SPH_K_PCISPH_RHO_STAR); h->L->pcisph_rho_star(s); }
+            { ProfScope p(h, SPH_K_PCISPH_PRESSURE_ACCEL); h->L->pcisph_pressure_accel(s); }
+        }, &itr, &launched, &sum);
+        if (rc) return rc;
+        h->last.iter_pcisph = itr; h->last.err_pcisph = h->n_fluid > 0 ? sum / (float)h->n_fluid : 0.0f;
+        return SPH_OK;
+    }
     while (itr < max_itr) {
         { ProfScope p(h, SPH_K_PCISPH_RHO_STAR); h->L->pcisph_rho_star(s); }
         { ProfScope p(h, SPH_K_PCISPH_PRESSURE_ACCEL); h->L->pcisph_pressure_accel(s); }
