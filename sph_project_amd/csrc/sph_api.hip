@@ -227,6 +227,10 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.lane_perm = nullptr; s.perm_n = -1;
     s.loop_flag = nullptr; s.loop_slot = 0; s.loop_kind = 0; s.loop_denom = 1.0f; s.loop_thr = 0.0;
     CHK_CREATE(dalloc(h, &s.blk_hdr, (cap + 255) / 256 * 20));
+    s.blk_flag = s.blk_list = s.blk_count = nullptr; s.list_n = -1; s.last_pass_listed = 0;
+    if (!getenv("SPH_NO_BLOCK_LIST")) {
+        CHK_CREATE(dalloc(h, &s.blk_flag, (cap + 255) / 256)); CHK_CREATE(dalloc(h, &s.blk_list, (cap + 255) / 256)); CHK_CREATE(dalloc(h, &s.blk_count, 1));
+    }
     if (s.nbr_mask && !getenv("SPH_NO_LANE_PERM")) CHK_CREATE(dalloc(h, &s.lane_perm, (cap + 255) / 256 * 256));
     s.alpha = s.kappa = s.kappa_v = s.rho_star = s.rho_deriv = s.kappa_next = s.kappa_v_next = nullptr; s.kr = nullptr;
     s.pacc = s.pvel = s.ppos = s.acc_np = nullptr; s.np_acc_out = nullptr; s.np_visc_vel = nullptr;
@@ -318,7 +322,7 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
     h->n_nonfluid += n - nfl;
     h->rigid_volume_done = false;
     s.masks_valid = 0;
-    s.perm_n = -1;
+    s.perm_n = -1; s.list_n = -1;
     refresh_counts(h);
     return SPH_OK;
 }

@@ -95,6 +95,7 @@ struct CgPreparePass {
 // Bytes / particle: R posv 16 + m 4 + rho 4 + dinv 36 + p 16 -> W Ap 16.
 template <bool AF>
 struct CgApPass {
+    static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
@@ -162,18 +163,23 @@ struct CgApPass {
 };
 
 // ---- per-particle vector kernels with fixed-order block reductions -------------------------------
-__device__ __forceinline__ void block_sum2(float a, float b, float *out_a, float *out_b) {
+__device__ __forceinline__ void block_sum2(float a, float b, float *out_a, float *out_b, int blk) {
     __shared__ float s_a[4], s_b[4];
     a = wave_sum(a); b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out_a[blockIdx.x] = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
-        out_b[blockIdx.x] = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+        out_a[blk] = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+        out_b[blk] = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
     }
 }
 
 __device__ __forceinline__ bool is_fluid(const int *meta, int i, int all_fluid) { return all_fluid || META_MAT(meta[i]) == 1; }
+// workgroup index of a vector kernel: the k-th listed workgroup when only those that hold fluid are launched (-1: none)
+__device__ __forceinline__ int cg_block(const int *blk_list, const int *blk_count) {
+    if (!blk_list) return blockIdx.x;
+    return (int)blockIdx.x < *blk_count ? blk_list[blockIdx.x] : -1;
+}
 
 // :318 prepare_conjugate_gradient_solver2
 __global__ void __launch_bounds__(256)
@@ -190,16 +196,18 @@ k_cg_prepare2(int n, const int *meta, int all_fluid, const float *dinv, const fl
 // :394 compute_cg_alpha, partial sums of |r|^2 and p.Ap
 __global__ void __launch_bounds__(256)
 k_cg_dots(int n, const int *meta, int all_fluid, const float4 *r, const float4 *p, const float4 *Ap, float *part_a, float *part_b,
-          const int *stop_flag) {
+          const int *stop_flag, const int *blk_list, const int *blk_count) {
     if (stop_flag && *stop_flag) return;
-    int i = blockIdx.x * 256 + threadIdx.x;
+    const int blk = cg_block(blk_list, blk_count);
+    if (blk < 0) return;
+    int i = blk * 256 + threadIdx.x;
     float num = 0.f, den = 0.f;
     if (i < n && is_fluid(meta, i, all_fluid)) {
         const float4 rr = r[i], pp = p[i], a = Ap[i];
         num = rr.x * rr.x + rr.y * rr.y + rr.z * rr.z;
         den = pp.x * a.x + pp.y * a.y + pp.z * a.z;
     }
-    block_sum2(num, den, part_a, part_b);
+    block_sum2(num, den, part_a, part_b, blk);
 }
 
 // finishes a two-sum reduction; mode 0: alpha = num/den (:403); mode 1: beta = num/den, err = sqrt(num) (:427-431).
@@ -207,11 +215,13 @@ k_cg_dots(int n, const int *meta, int all_fluid, const float4 *r, const float4 *
 // reference's `while tol > 1e-6` (:445) would leave the loop; the update_p that follows in the same iteration is then
 // skipped, which only touches cg_p -- re-initialised by the next solve (:318).
 __global__ void __launch_bounds__(256)
-k_cg_scalars(const float *part_a, const float *part_b, int nb, DevScalars *scal, int mode, int looped, float tol) {
+k_cg_scalars(const float *part_a, const float *part_b, int nb, DevScalars *scal, int mode, int looped, float tol,
+             const int *blk_list, const int *blk_count) {
     if (looped && scal->flags[0]) return;
     __shared__ float s_a[4], s_b[4];
     float a = 0.f, b = 0.f;
-    for (int k = threadIdx.x; k < nb; k += 256) { a += part_a[k]; b += part_b[k]; }
+    if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) { a += part_a[blk_list[k]]; b += part_b[blk_list[k]]; } }
+    else for (int k = threadIdx.x; k < nb; k += 256) { a += part_a[k]; b += part_b[k]; }
     a = wave_sum(a); b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
     __syncthreads();
@@ -231,9 +241,11 @@ k_cg_scalars(const float *part_a, const float *part_b, int nb, DevScalars *scal,
 // :409 update_cg_x + :415 update_cg_r_and_beta (partials of |new_r|^2 and |r|^2)
 __global__ void __launch_bounds__(256)
 k_cg_update_xr(int n, const int *meta, int all_fluid, const DevScalars *scal, float4 *x, float4 *r, const float4 *p,
-               const float4 *Ap, float *part_a, float *part_b, const int *stop_flag) {
+               const float4 *Ap, float *part_a, float *part_b, const int *stop_flag, const int *blk_list, const int *blk_count) {
     if (stop_flag && *stop_flag) return;
-    int i = blockIdx.x * 256 + threadIdx.x;
+    const int blk = cg_block(blk_list, blk_count);
+    if (blk < 0) return;
+    int i = blk * 256 + threadIdx.x;
     float num = 0.f, den = 0.f;
     if (i < n && is_fluid(meta, i, all_fluid)) {
         const float alpha = scal->red[4];
@@ -246,14 +258,17 @@ k_cg_update_xr(int n, const int *meta, int all_fluid, const DevScalars *scal, fl
         den = rr.x * rr.x + rr.y * rr.y + rr.z * rr.z;
         r[i] = nr;
     }
-    block_sum2(num, den, part_a, part_b);
+    block_sum2(num, den, part_a, part_b, blk);
 }
 
 // :434 update_p
 __global__ void __launch_bounds__(256)
-k_cg_update_p(int n, const int *meta, int all_fluid, const DevScalars *scal, const float4 *r, float4 *p, const int *stop_flag) {
+k_cg_update_p(int n, const int *meta, int all_fluid, const DevScalars *scal, const float4 *r, float4 *p, const int *stop_flag,
+              const int *blk_list, const int *blk_count) {
     if (stop_flag && *stop_flag) return;
-    int i = blockIdx.x * 256 + threadIdx.x;
+    const int blk = cg_block(blk_list, blk_count);
+    if (blk < 0) return;
+    int i = blk * 256 + threadIdx.x;
     if (i >= n || !is_fluid(meta, i, all_fluid)) return;
     const float beta = scal->red[5];
     const float4 rr = r[i];

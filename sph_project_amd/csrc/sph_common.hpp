@@ -125,6 +125,9 @@ struct State {
     int loop_kind;           // 1: (double)(sum / denom) <= thr   2: (sum / denom) < (float)thr   3: CG, !(err > thr)
     float loop_denom; double loop_thr;
     unsigned char *lane_perm;  // [ceil(cap / 256) * 256]: lane -> particle map of every 256-particle workgroup (k_lane_perm)
+    int *blk_flag, *blk_list, *blk_count;   // per-workgroup 'holds fluid' flag, ascending list of those workgroups, its length (device)
+    int list_n;                // particle count the list was built for (-1: none)
+    int last_pass_listed;      // the last pass with a reduction ran the listed workgroups only: so must the sum of its partials
     int *blk_hdr;              // [ceil(cap / 256)][BLK_HDR_INTS]: cell span and candidate-run windows of every workgroup
     int perm_n;                // particle count blk_hdr / lane_perm were built for (-1: none)
     int has_emitter;     // gravitationUpper set (base_solver.py:18-23)

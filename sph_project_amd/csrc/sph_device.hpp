@@ -348,6 +348,11 @@ __device__ __forceinline__ float2 lds_ld2(const float2 *p) {
     const unsigned long long v = *(lds_u64)(p);
     return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
+// P::FLUID_BLOCKS_ONLY: the functor is active for fluid particles only and its passive() is empty, so workgroups without
+// a single fluid particle (the bulk of a scene with a sampled domain box) need not be launched at all.
+template <class P, class = void> struct PassFluidOnly { static constexpr bool value = false; };
+template <class P> struct PassFluidOnly<P, decltype((void)P::FLUID_BLOCKS_ONLY)> { static constexpr bool value = P::FLUID_BLOCKS_ONLY; };
+
 // Optional second per-candidate payload (P::HAS_C, P::CT): staged into its own LDS array; stage() and pair() of
 // such a functor take it as one more argument.
 template <class P, class = void> struct PassC { static constexpr bool value = false; typedef int type; };
@@ -548,8 +553,9 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
 // of a wave agree on their trip counts per group.  Any permutation is correct (every lane still walks its own
 // particle's neighbours in reference order); this one is only faster.  perm[b * 256 + lane] = particle of the lane.
 __global__ void __launch_bounds__(256)
-k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restrict__ cell_start,
-             int *__restrict__ blk_hdr, unsigned char *__restrict__ perm) {
+k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restrict__ meta,
+             const int *__restrict__ cell_start, int *__restrict__ blk_hdr, unsigned char *__restrict__ perm,
+             int *__restrict__ blk_flag) {
     __shared__ int s_cnt[4][64];
     __shared__ int s_c[2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -571,6 +577,10 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
         }
     }
     (&s_cnt[0][0])[tid] = 0;
+    if (blk_flag) {   // does this workgroup hold any fluid particle? (k_compact_blocks lists those that do)
+        const int anyf = __syncthreads_or((i < c.n && META_ACTIVE_FLUID(meta[i])) ? 1 : 0);
+        if (tid == 0) blk_flag[blockIdx.x] = anyf ? 1 : 0;
+    }
     unsigned long long peers = ~0ull;   // lanes of this wave holding the same key
 #pragma unroll
     for (int bit = 0; bit < 6; ++bit) {
@@ -608,6 +618,22 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
     }
 }
 
+// ascending list of the workgroups whose flag is set (one workgroup, fixed order: the list is deterministic)
+__global__ void __launch_bounds__(256)
+k_compact_blocks(const int *__restrict__ flag, int nb, int *__restrict__ list, int *__restrict__ count) {
+    __shared__ int s_w[4];
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const int f = b < nb ? flag[b] : 0;
+        int tot;
+        const int ex = block_excl_scan_256(f, s_w, tot);
+        if (f) list[carry + ex] = b;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *count = carry;
+}
+
 // LDS particle slots per staging group.  All instantiations run 4 workgroups per CU (see nbr_waves_per_simd), so each
 // may use a quarter of the 160 KB: the tile gets what is left after the cell windows, up to 1280 slots (5 per thread).
 // A rest-density workgroup needs ~3 x 34 cells x 8 = 816; moving fluid piles up to 900-1000, and every overflow sends
@@ -636,8 +662,10 @@ __global__ void __launch_bounds__(P::BLOCK, (nbr_waves_per_simd<P, MASKMODE>()))
 k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevScalars *__restrict__ scal,
            int nblocks, unsigned *__restrict__ nbr_mask, unsigned *__restrict__ nbr_mask_hi, int mask_stride,
            const int *__restrict__ blk_hdr, const unsigned char *__restrict__ lane_perm,
-           unsigned long long *__restrict__ timeline, const int *__restrict__ stop_flag) {
+           unsigned long long *__restrict__ timeline, const int *__restrict__ stop_flag,
+           const int *__restrict__ blk_list, const int *__restrict__ blk_count) {
     if (stop_flag && *stop_flag) return;   // iteration launched past the convergence of a device-controlled loop
+    if (blk_list && (int)blockIdx.x >= *blk_count) return;   // only the workgroups that hold fluid were listed
     constexpr int BLOCK = P::BLOCK;
     constexpr int CAP = nbr_tile_cap<P>();   // LDS particle slots per staging group
     constexpr int NS = (CAP + BLOCK - 1) / BLOCK;   // tile slots staged per thread
@@ -658,7 +686,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
 
     const int tid = threadIdx.x;
     NBR_STAMP(0);
-    const int b = xcd_remap(blockIdx.x, nblocks);
+    const int b = blk_list ? blk_list[blockIdx.x] : xcd_remap(blockIdx.x, nblocks);
     const int i0 = b * BLOCK;
     // which particle of the workgroup this lane owns for the whole pass
     const int who = lane_perm ? (int)lane_perm[i0 + tid] : tid;
@@ -891,11 +919,12 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
 // the iteration and raises the stop flag when the solver's criterion is met (DFSPH.py:150/:239, PCISPH.py:122).
 __global__ void __launch_bounds__(256)
 k_reduce_partials(const float *__restrict__ partial, int n, DevScalars *__restrict__ scal, int slot, int kind,
-                  float denom, double thr) {
+                  float denom, double thr, const int *__restrict__ blk_list, const int *__restrict__ blk_count) {
     if (kind && scal->flags[0]) return;
     __shared__ float s_w[4];
     float t = 0.0f;
-    for (int k = threadIdx.x; k < n; k += 256) t += partial[k];
+    if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) t += partial[blk_list[k]]; }   // the pass ran these only
+    else for (int k = threadIdx.x; k < n; k += 256) t += partial[k];
     t = wave_sum(t);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
     __syncthreads();

@@ -45,8 +45,11 @@ void l_scan(State &s) {
 void l_block_prep(State &s) {
     const int n = s.c.n;
     if (n == 0) return;
-    hipLaunchKernelGGL(k_block_prep, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.cell_start,
-                       s.blk_hdr, s.lane_perm);
+    const bool lst = !s.c.all_fluid && s.blk_list;
+    hipLaunchKernelGGL(k_block_prep, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.meta.cur(), s.cell_start,
+                       s.blk_hdr, s.lane_perm, lst ? s.blk_flag : nullptr);
+    if (lst) hipLaunchKernelGGL(k_compact_blocks, dim3(1), dim3(256), 0, s.stream, s.blk_flag, cdiv(n, 256), s.blk_list, s.blk_count);
+    s.list_n = lst ? n : -1;
     s.perm_n = n;
 }
 
@@ -93,15 +96,19 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     // neighbouring lanes on neighbouring cells, which is what makes its LDS reads conflict-free
     if (s.perm_n != n) l_block_prep(s);   // particles were appended since the last sort
     const unsigned char *perm = (mask_mode == 2 && s.lane_perm) ? s.lane_perm : nullptr;
+    // workgroups without fluid are not launched for functors that have nothing to do there
+    const bool use_list = PassFluidOnly<P>::value && !s.c.all_fluid && s.list_n == n && s.c.force_global == 0;
+    const int *bl = use_list ? s.blk_list : nullptr, *bc = use_list ? s.blk_count : nullptr;
+    if (P::HAS_REDUCE) s.last_pass_listed = use_list ? 1 : 0;   // whose partial sums l_reduce_sum will finish
     unsigned long long *tl = (s.c.force_global == 20 && (size_t)nb * 16 * 8 <= (size_t)s.cap * 4) ? (unsigned long long *)s.tmp_idx : nullptr;
     if (tl) hipMemsetAsync(tl, 0, (size_t)nb * 16 * 8, s.stream);
     if (mask_mode == 1) {
-        hipLaunchKernelGGL((k_nbr_pass<P, 1>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag);
+        hipLaunchKernelGGL((k_nbr_pass<P, 1>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc);
         s.masks_valid = 1;
     } else if (mask_mode == 2) {
-        hipLaunchKernelGGL((k_nbr_pass<P, 2>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag);
+        hipLaunchKernelGGL((k_nbr_pass<P, 2>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc);
     } else {
-        hipLaunchKernelGGL((k_nbr_pass<P, 0>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag);
+        hipLaunchKernelGGL((k_nbr_pass<P, 0>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc);
     }
     if (tl) {   // debug: mean shader-clock deltas between the phase stamps of k_nbr_pass (tmp_idx is free between sorts)
         static int shown = 0;

@@ -17,6 +17,7 @@ __device__ __forceinline__ void add_wrench(DevScalars *scal, int obj, float fx, 
 // Algorithmic HBM bytes / particle: R posv 16 -> W rho 4 (+ rho_raw 4, prs 4, ptm 4 with EOS).
 template <bool AF, bool EOS>
 struct DensityPass {
+    static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = false, COUNT_PAIRS = true;

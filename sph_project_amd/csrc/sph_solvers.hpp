@@ -8,6 +8,7 @@
 // Bytes / particle: R posv 16 -> W rho 4 + alpha 4.
 template <bool AF>
 struct DfsphDensityAlphaPass {
+    static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = false, COUNT_PAIRS = true, HAS_REDUCE = false;
@@ -58,6 +59,7 @@ struct DfsphDensityAlphaPass {
 // Bytes / particle: R posv 16 + velm 16 (+rho, alpha 8) -> W 8.
 template <bool AF, int MODE>
 struct DfsphRhoAdvPass {
+    static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
@@ -110,6 +112,7 @@ struct DfsphRhoAdvPass {
 // Bytes / particle: R posv 16 + kappa 4 + rho 4 + velm 16 -> W velm 16.
 template <bool AF, int MODE>
 struct DfsphCorrectPass {
+    static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
@@ -183,6 +186,7 @@ struct DfsphCorrectPass {
 // Bytes / particle: R posv 16 + ppos 16 + prs 4 + rho 4 -> W rho_star 4 + prs 4 + ptm 4.
 template <bool AF>
 struct PcisphRhoStarPass {
+    static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;

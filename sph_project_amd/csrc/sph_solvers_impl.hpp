@@ -37,7 +37,7 @@ static void l_advect_boundary(State &s) {
 static void l_reduce_sum(State &s, int slot, int nblocks) {
     const int kind = (s.loop_flag && s.loop_slot == slot) ? s.loop_kind : 0;
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s.stream, s.red_partial, nblocks, s.scal, slot, kind,
-                       s.loop_denom, s.loop_thr);
+                       s.loop_denom, s.loop_thr, s.last_pass_listed ? s.blk_list : nullptr, s.last_pass_listed ? s.blk_count : nullptr);
 }
 
 static void l_dfsph_density_alpha(State &s) {
@@ -129,23 +129,25 @@ static void l_cg_prepare2(State &s) {
     if (s.c.n == 0) return;
     hipLaunchKernelGGL(k_cg_prepare2, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_dinv, s.cg_b, s.cg_Ap, s.cg_r, s.cg_p);
 }
+// the per-particle CG kernels run the workgroups that hold fluid only (same list as the neighbour passes)
+#define CG_LIST (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_list : nullptr, (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_count : nullptr
 static void l_cg_alpha(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
     float *pa = s.red_partial, *pb = s.red_partial + s.red_blocks;
-    hipLaunchKernelGGL(k_cg_dots, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_r, s.cg_p, s.cg_Ap, pa, pb, s.loop_flag);
-    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 0, s.loop_flag ? 1 : 0, (float)s.loop_thr);
+    hipLaunchKernelGGL(k_cg_dots, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_r, s.cg_p, s.cg_Ap, pa, pb, s.loop_flag, CG_LIST);
+    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 0, s.loop_flag ? 1 : 0, (float)s.loop_thr, CG_LIST);
 }
 static void l_cg_update_xr(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
     float *pa = s.red_partial, *pb = s.red_partial + s.red_blocks;
-    hipLaunchKernelGGL(k_cg_update_xr, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap, pa, pb, s.loop_flag);
-    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 1, s.loop_flag ? 1 : 0, (float)s.loop_thr);
+    hipLaunchKernelGGL(k_cg_update_xr, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap, pa, pb, s.loop_flag, CG_LIST);
+    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 1, s.loop_flag ? 1 : 0, (float)s.loop_thr, CG_LIST);
 }
 static void l_cg_update_p(State &s) {
     if (s.c.n == 0) return;
-    hipLaunchKernelGGL(k_cg_update_p, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_r, s.cg_p, s.loop_flag);
+    hipLaunchKernelGGL(k_cg_update_p, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_r, s.cg_p, s.loop_flag, CG_LIST);
 }
 static void l_cg_prepare_guess(State &s) {
     if (s.c.n == 0) return;

@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-events", action="store_true", help="no per-kernel HIP events (they serialise the stream a little)")
     args = ap.parse_args()
     from tests import helpers as H
     cfg = c5_scene()
@@ -39,7 +40,7 @@ def main():
     names = [eng.lib.sph_kernel_name(k).decode() for k in range(19)]
     for _ in range(args.warmup):
         solver.step()
-    eng.profile_enable(-1, True)
+    eng.profile_enable(-1, not args.no_events)
     eng.profile_reset()
     eng.synchronize()
     iters = []
