@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--force-global", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--measured-iterations", action="store_true",
+                    help="c3: the solver's own convergence tests (DFSPH.py:150/:239) instead of 2+2 fixed iterations; "
+                         "iteration counts of the last step are reported in config")
     ap.add_argument("--presteps", type=int, default=0,
                     help="untimed steps before the warm-up (tuning aid: time the passes on a dam break in motion instead of "
                          "the rest lattice; the headline number is always quoted with 0)")
@@ -145,7 +148,7 @@ def main():
         del batches, z
     opts = dict(fast_math=0 if args.strict_math else 1, deterministic=0 if args.no_deterministic else 1,
                 force_global=int(os.environ.get('SPH_DEBUG_MODE', int(args.force_global))), device=local_rank if world > 1 else -1)
-    if method != "wcsph":
+    if method != "wcsph" and not args.measured_iterations:
         opts["fixed_iterations"] = 2
     container = solver = None
     if slab_opt:
@@ -178,15 +181,16 @@ def main():
             if not use_gloo:
                 torch.cuda.synchronize()
 
+    run = eng.step if args.measured_iterations else eng.step_async   # convergence tests need the (batched) flag read-back
     if args.presteps:
-        eng.step_async(args.presteps)
-    eng.step_async(args.warmup)
+        run(args.presteps)
+    run(args.warmup)
     fence()
 
     # pre-pass: which kernel dominates?  (all-kernel events perturb the stream slightly -> untimed)
     eng.profile_enable(-1, True)
     eng.profile_reset()
-    eng.step_async(5)
+    run(5)
     eng.synchronize()
     table = {names[k]: eng.profile_read(k) for k in range(19)}
     table = {k: v for k, v in table.items() if v[0] > 0}
@@ -200,7 +204,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    eng.step_async(args.steps)
+    run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -235,7 +239,7 @@ def main():
         "higher_is_better": True, "scaling": args.scaling if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": {"c1": "C1 8,000-particle cube dam break", "c2": "C2 1,231,200-particle dam break" + (f" x{scale_z} in z" if scale_z > 1 else ""),
-                         "c3": "C3 1,231,200-particle dam break, 2+2 fixed DFSPH iterations"}[args.config],
+                         "c3": "C3 1,231,200-particle dam break, " + ("DFSPH iterations as measured" if args.measured_iterations else "2+2 fixed DFSPH iterations")}[args.config],
             "method": method, "particles": int(n_total), "grid_cells": int(container.grid_num.prod()),
             "dt": cfg["Configuration"]["timeStepSize"], "math": "strict" if args.strict_math else "fast",
             "deterministic_sort": not args.no_deterministic,
@@ -244,6 +248,7 @@ def main():
             "pair_interactions_per_step": int(pairs),
             "pair_interactions_per_s": pairs * args.steps / elapsed,
             "lds_fallback_blocks_last_step": int(stats["lds_fallback_blocks"]),
+            **({"solver_iterations_last_step": {"density": int(stats["iter_density"]), "divergence": int(stats["iter_divergence"])}} if method == "dfsph" else {}),
             "device": eng.device_info()["name"],
         },
         "roofline": {
