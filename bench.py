@@ -199,7 +199,7 @@ def main():
         for k, (n, ms) in sorted(table.items(), key=lambda kv: -kv[1][1]):
             print(f"  {k:24s} launches {n:5d}  avg {1e3 * ms / n:9.1f} us", file=sys.stderr)
     eng.profile_enable(-1, False)
-    eng.profile_enable(names.index(dom), True)
+    eng.profile_enable(names.index(dom), not os.environ.get('SPH_BENCH_NO_EVENTS'))
     eng.profile_reset()
 
     fence()

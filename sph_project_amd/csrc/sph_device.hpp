@@ -313,21 +313,22 @@ k_scatter(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
 // for typical cell populations (a float4 tile read as b128/b96 is 2-way conflicted at 8 per cell).
 #define NBR_PAD 40   // phase 1 may read up to 32+7 slots past a lane's run (masked afterwards)
 typedef float v2f __attribute__((ext_vector_type(2)));
-// 8 candidates = 16 ds_read_b64 (x,y) / (z,w) from `a` + 8u and `a` + zw_off + 8u, one s_waitcnt at the end.
+// 8 candidates = 8 ds_read_b64 (x,y) from `a` + 8u and 8 ds_read_b32 (z alone: w is not needed for the distance test,
+// 12 instead of 16 LDS bytes per candidate and lane) from `a` + zw_off + 8u, one s_waitcnt at the end.
 template <int ZW_OFF>
-__device__ __forceinline__ void lds_load_chunk_imm(unsigned a, v2f (&xy)[8], v2f (&zw)[8]) {
+__device__ __forceinline__ void lds_load_chunk_imm(unsigned a, v2f (&xy)[8], float (&z)[8]) {
     asm volatile(
-        "ds_read_b64 %0, %16\n\tds_read_b64 %8, %16 offset:%17\n\t"
-        "ds_read_b64 %1, %16 offset:8\n\tds_read_b64 %9, %16 offset:%17+8\n\t"
-        "ds_read_b64 %2, %16 offset:16\n\tds_read_b64 %10, %16 offset:%17+16\n\t"
-        "ds_read_b64 %3, %16 offset:24\n\tds_read_b64 %11, %16 offset:%17+24\n\t"
-        "ds_read_b64 %4, %16 offset:32\n\tds_read_b64 %12, %16 offset:%17+32\n\t"
-        "ds_read_b64 %5, %16 offset:40\n\tds_read_b64 %13, %16 offset:%17+40\n\t"
-        "ds_read_b64 %6, %16 offset:48\n\tds_read_b64 %14, %16 offset:%17+48\n\t"
-        "ds_read_b64 %7, %16 offset:56\n\tds_read_b64 %15, %16 offset:%17+56\n\t"
+        "ds_read_b64 %0, %16\n\tds_read_b32 %8, %16 offset:%17\n\t"
+        "ds_read_b64 %1, %16 offset:8\n\tds_read_b32 %9, %16 offset:%17+8\n\t"
+        "ds_read_b64 %2, %16 offset:16\n\tds_read_b32 %10, %16 offset:%17+16\n\t"
+        "ds_read_b64 %3, %16 offset:24\n\tds_read_b32 %11, %16 offset:%17+24\n\t"
+        "ds_read_b64 %4, %16 offset:32\n\tds_read_b32 %12, %16 offset:%17+32\n\t"
+        "ds_read_b64 %5, %16 offset:40\n\tds_read_b32 %13, %16 offset:%17+40\n\t"
+        "ds_read_b64 %6, %16 offset:48\n\tds_read_b32 %14, %16 offset:%17+48\n\t"
+        "ds_read_b64 %7, %16 offset:56\n\tds_read_b32 %15, %16 offset:%17+56\n\t"
         "s_waitcnt lgkmcnt(0)"
         : "=&v"(xy[0]), "=&v"(xy[1]), "=&v"(xy[2]), "=&v"(xy[3]), "=&v"(xy[4]), "=&v"(xy[5]), "=&v"(xy[6]), "=&v"(xy[7]),
-          "=&v"(zw[0]), "=&v"(zw[1]), "=&v"(zw[2]), "=&v"(zw[3]), "=&v"(zw[4]), "=&v"(zw[5]), "=&v"(zw[6]), "=&v"(zw[7])
+          "=&v"(z[0]), "=&v"(z[1]), "=&v"(z[2]), "=&v"(z[3]), "=&v"(z[4]), "=&v"(z[5]), "=&v"(z[6]), "=&v"(z[7])
         : "v"(a), "n"(ZW_OFF)
         : "memory");
 }
@@ -403,11 +404,12 @@ __device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int
         // All 16 ds_read_b64 of the chunk are issued back to back from one base register with immediate
         // offsets and waited for once (hand-placed: left to itself the scheduler keeps at most one candidate
         // in flight, or fuses neighbours into ds_read2_b64 = 8 LDS cycles per 16 bytes).
-        v2f xy[8], zw[8];
-        lds_load_chunk_imm<ZW_OFF>(lds_addr(&sXY[base + t0]), xy, zw);
+        v2f xy[8];
+        float zz[8];
+        lds_load_chunk_imm<ZW_OFF>(lds_addr(&sXY[base + t0]), xy, zz);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zw[u].x;
+            const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zz[u];
             const float r2 = dx * dx + dy * dy + dz * dz;
             asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                 : "+v"(mask) : "v"(r2), "v"(h2) : "vcc");  // not volatile: ordered by the dependence on mask
