@@ -750,6 +750,13 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                 const int o = tid == 0 ? lo_[0] : (tid == 1 ? lo_[1] : lo_[2]);
                 if (o == INT_MIN && l > 0) atomicAdd(&scal->fallback[c.stat_bank][b & (SPH_STAT_SLOTS - 1)], 1ull);
             }
+            // first mask word of this group's runs ([run][particle] layout): issued first, nothing below depends on them
+            // until the staging barrier has passed
+            unsigned mk[RPG] = {0u, 0u, 0u}, mh[RPG] = {0u, 0u, 0u};
+            if (MASKMODE == 2 && active && c.force_global != 12) {
+#pragma unroll
+                for (int q = 0; q < RPG; ++q) mk[q] = nbr_mask[(size_t)(g * RPG + q) * mask_stride + i];
+            }
             // candidate sub-ranges of this lane's particle in the three runs (from the cached cell_start windows)
             bool inr[RPG];
             int js_[RPG], m_[RPG];
@@ -775,16 +782,10 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     wide = wide || m_[q] > 32;
                     longrun = longrun || m_[q] > 64;
                 }
-            }
-            // stored masks of this group's runs ([run][particle] layout; second word only for runs beyond 32 candidates),
-            // issued before the staging so that their latency hides behind it
-            unsigned mk[RPG] = {0u, 0u, 0u}, mh[RPG] = {0u, 0u, 0u};
-            if (MASKMODE == 2 && c.force_global != 12) {
-#pragma unroll
-                for (int q = 0; q < RPG; ++q) {
-                    if (m_[q] > 0) mk[q] = nbr_mask[(size_t)(g * RPG + q) * mask_stride + i];
-                    if (m_[q] > 32) mh[q] = nbr_mask_hi[(size_t)(g * RPG + q) * mask_stride + i];
-                }
+                // second word only for the runs beyond 32 candidates; a run without candidates (or out of range) may hold
+                // a stale first word
+                if (MASKMODE == 2 && m_[q] > 32 && c.force_global != 12) mh[q] = nbr_mask_hi[(size_t)k * mask_stride + i];
+                if (MASKMODE == 2 && m_[q] <= 0) mk[q] = 0u;
             }
             // stage the runs that fit: <= 4 slots per thread; the loads of a batch are all issued before its first LDS
             // write (one global round trip per batch; wide records go in two batches to stay within the VGPR budget);
