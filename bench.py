@@ -146,12 +146,29 @@ def main():
         slab_opt = dict(rank=rank, nranks=world, unique_id=uid[0], cuts=cuts)
         n_global = int(sum((b["material"] == 1).sum() for b in batches))
         del batches, z
+    if world == 1 and os.environ.get("SPH_BENCH_FORCE_SLAB") and method == "wcsph":
+        # tuning aid: ONE rank in slab mode (classify / tables / ghost-aware kernels, no neighbour to talk to)
+        import numpy as np
+        _, geo, _b = H.scene_particles(cfg)
+        os.environ.setdefault("SPH_COMM_TRANSPORT", "shm")   # SPH_COMM_TRANSPORT=rccl: a one-rank RCCL communicator instead
+        uid = b"\0" * 128
+        if os.environ["SPH_COMM_TRANSPORT"] != "shm":
+            import ctypes
+            from sph_project_amd import _lib as L
+            buf = ctypes.create_string_buffer(128)
+            assert L.load().sph_comm_unique_id(buf) == 0
+            uid = buf.raw
+        slab_opt = dict(rank=0, nranks=1, unique_id=uid, cuts=[0, int(geo.grid_num[2])])
+        n_global = int(sum((b["material"] == 1).sum() for b in _b))
+        del _b
     opts = dict(fast_math=0 if args.strict_math else 1, deterministic=0 if args.no_deterministic else 1,
                 force_global=int(os.environ.get('SPH_DEBUG_MODE', int(args.force_global))), device=local_rank if world > 1 else -1)
     if method != "wcsph" and not args.measured_iterations:
         opts["fixed_iterations"] = 2
     container = solver = None
-    if slab_opt:
+    if slab_opt and world == 1:
+        container, solver = H.build_product(cfg, slab=slab_opt, **opts)
+    elif slab_opt:
         # every rank must agree on the mode: if the communicator cannot be set up anywhere, all fall back to replicas
         import torch
         err = ""

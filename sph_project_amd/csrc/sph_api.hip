@@ -31,6 +31,7 @@ struct SphHandle {
     int n = 0;            // particle_num
     int n_fluid = 0;      // fluid_particle_num
     int n_nonfluid = 0;
+    bool any_rigid_object = false;   // a non-fluid object was registered (slab sharding: its particles may live on another rank)
     int64_t steps = 0;
     double total_time = 0.0;
     bool prepared = false;
@@ -123,12 +124,14 @@ static void fill_consts(SphHandle *h) {
     c.V0 = (float)p.V0;
     c.force_global = p.force_global;
     c.stat_bank = 0;
+    c.ghosts = 0;
 }
 
 static void refresh_counts(SphHandle *h) {
     h->st.c.n = h->n;
     h->st.has_emitter = h->prm.g_upper < 9999.0;
-    h->st.c.all_fluid = (h->n_nonfluid == 0 && !h->st.has_emitter && !h->st.slab_active) ? 1 : 0;
+    h->st.c.all_fluid = (h->n_nonfluid == 0 && !h->st.has_emitter && !(h->st.slab_active && h->any_rigid_object)) ? 1 : 0;
+    h->st.c.ghosts = h->st.slab_active ? 1 : 0;
     h->st.has_rigid = h->n_nonfluid > 0;
 }
 
@@ -213,9 +216,9 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     }
     s.orig.b[0] = s.orig.b[1] = nullptr;
     const size_t G = (size_t)s.c.G;
-    CHK_CREATE(dalloc(h, &s.cell_count, G + 1)); CHK_CREATE(dalloc(h, &s.cell_start, G + 1));
+    CHK_CREATE(dalloc(h, &s.cell_count, G + 2)); CHK_CREATE(dalloc(h, &s.cell_start, G + 2));   // + graveyard cell (slab sharding)
     CHK_CREATE(dalloc(h, &s.cellid, cap)); CHK_CREATE(dalloc(h, &s.rank, cap)); CHK_CREATE(dalloc(h, &s.tmp_idx, cap));
-    s.scan_blocks = (int)((G + 2047) / 2048);
+    s.scan_blocks = (int)((G + 1 + 2047) / 2048);
     if (s.scan_blocks < SPH_STAT_SLOTS / 256) s.scan_blocks = SPH_STAT_SLOTS / 256;   // k_scan_final also clears the statistics slots
     CHK_CREATE(dalloc(h, &s.scan_partial, (size_t)s.scan_blocks + 1));
     s.cell_count_clean = 1;
@@ -337,6 +340,7 @@ extern "C" int sph_set_object(SphHandle *h, int object_id, int material, int is_
     if (!h || object_id < 0 || object_id >= SPH_MAX_OBJECTS) return fail(h, SPH_ERR_INVALID, "set_object: bad object id");
     HIPCHK(h, hipSetDevice(h->device));
     h->pose_h.material[object_id] = material;
+    if (material != 1) h->any_rigid_object = true;
     h->pose_h.is_dynamic[object_id] = is_dynamic ? 1 : 0;
     return upload_pose(h);
 }

@@ -225,29 +225,64 @@ static int slab_neighbor_search(SphHandle *h) {
     State &s = h->st;
     SlabComm &c = h->comm;
     { ProfScope p(h, SPH_K_HALO); h->L->halo_classify_pack(s, h->n); }
-    HIPCHK(h, hipMemcpyAsync(c.cnt_host, s.halo_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
-    HIPCHK(h, hipStreamSynchronize(s.stream));
-    const int kept = c.cnt_host[2];
-    for (int side = 0; side < 2; ++side) {
-        c.n_send[side] = c.cnt_host[side];
-        if (c.n_send[side] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "halo message of %d particles exceeds capacity %d", c.n_send[side], s.halo_cap);
-    }
     const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
     void *recv[2] = {s.recvbuf[0], s.recvbuf[1]};
-    const size_t bs[2] = {(size_t)c.n_send[0] * 48, (size_t)c.n_send[1] * 48};
-    size_t br[2] = {0, 0};
-    { ProfScope p(h, SPH_K_HALO); int rc = comm_exchange(h, send, bs, recv, br, false); if (rc) return rc; }
-    c.n_recv[0] = (int)(br[0] / 48); c.n_recv[1] = (int)(br[1] / 48);
-    if (c.n_recv[0] > s.halo_cap || c.n_recv[1] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "received halo exceeds capacity");
-    if ((long long)kept + c.n_recv[0] + c.n_recv[1] > s.cap)
-        return fail(h, SPH_ERR_CAPACITY, "slab holds %d + %d + %d particles, particle_max_num is %d", kept, c.n_recv[0], c.n_recv[1], s.cap);
+    int dropped = 0;
+    if (c.kind == 1) {
+        // RCCL: the record counts go to the neighbours straight from device memory, then ONE read-back brings my own
+        // counts and theirs to the host (the payload calls need both), then the payload
+        ProfScope p(h, SPH_K_HALO);
+        ncclComm_t comm = (ncclComm_t)c.nccl;
+        const int peer[2] = {c.rank - 1, c.rank + 1};
+        const bool has[2] = {s.has_down != 0, s.has_up != 0};
+        NCCLCHK(h, ncclGroupStart());
+        for (int side = 0; side < 2; ++side) {
+            if (!has[side]) continue;
+            NCCLCHK(h, ncclSend(s.halo_counts + side, 1, ncclInt32, peer[side], comm, s.stream));
+            NCCLCHK(h, ncclRecv(c.cnt_dev + 2 + side, 1, ncclInt32, peer[side], comm, s.stream));
+        }
+        NCCLCHK(h, ncclGroupEnd());
+        HIPCHK(h, hipMemcpyAsync(c.cnt_host, s.halo_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(h, hipMemcpyAsync(c.cnt_host + 4, c.cnt_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        dropped = c.cnt_host[2];
+        for (int side = 0; side < 2; ++side) {
+            c.n_send[side] = c.cnt_host[side];
+            c.n_recv[side] = has[side] ? c.cnt_host[6 + side] : 0;
+            if (c.n_send[side] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "halo message of %d particles exceeds capacity %d", c.n_send[side], s.halo_cap);
+            if (c.n_recv[side] < 0 || c.n_recv[side] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "received halo exceeds capacity");
+        }
+        const size_t bs[2] = {(size_t)c.n_send[0] * 48, (size_t)c.n_send[1] * 48};
+        size_t br[2] = {(size_t)c.n_recv[0] * 48, (size_t)c.n_recv[1] * 48};
+        int rc = comm_exchange(h, send, bs, recv, br, true); if (rc) return rc;
+    } else {
+        HIPCHK(h, hipMemcpyAsync(c.cnt_host, s.halo_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        dropped = c.cnt_host[2];
+        for (int side = 0; side < 2; ++side) {
+            c.n_send[side] = c.cnt_host[side];
+            if (c.n_send[side] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "halo message of %d particles exceeds capacity %d", c.n_send[side], s.halo_cap);
+        }
+        const size_t bs[2] = {(size_t)c.n_send[0] * 48, (size_t)c.n_send[1] * 48};
+        size_t br[2] = {0, 0};
+        { ProfScope p(h, SPH_K_HALO); int rc = comm_exchange(h, send, bs, recv, br, false); if (rc) return rc; }
+        c.n_recv[0] = (int)(br[0] / 48); c.n_recv[1] = (int)(br[1] / 48);
+        if (c.n_recv[0] > s.halo_cap || c.n_recv[1] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "received halo exceeds capacity");
+    }
+    // nothing was compacted: the arrivals are appended behind the old particles (dead ones included), the sort files the
+    // dead ones into the graveyard cell behind all live particles, and only then does the particle count shrink
+    const int n_old = h->n;
+    if ((long long)n_old + c.n_recv[0] + c.n_recv[1] > s.cap)
+        return fail(h, SPH_ERR_CAPACITY, "slab holds %d + %d + %d particles, particle_max_num is %d", n_old, c.n_recv[0], c.n_recv[1], s.cap);
     { ProfScope p(h, SPH_K_HALO);
-      h->L->halo_unpack_append(s, 0, c.n_recv[0], kept);
-      h->L->halo_unpack_append(s, 1, c.n_recv[1], kept + c.n_recv[0]); }
-    h->n = kept + c.n_recv[0] + c.n_recv[1];
+      h->L->halo_unpack_append(s, 0, c.n_recv[0], n_old);
+      h->L->halo_unpack_append(s, 1, c.n_recv[1], n_old + c.n_recv[0]); }
+    h->n = n_old + c.n_recv[0] + c.n_recv[1];
     refresh_counts(h);
-    s.c.all_fluid = 0;  // ghosts are told apart through the meta word
     ph_neighbor_search(h);
+    h->n -= dropped;
+    refresh_counts(h);   // ghosts are told apart through the meta word (Consts::ghosts)
+    s.halo_longest = std::max(std::max(c.n_send[0], c.n_send[1]), std::max(c.n_recv[0], c.n_recv[1]));
     { ProfScope p(h, SPH_K_HALO); h->L->halo_build_tables(s); }
     return SPH_OK;
 }

@@ -22,6 +22,7 @@
 #define META_DYN(m) (((m) >> 10) & 0x1)
 #define META_PACK(obj, mat, dyn) ((((obj) + 1) & 0xff) | (((mat) & 0x3) << 8) | (((dyn) & 1) << 10))
 #define META_GHOST(m) (((m) >> 11) & 0x1)   /* slab sharding: copy of a neighbour rank's boundary particle */
+#define META_DEAD(m) (((m) >> 12) & 0x1)    /* slab sharding: left this rank (or last step's ghost); sorted into the graveyard cell G */
 #define META_ACTIVE_FLUID(m) ((((m) >> 8) & 0xB) == 1) /* material fluid and not a ghost */
 #define META_SET_MAT(m, mat) (((m) & ~(0x3 << 8)) | (((mat) & 0x3) << 8))
 
@@ -43,6 +44,7 @@ struct Consts {
     int   n;                // particle_num
     int   all_fluid;        // no rigid / emitter particles in the container
     int   force_global;
+    int   ghosts;           // slab sharding: ghost particles present (meta bit 11) even when all_fluid
     int   stat_bank;        // DevScalars bank the running step counts into (step parity)
 };
 
@@ -114,6 +116,7 @@ struct State {
     float4 *sendbuf[2], *recvbuf[2];     // 3 float4 per particle record
     int *halo_counts;    // device: [0..1] send counts, [2] kept count
     int halo_cap;        // particles per message buffer
+    int halo_longest;    // longest halo message of the running step, in particles (sent or received)
     int slab_active, z_lo, z_hi, has_down, has_up;
     unsigned *nbr_mask;  // [9][cap]: acceptance mask of the first 32 candidates of every (particle, run), see process_run
     unsigned *nbr_mask_hi;  // [9][cap]: candidates 32..63 of the runs that have them

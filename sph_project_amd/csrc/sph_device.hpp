@@ -151,7 +151,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // particle's arrival rank inside its cell, which replaces the second atomic pass of :515.
 __global__ void __launch_bounds__(256)
 k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ cellid,
-             int *__restrict__ rank, int *__restrict__ cell_count) {
+             int *__restrict__ rank, int *__restrict__ cell_count, const int *__restrict__ meta_dead) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = i < c.n;
@@ -162,6 +162,7 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
         const int cy = cell_coord(p.y, c.grid_size, c.ny);
         const int cz = cell_coord(p.z, c.grid_size, c.nz);
         lin = (cx * c.ny + cy) * c.nz + cz;
+        if (meta_dead && META_DEAD(meta_dead[i])) lin = c.G;   // slab sharding: graveyard cell behind the grid
         cellid[i] = lin;
     }
     // The input is the previous step's sorted order, so lanes of one wave fall into a few runs of equal
@@ -265,6 +266,7 @@ k_scatter_index(int n, const int *__restrict__ cellid, const int *__restrict__ r
 }
 
 struct SortArrays {
+    int G;   // number of grid cells (cell id G = graveyard of the slab sharding)
     const float4 *posv_in, *velm_in, *orig_in;
     const int *meta_in, *pid_in;
     const unsigned *color_in;
@@ -287,7 +289,7 @@ k_scatter(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
     int cell = cellid[i];
     int s = cell_start[cell];
     int r;
-    if (STABLE) {
+    if (STABLE && cell < a.G) {   // the graveyard cell (slab sharding) may hold 1e5 particles nobody looks at again
         int e = cell_start[cell + 1];
         r = 0;
         for (int k = s; k < e; ++k) r += tmp_idx[k] < i ? 1 : 0;

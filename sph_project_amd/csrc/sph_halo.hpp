@@ -23,8 +23,7 @@
 #define META_SET_GHOST(m, g) (((m) & ~(1 << 11)) | ((g) << 11))
 
 struct HaloArrays {
-    const float4 *posv_in, *velm_in; const int *meta_in, *pid_in; const unsigned *color_in; const float *rho_in;
-    float4 *posv_out, *velm_out; int *meta_out, *pid_out; unsigned *color_out; float *rho_out; int *xidx_out;
+    const float4 *posv, *velm; int *meta; const int *pid; const unsigned *color; const float *rho; int *xidx;
 };
 
 __device__ __forceinline__ void halo_write_record(float4 *buf, int k, const float4 &p, const float4 &v, int meta,
@@ -34,47 +33,59 @@ __device__ __forceinline__ void halo_write_record(float4 *buf, int k, const floa
     buf[3 * k + 2] = make_float4(__int_as_float(meta), __int_as_float(pid), __uint_as_float(color), rho);
 }
 
-// counts[0] = records for the lower rank, counts[1] = upper rank, counts[2] = particles kept locally
+// one atomic per wave and counter: base index of this lane among the lanes with `want`
+__device__ __forceinline__ int halo_wave_slot(bool want, int *counter) {
+    const unsigned long long m = __ballot(want);
+    if (!m) return 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// In place: nothing is compacted or copied.  Particles that are no longer this rank's business (last step's ghosts,
+// migrants beyond the neighbour's boundary layer) get the DEAD bit; the sort that follows files them into the
+// graveyard cell G behind every live particle, and the live count shrinks by counts[2].
+// counts[0] = records for the lower rank, counts[1] = upper rank, counts[2] = particles that died.
 __global__ void __launch_bounds__(256)
 k_halo_classify(const Consts c, int n, int z_lo, int z_hi, int has_down, int has_up, HaloArrays a,
                 float4 *send_down, float4 *send_up, int cap, int *counts) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    int side = -1, dead = 0, xi = 0, mnew = 0, mrec = 0;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        const int m = a.meta[i];
+        mnew = m;
+        if (META_GHOST(m) || META_DEAD(m)) {   // last step's ghosts are re-sent by their owners
+            dead = 1;
+        } else {
+            p = a.posv[i];
+            const int cz = cell_coord(p.z, c.grid_size, c.nz);
+            if (cz < z_lo && has_down) {           // left through the lower face: ownership moves down
+                side = 0; mrec = META_SET_GHOST(m, 0);
+                if (cz == z_lo - 1) mnew = META_SET_GHOST(m, 1); else dead = 1;   // kept as "echo ghost" / gone
+            } else if (cz >= z_hi && has_up) {
+                side = 1; mrec = META_SET_GHOST(m, 0);
+                if (cz == z_hi) mnew = META_SET_GHOST(m, 1); else dead = 1;
+            } else if (cz == z_lo && has_down) { side = 0; mrec = META_SET_GHOST(m, 1); }
+            else if (cz == z_hi - 1 && has_up) { side = 1; mrec = META_SET_GHOST(m, 1); }
+        }
+    }
+    const int k0 = halo_wave_slot(side == 0, &counts[0]);
+    const int k1 = halo_wave_slot(side == 1, &counts[1]);
+    halo_wave_slot(dead != 0, &counts[2]);
     if (i >= n) return;
-    const int m = a.meta_in[i];
-    if (META_GHOST(m)) return;  // last step's ghosts are re-sent by their owners
-    const float4 p = a.posv_in[i];
-    const float4 v = a.velm_in[i];
-    const int pid = a.pid_in[i];
-    const unsigned col = a.color_in[i];
-    const float rho = a.rho_in[i];
-    const int cz = cell_coord(p.z, c.grid_size, c.nz);
-    int keep = 1, ghost_local = 0, xi = 0;
-    if (cz < z_lo && has_down) {           // left through the lower face: ownership moves down
-        const int k = atomicAdd(&counts[0], 1);
-        if (k < cap) halo_write_record(send_down, k, p, v, META_SET_GHOST(m, 0), pid, col, rho);
-        keep = cz == z_lo - 1; ghost_local = 1;
-        xi = HALO_PACK(HALO_ECHO_GHOST + 0, k);
-    } else if (cz >= z_hi && has_up) {
-        const int k = atomicAdd(&counts[1], 1);
-        if (k < cap) halo_write_record(send_up, k, p, v, META_SET_GHOST(m, 0), pid, col, rho);
-        keep = cz == z_hi; ghost_local = 1;
-        xi = HALO_PACK(HALO_ECHO_GHOST + 1, k);
-    } else if (cz == z_lo && has_down) {
-        const int k = atomicAdd(&counts[0], 1);
-        if (k < cap) halo_write_record(send_down, k, p, v, META_SET_GHOST(m, 1), pid, col, rho);
-        xi = HALO_PACK(HALO_SEND + 0, k);
-    } else if (cz == z_hi - 1 && has_up) {
-        const int k = atomicAdd(&counts[1], 1);
-        if (k < cap) halo_write_record(send_up, k, p, v, META_SET_GHOST(m, 1), pid, col, rho);
-        xi = HALO_PACK(HALO_SEND + 1, k);
+    if (side >= 0) {
+        const int k = side == 0 ? k0 : k1;
+        if (k < cap) halo_write_record(side == 0 ? send_down : send_up, k, p, a.velm[i], mrec, a.pid[i], a.color[i], a.rho[i]);
+        const bool migrant = !META_GHOST(mrec);
+        xi = HALO_PACK((migrant ? HALO_ECHO_GHOST : HALO_SEND) + side, k);
     }
-    if (keep) {
-        const int d = atomicAdd(&counts[2], 1);
-        a.posv_out[d] = p; a.velm_out[d] = v;
-        a.meta_out[d] = META_SET_GHOST(m, ghost_local);
-        a.pid_out[d] = pid; a.color_out[d] = col; a.rho_out[d] = rho;
-        a.xidx_out[d] = xi;
-    }
+    if (dead) { mnew |= 1 << 12; xi = 0; }
+    a.meta[i] = mnew;
+    a.xidx[i] = xi;
 }
 
 // appends `count` records received from `side` (0 = lower rank, 1 = upper rank) at [offset, offset + count)
@@ -97,6 +108,13 @@ k_halo_unpack(const Consts c, int count, int offset, int side, int z_lo, int z_h
         xi = cz == edge ? HALO_PACK(HALO_ECHO_SEND + side, k) : 0;
     }
     xidx[d] = xi;
+}
+
+// slot tables start out empty (-1) up to the longest message of this step
+__global__ void __launch_bounds__(256) k_halo_tab_reset(int count, int *t0, int *t1, int *t2, int *t3, int *t4, int *t5, int *t6, int *t7) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    t0[k] = -1; t1[k] = -1; t2[k] = -1; t3[k] = -1; t4[k] = -1; t5[k] = -1; t6[k] = -1; t7[k] = -1;
 }
 
 // after the sort: slot tables from the xidx that rode along.  tab[kind - 1] for kinds 1..8.

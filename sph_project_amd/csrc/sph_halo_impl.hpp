@@ -1,18 +1,14 @@
 // sph_halo_impl.hpp -- launchers of the slab-sharding kernels (included inside the per-build namespace)
 #pragma once
 
-// reads the current arrays, writes the kept particles to the alt buffers (then flips) and the messages
+// in place: marks the particles this rank drops, tags the ones a neighbour needs and writes the two messages
 static void l_halo_classify_pack(State &s, int n) {
     hipMemsetAsync(s.halo_counts, 0, 4 * sizeof(int), s.stream);
-    for (int k = 0; k < 8; ++k) hipMemsetAsync(s.halo_tab[k], 0xff, sizeof(int) * (size_t)s.halo_cap, s.stream);
     if (n > 0) {
-        HaloArrays a{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(),
-                     s.posv.alt(), s.velm.alt(), s.meta.alt(), s.pid.alt(), s.color.alt(), s.rho.alt(), s.xidx[1 - s.xcur]};
+        HaloArrays a{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(), s.xidx[s.xcur]};
         hipLaunchKernelGGL(k_halo_classify, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, n, s.z_lo, s.z_hi, s.has_down,
                            s.has_up, a, s.sendbuf[0], s.sendbuf[1], s.halo_cap, s.halo_counts);
     }
-    s.posv.flip(); s.velm.flip(); s.meta.flip(); s.pid.flip(); s.color.flip(); s.rho.flip();
-    s.xcur = 1 - s.xcur;
 }
 
 static void l_halo_unpack_append(State &s, int side, int count, int offset) {
@@ -24,6 +20,10 @@ static void l_halo_unpack_append(State &s, int side, int count, int offset) {
 
 static void l_halo_build_tables(State &s) {
     if (s.c.n == 0) return;
+    const int longest = s.halo_longest;   // longest message of this step (sent or received)
+    if (longest > 0)
+        hipLaunchKernelGGL(k_halo_tab_reset, dim3(cdiv(longest, 256)), dim3(256), 0, s.stream, longest, s.halo_tab[0], s.halo_tab[1],
+                           s.halo_tab[2], s.halo_tab[3], s.halo_tab[4], s.halo_tab[5], s.halo_tab[6], s.halo_tab[7]);
     HaloTables t;
     for (int k = 0; k < 8; ++k) t.tab[k] = s.halo_tab[k];
     hipLaunchKernelGGL(k_halo_tables, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.xidx[s.xcur], t);

@@ -24,15 +24,15 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 void l_hash_count(State &s) {
     const int n = s.c.n;
-    if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 1), s.stream);
+    if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 2), s.stream);
     s.cell_count_clean = 0;
     if (n == 0) return;
     hipLaunchKernelGGL(k_hash_count, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.cellid,
-                       s.rank, s.cell_count);
+                       s.rank, s.cell_count, s.slab_active ? s.meta.cur() : nullptr);
 }
 
 void l_scan(State &s) {
-    const int G = s.c.G;
+    const int G = s.c.G + (s.slab_active ? 1 : 0);   // + graveyard cell
     const int nb = s.scan_blocks;
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_TPB), 0, s.stream, s.scan_partial, nb);
@@ -57,6 +57,7 @@ void l_scatter_impl(State &s, bool stable) {
     const int n = s.c.n;
     if (n == 0) return;
     SortArrays a;
+    a.G = s.c.G;
     a.posv_in = s.posv.cur(); a.posv_out = s.posv.alt();
     a.velm_in = s.velm.cur(); a.velm_out = s.velm.alt();
     a.meta_in = s.meta.cur(); a.meta_out = s.meta.alt();
@@ -78,7 +79,8 @@ void l_scatter_impl(State &s, bool stable) {
     (void)tmp_idx;
     s.posv.flip(); s.velm.flip(); s.meta.flip(); s.pid.flip(); s.color.flip(); s.rho.flip();
     s.masks_valid = 0;  // new order, new candidate runs
-    l_block_prep(s);
+    if (!s.slab_active) l_block_prep(s);
+    else s.perm_n = s.list_n = -1;   // slab sharding: rebuilt once the dead particles behind the live ones are dropped (launch_pass)
     if (s.orig.cur()) s.orig.flip();
     if (s.slab_active) s.xcur = 1 - s.xcur;
 }

@@ -31,9 +31,10 @@ struct DensityPass {
     __device__ float4 loadA(int j) const { return posv[j]; }
     __device__ BT loadB(int) const { return 0; }
     __device__ float4 stage(const Consts &, int j, BT &) const { return posv[j]; }
-    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
+    __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
         o.sum = 0.0f;
-        return AF || META_ACTIVE_FLUID(meta[i]);
+        if (AF && !c.ghosts) return true;
+        return META_ACTIVE_FLUID(meta[i]);   // all-fluid slab: every particle is fluid, ghosts are not targets
     }
     __device__ void pair(const Consts &c, Own &o, float, float, float, float r2, const float4 &a, const BT &,
                          int) const {
@@ -96,7 +97,7 @@ struct NonPressurePass {
     }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
     __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
-        if (!AF && !META_ACTIVE_FLUID(meta[i])) return false;
+        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
         float4 v = velm[i];
         if (visc_vel) { const float4 u = visc_vel[i]; v.x = u.x; v.y = u.y; v.z = u.z; }  // base_solver.py:464
         o.vx = v.x; o.vy = v.y; o.vz = v.z; o.m = v.w;
@@ -203,8 +204,9 @@ struct PressurePass {
     __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
-    __device__ bool begin(const Consts &, int i, const float4 &pi, Own &o) const {
+    __device__ bool begin(const Consts &c, int i, const float4 &pi, Own &o) const {
         if (!AF) { const int m = meta[i]; if (!META_ACTIVE_FLUID(m) || !META_DYN(m)) return false; }
+        else if (c.ghosts && META_GHOST(meta[i])) return false;
         o.x = pi.x; o.y = pi.y; o.z = pi.z; o.m0 = rho0 * pi.w;
         o.pt = ptm[i]; o.p = prs[i];
         const float r = rho[i];
@@ -290,6 +292,7 @@ struct WcsphForcePass {
     }
     __device__ bool begin(const Consts &c, int i, const float4 &pi, Own &o) const {
         o.dyn = 1;
+        if (AF && c.ghosts && META_GHOST(meta[i])) return false;   // all-fluid slab: ghosts are neighbours only
         if (!AF) {
             const int m = meta[i];
             if (!META_ACTIVE_FLUID(m)) return false;
