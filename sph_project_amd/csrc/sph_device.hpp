@@ -472,7 +472,8 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
         for (int j0 = js; j0 < je; j0 += 32) {
             const int m = (je - j0) < 32 ? (je - j0) : 32;
             unsigned mask = 0;
-#pragma unroll(MASKMODE == 2 ? 1 : 4)
+            constexpr int UNR = MASKMODE == 2 ? 1 : 4;
+#pragma unroll UNR
             for (int t = 0; t < m; ++t) {
                 const int j = j0 + t;
                 const float4 a = p.loadA(j);
@@ -644,7 +645,7 @@ k_compact_blocks(const int *__restrict__ flag, int nb, int *__restrict__ list, i
 // a whole group down the ordered path.
 template <class P> constexpr int nbr_tile_cap() {
     const int per_slot = 16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0);
-    const int slots = (40960 - 9 * NBR_CS_PITCH * 2 - 256) / per_slot - NBR_PAD;
+    const int slots = (40960 - 9 * NBR_CS_PITCH * 2 - 1536) / per_slot - NBR_PAD;   // 1.5 KB for the small arrays and the allocation granule
     return slots > 1280 ? 1280 : slots / 8 * 8;
 }
 // LDS bytes of k_nbr_pass<P, MASKMODE> (tile + cell_start windows + small change)
