@@ -346,21 +346,32 @@ class BaseContainer:
         return np.asarray(pts, dtype=np.float32).reshape(-1, self.dim)
 
     def load_rigid_body(self, rigid_body, pitch=None):
-        """base_container.py:611 voxelises the mesh with trimesh.  Mesh voxelisation is outside the
-        accelerated path: supply precomputed points via "voxelizedPoints" (array or .npy path) or
-        have trimesh installed."""
+        """base_container.py:611: the mesh is voxelised at the particle diameter and filled.  Order of preference:
+        a "voxelizedPoints" entry in the scene (array or .npy path: pins the particle set), trimesh if it is installed
+        (the reference's own code path), else sph_project_amd.meshgen (numpy restatement, parity unpinned)."""
         pts = self._points_from_body(rigid_body, "rigid")
         if pts is not None:
             return pts
+        pitch = self.particle_diameter if pitch is None else pitch
+        angle = rigid_body["rotationAngle"] / 360 * 2 * 3.1415926
         try:
             import trimesh as tm
-        except ImportError as exc:
-            raise NotImplementedError('RigidBodies need trimesh (absent) or a "voxelizedPoints" entry') from exc
-        pitch = self.particle_diameter if pitch is None else pitch
+        except ImportError:
+            tm = None
+        if tm is None:
+            from sph_project_amd import meshgen
+            mesh = meshgen.load_obj(rigid_body["geometryFile"])
+            if rigid_body["isDynamic"]:   # :616-626: dynamic bodies are scaled only, the rigid solver places them
+                mesh = meshgen.place(mesh, rigid_body["scale"], 0.0, [0.0, 1.0, 0.0], [0.0, 0.0, 0.0])
+            else:
+                mesh = meshgen.place(mesh, rigid_body["scale"], angle, rigid_body["rotationAxis"], rigid_body["translation"])
+            rigid_body["mesh"] = mesh.copy()
+            rigid_body["restPosition"] = rigid_body["mesh"].vertices
+            rigid_body["restCenterOfMass"] = np.array([0.0, 0.0, 0.0])
+            return meshgen.voxel_points(mesh, pitch)
         mesh = tm.load(rigid_body["geometryFile"])
         mesh.apply_scale(rigid_body["scale"])
         if not rigid_body["isDynamic"]:
-            angle = rigid_body["rotationAngle"] / 360 * 2 * 3.1415926
             rot = tm.transformations.rotation_matrix(angle, rigid_body["rotationAxis"], mesh.vertices.mean(axis=0))
             mesh.apply_transform(rot)
             mesh.vertices += np.array(rigid_body["translation"])
@@ -371,18 +382,20 @@ class BaseContainer:
         return np.asarray(mesh.voxelized(pitch=pitch).fill().points, dtype=np.float32)
 
     def load_fluid_body(self, body, pitch=None):
-        """base_container.py:676 (same note as load_rigid_body)."""
+        """base_container.py:676: lattice points inside the mesh (same order of preference as load_rigid_body)."""
         pts = self._points_from_body(body, "fluid")
         if pts is not None:
             return pts
+        pitch = self.particle_diameter if pitch is None else pitch
+        angle = body["rotationAngle"] / 360 * 2 * 3.1415926
         try:
             import trimesh as tm
-        except ImportError as exc:
-            raise NotImplementedError('FluidBodies need trimesh (absent) or a "voxelizedPoints" entry') from exc
-        pitch = self.particle_diameter if pitch is None else pitch
+        except ImportError:
+            from sph_project_amd import meshgen
+            mesh = meshgen.place(meshgen.load_obj(body["geometryFile"]), body["scale"], angle, body["rotationAxis"], body["translation"])
+            return meshgen.fluid_points(mesh, pitch)
         mesh = tm.load(body["geometryFile"])
         mesh.apply_scale(body["scale"])
-        angle = body["rotationAngle"] / 360 * 2 * 3.1415926
         mesh.apply_transform(tm.transformations.rotation_matrix(angle, body["rotationAxis"], mesh.vertices.mean(axis=0)))
         mesh.vertices += np.array(body["translation"])
         lo, hi = mesh.bounding_box.bounds

@@ -91,3 +91,41 @@ def test_dynamic_rigid_wrench_and_pose(gpu, method):
     vr = H.by_id(H.oracle_ids(ref), ref.field("particle_velocities").copy())
     np.testing.assert_allclose(H.by_id(ids, eng.download(L.F_POSITION))[rigid], xr[rigid], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(H.by_id(ids, eng.download(L.F_VELOCITY))[rigid], vr[rigid], rtol=1e-5, atol=1e-7)
+
+
+def test_mesh_rigid_and_fluid_bodies_from_obj(gpu, tmp_path):
+    """a scene in the reference's format with a static mesh obstacle (RigidBodies) and a mesh-shaped
+    fluid volume (FluidBodies), both from .obj files, runs through the container without trimesh: the particles come
+    from sph_project_amd.meshgen.  Known answers: particle counts of the unit-cube mesh, the obstacle does not move, the
+    fluid stays above it, the fluid->rigid wrench is downwards on a static body that was declared dynamic = False."""
+    from tests.test_meshgen import write_cube_obj
+    obj = tmp_path / "cube.obj"
+    write_cube_obj(obj)
+    cfg = H.dam_break_scene(domain_end=(1.0, 1.0, 1.0), end=(0.0, 0.0, 0.0))
+    cfg["FluidBlocks"] = []
+    cfg["RigidBodies"] = [{"objectId": 1, "geometryFile": str(obj), "translation": [0.3, 0.1, 0.3], "rotationAxis": [0, 1, 0],
+                           "rotationAngle": 0.0, "scale": [0.4, 0.1, 0.4], "velocity": [0, 0, 0], "density": 1000.0,
+                           "color": [255, 255, 255], "isDynamic": False, "entryTime": -1.0}]
+    cfg["FluidBodies"] = [{"objectId": 0, "geometryFile": str(obj), "translation": [0.4, 0.26, 0.4], "rotationAxis": [0, 1, 0],
+                           "rotationAngle": 0.0, "scale": [0.2, 0.2, 0.2], "velocity": [0, 0, 0], "density": 1000.0,
+                           "color": [50, 100, 200], "entryTime": -1.0}]
+    container, solver = H.build_product(cfg)
+    solver.prepare()
+    e = container.engine
+    mat = e.download(L.F_MATERIAL)
+    n_rigid, n_fluid = int((mat == 2).sum()), int((mat == 1).sum())
+    assert n_rigid == 21 * 6 * 21      # voxels of a 0.4 x 0.1 x 0.4 slab at pitch 0.02, surface + interior
+    from sph_project_amd import meshgen
+    expect = meshgen.fluid_points(meshgen.place(meshgen.load_obj(str(obj)), [0.2, 0.2, 0.2], 0.0, [0, 1, 0], [0.4, 0.26, 0.4]), 0.02)
+    assert n_fluid == len(expect) and 9 ** 3 <= n_fluid <= 11 ** 3   # np.arange lattice of a 0.2 cube (end points: fp)
+    x0 = H.by_id(e.download(L.F_PARTICLE_ID), e.download(L.F_POSITION))
+    rigid_ids = np.nonzero(H.by_id(e.download(L.F_PARTICLE_ID), mat) == 2)[0]
+    for _ in range(300):
+        solver.step()
+    ids = e.download(L.F_PARTICLE_ID)
+    x = H.by_id(ids, e.download(L.F_POSITION))
+    assert np.isfinite(x).all()
+    np.testing.assert_array_equal(x[rigid_ids], x0[rigid_ids])             # static obstacle
+    fluid = np.setdiff1d(np.arange(len(x)), rigid_ids)
+    assert x[fluid, 1].min() > 0.2 - 0.5 * 0.02                            # nothing leaked through the slab top (y = 0.2)
+    assert x[fluid, 1].mean() < x0[fluid, 1].mean()                        # and the block has come down onto it
