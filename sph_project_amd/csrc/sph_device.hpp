@@ -181,7 +181,7 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
 }
 
 // base_container.py:546 PrefixSumExecutor.run -- here an exclusive scan into cell_start[0..G],
-// three launches: tile sums, scan of tile sums, tile rescans.
+// two launches: tile sums, then tile rescans (each adds up the tile sums before it).
 #define SCAN_TPB 256
 #define SCAN_IPT 8
 #define SCAN_TILE (SCAN_TPB * SCAN_IPT)
@@ -216,20 +216,6 @@ k_scan_reduce(const int *__restrict__ in, int n, int *__restrict__ partial) {
 }
 
 __global__ void __launch_bounds__(SCAN_TPB)
-k_scan_partials(int *__restrict__ partial, int nb) {
-    __shared__ int s_w[SCAN_TPB / 64];
-    int carry = 0;
-    for (int b0 = 0; b0 < nb; b0 += SCAN_TPB) {
-        int idx = b0 + threadIdx.x;
-        int v = idx < nb ? partial[idx] : 0;
-        int tot;
-        int ex = block_excl_scan_256(v, s_w, tot);
-        if (idx < nb) partial[idx] = carry + ex;
-        carry += tot;
-    }
-}
-
-__global__ void __launch_bounds__(SCAN_TPB)
 k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *__restrict__ out,
              int total_particles, DevScalars *__restrict__ scal, int clear_bank) {
     // side jobs of the kernel that runs every step: clears cell_count behind itself (the next histogram starts from
@@ -244,8 +230,13 @@ k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *
     int s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; ++k) { int idx = base + k; v[k] = idx < n ? in[idx] : 0; s += v[k]; }
-    int tot;
-    int ex = block_excl_scan_256(s, s_w, tot) + partial[blockIdx.x];
+    // offset of this tile = sum of the tile sums before it (every workgroup adds them up itself: a few thousand ints
+    // out of L2 instead of a third launch)
+    int before = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_TPB) before += partial[k];
+    int tot, btot;
+    block_excl_scan_256(before, s_w, btot);
+    int ex = block_excl_scan_256(s, s_w, tot) + btot;
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; ++k) {
         int idx = base + k;

@@ -35,7 +35,6 @@ void l_scan(State &s) {
     const int G = s.c.G + (s.slab_active ? 1 : 0);   // + graveyard cell
     const int nb = s.scan_blocks;
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_TPB), 0, s.stream, s.scan_partial, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial,
                        s.cell_start, s.c.n, s.scal, 1 - s.c.stat_bank);
     s.cell_count_clean = 1;
