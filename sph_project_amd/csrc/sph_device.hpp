@@ -335,13 +335,6 @@ __device__ __forceinline__ float2 lds_ld2a(unsigned byte_addr) {  // plain (sche
     const unsigned long long v = *(lds_cu64 *)(size_t)byte_addr;
     return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
-// volatile 64-bit LDS load: keeps the backend from fusing neighbouring reads into ds_read2_b64
-// (16 B per lane at 8 cycles, 32-bank modulus) -- two plain ds_read_b64 cost 2 cycles each.
-__device__ __forceinline__ float2 lds_ld2(const float2 *p) {
-    typedef const volatile __attribute__((address_space(3))) unsigned long long *lds_u64;
-    const unsigned long long v = *(lds_u64)(p);
-    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
-}
 // P::FLUID_BLOCKS_ONLY: the functor is active for fluid particles only and its passive() is empty, so workgroups without
 // a single fluid particle (the bulk of a scene with a sampled domain box) need not be launched at all.
 template <class P, class = void> struct PassFluidOnly { static constexpr bool value = false; };
