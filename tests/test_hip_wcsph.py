@@ -235,3 +235,48 @@ def test_c2_full_size_20_steps(gpu):
     assert solver.stats()["pair_interactions"] == ref.last_pairs
 
 
+
+
+def test_fluid_workgroup_list_changes_nothing(gpu, monkeypatch):
+    """With a sampled domain box most workgroups hold no fluid; fluid-only functors launch the listed ones only.
+    Same particles, same order of operations: bitwise the same state as with every workgroup launched."""
+    cfg = H.dam_break_scene(domain_end=(0.6, 0.6, 0.6), end=(0.2, 0.2, 0.2), translation=(0.06, 0.06, 0.06),
+                            add_domain_box=True)
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("SPH_NO_BLOCK_LIST", "1")
+        container, solver = H.build_product(cfg)
+        solver.prepare()
+        for _ in range(10):
+            solver.step()
+        out.append((_state(container), solver.stats()))
+    for k in ("x", "v", "rho", "p", "a", "V"):
+        np.testing.assert_array_equal(out[0][0][k], out[1][0][k])
+    assert out[0][1]["pair_interactions"] == out[1][1]["pair_interactions"]
+
+
+def test_bench_line_contract(gpu):
+    """bench.py prints ONE JSON line with the fields the driver and the judge read (small configuration)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c1", "--steps", "5", "--warmup", "2",
+                        "--cpu-steps", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["dtype"] == "f32" and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["bound"] == "hbm" and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port" and d["value"] > d["cpu_baseline"]["value"] > 0
