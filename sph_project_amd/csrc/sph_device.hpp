@@ -125,6 +125,9 @@ template <class T> __device__ __forceinline__ T ldg_idx(const T *base, int j) {
 // XCD-aware, bijective workgroup remap: consecutive tiles share neighbour runs, so keep them on
 // one XCD's L2 (dispatch places workgroup b on XCD b % 8).
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
+#ifdef SPH_NO_XCD_REMAP
+    return b;
+#endif
     int xcd = b & 7, q = nb >> 3, r = nb & 7;
     int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (b >> 3);
