@@ -91,7 +91,8 @@ static void fill_consts(SphHandle *h) {
     const SphParams &p = h->prm;
     Consts &c = h->st.c;
     memset(&c, 0, sizeof(c));
-    c.nx = p.grid_num[0]; c.ny = p.grid_num[1]; c.nz = p.grid_num[2];
+    c.nx = p.grid_num[0]; c.ny = p.grid_num[1]; c.nz = c.nz_glob = p.grid_num[2];
+    c.cz_off = 0;
     c.G = c.nx * c.ny * c.nz;
     const double hd = p.support_radius;
     c.grid_size = (float)hd;
@@ -262,7 +263,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     for (int o = 0; o < SPH_NOBJ; ++o) { h->pose_h.rot[o][0] = h->pose_h.rot[o][4] = h->pose_h.rot[o][8] = 1.0f; }
     memset(&h->last, 0, sizeof(h->last));
     s.has_dynamic_rigid = 0; s.has_rigid = 0;
-    s.slab_active = 0; s.xcur = 0; s.halo_cap = 0; s.z_lo = 0; s.z_hi = s.c.nz; s.has_down = s.has_up = 0;
+    s.slab_active = 0; s.xcur = 0; s.halo_cap = 0; s.z_lo = 0; s.z_hi = s.c.nz_glob; s.has_down = s.has_up = 0;
     s.xidx[0] = s.xidx[1] = nullptr; s.halo_counts = nullptr;
     s.visc_rho_raw = (p.method == SPH_METHOD_WCSPH);
     s.skip_viscosity = 0;
@@ -673,7 +674,7 @@ extern "C" int sph_download(SphHandle *h, int field, void *dst, size_t bytes) {
         const Consts &c = s.c;
         auto cc = [](float x, float gs, int nn) { int v = (int)(x / gs); v = v < 0 ? 0 : v; return v > nn - 1 ? nn - 1 : v; };
         for (size_t i = 0; i < n; ++i)
-            d[i] = (cc(tmp[i].x, c.grid_size, c.nx) * c.ny + cc(tmp[i].y, c.grid_size, c.ny)) * c.nz + cc(tmp[i].z, c.grid_size, c.nz);
+            d[i] = (cc(tmp[i].x, c.grid_size, c.nx) * c.ny + cc(tmp[i].y, c.grid_size, c.ny)) * c.nz + std::min(std::max(cc(tmp[i].z, c.grid_size, c.nz_glob) - c.cz_off, 0), c.nz - 1);
         return SPH_OK;
     }
     return fail(h, SPH_ERR_INVALID, "download: unknown field %d", field);

@@ -123,14 +123,23 @@ extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id1
     }
     s.slab_active = 1;
     s.has_down = rank > 0; s.has_up = rank < nranks - 1;
-    s.z_lo = 0; s.z_hi = s.c.nz;
+    s.z_lo = 0; s.z_hi = s.c.nz_glob;
     return SPH_OK;
 }
 
 extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
     if (!h || !h->comm.kind) return fail(h, SPH_ERR_INVALID, "comm_set_slab: communicator not initialised");
-    if (z_lo < 0 || z_hi > h->st.c.nz || z_hi - z_lo < 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: a slab needs >= 2 cell layers inside the grid");
+    Consts &c = h->st.c;
+    if (z_lo < 0 || z_hi > c.nz_glob || z_hi - z_lo < 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: a slab needs >= 2 cell layers inside the grid");
+    if (h->n > 0) return fail(h, SPH_ERR_INVALID, "comm_set_slab: set the slab before particles are appended");
     h->st.z_lo = z_lo; h->st.z_hi = z_hi;
+    // the cell lists cover the own layers plus one ghost layer per interior side only: G, and with it the histogram, the
+    // scan and the cell windows, shrink from the global grid to the slab (weak scaling would otherwise scan N times as
+    // many cells on every rank)
+    c.cz_off = z_lo > 0 ? z_lo - 1 : 0;
+    const int top = z_hi < c.nz_glob ? z_hi + 1 : c.nz_glob;
+    c.nz = top - c.cz_off;
+    c.G = c.nx * c.ny * c.nz;
     return SPH_OK;
 }
 

@@ -27,7 +27,8 @@
 #define META_SET_MAT(m, mat) (((m) & ~(0x3 << 8)) | (((mat) & 0x3) << 8))
 
 struct Consts {
-    int nx, ny, nz, G;
+    int nx, ny, nz, G;      // grid the cell lists are built on (slab sharding: nz = own layers + ghost layers, see cz_off)
+    int nz_glob, cz_off;    // global number of z layers; global layer of local layer 0
     float grid_size;        // f32(dh): cell size
     float h, h2, inv_h;     // support radius, squared, reciprocal (fast build)
     float kW, kG;           // cubic spline constants (base_solver.py:57, :81)

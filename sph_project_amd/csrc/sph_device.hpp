@@ -45,6 +45,14 @@ __device__ __forceinline__ int cell_coord(float x, float gs, int n) {
     return c;
 }
 
+// z axis: a slab-sharded rank builds its cell lists on its own layers only (local layer = global layer - cz_off); a
+// particle outside them (it is about to be dropped) is clamped onto the nearest local layer.
+__device__ __forceinline__ int cell_coord_z(const Consts &c, float z) {
+    int cz = cell_coord(z, c.grid_size, c.nz_glob) - c.cz_off;
+    cz = cz < 0 ? 0 : cz;
+    return cz > c.nz - 1 ? c.nz - 1 : cz;
+}
+
 // Per-pair geometry shared by kernel_W / kernel_gradient.  Strict build: rn = sqrt(r2), q = rn / h (IEEE).
 // Fast build: one v_rsq_f32 gives 1/rn; rn = r2 * (1/rn), q = rn * (1/h), 1/(rn h) = (1/rn)(1/h).
 struct Geom { float rn, q, inv_rnh; };
@@ -163,7 +171,7 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
         const float4 p = posv[i];
         const int cx = cell_coord(p.x, c.grid_size, c.nx);
         const int cy = cell_coord(p.y, c.grid_size, c.ny);
-        const int cz = cell_coord(p.z, c.grid_size, c.nz);
+        const int cz = cell_coord_z(c, p.z);
         lin = (cx * c.ny + cy) * c.nz + cz;
         if (meta_dead && META_DEAD(meta_dead[i])) lin = c.G;   // slab sharding: graveyard cell behind the grid
         cellid[i] = lin;
@@ -562,7 +570,7 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
         key = k < 0 ? 0 : (k > 62 ? 62 : k);
         if (tid == 0 || tid == nvalid - 1) {
             const int cy = cell_coord(p.y, c.grid_size, c.ny);
-            const int cz = cell_coord(p.z, c.grid_size, c.nz);
+            const int cz = cell_coord_z(c, p.z);
             const int lin = (cx * c.ny + cy) * c.nz + cz;
             if (tid == 0) s_c[0] = lin;
             if (tid == nvalid - 1) s_c[1] = lin;
@@ -709,7 +717,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     if (valid) {
         cx = cell_coord(pi.x, c.grid_size, c.nx);
         cy = cell_coord(pi.y, c.grid_size, c.ny);
-        cz = cell_coord(pi.z, c.grid_size, c.nz);
+        cz = cell_coord_z(c, pi.z);
         lin = (cx * c.ny + cy) * c.nz + cz;
         active = p.begin(c, i, pi, own);
     }

@@ -62,7 +62,7 @@ k_halo_classify(const Consts c, int n, int z_lo, int z_hi, int has_down, int has
             dead = 1;
         } else {
             p = a.posv[i];
-            const int cz = cell_coord(p.z, c.grid_size, c.nz);
+            const int cz = cell_coord(p.z, c.grid_size, c.nz_glob);   // global layer: compared with the slab bounds
             if (cz < z_lo && has_down) {           // left through the lower face: ownership moves down
                 side = 0; mrec = META_SET_GHOST(m, 0);
                 if (cz == z_lo - 1) mnew = META_SET_GHOST(m, 1); else dead = 1;   // kept as "echo ghost" / gone
@@ -103,7 +103,7 @@ k_halo_unpack(const Consts c, int count, int offset, int side, int z_lo, int z_h
     int xi;
     if (META_GHOST(m)) xi = HALO_PACK(HALO_GHOST + side, k);
     else {  // a migrant, now owned here; echo it back if it sits in my boundary layer facing the sender
-        const int cz = cell_coord(p.z, c.grid_size, c.nz);
+        const int cz = cell_coord(p.z, c.grid_size, c.nz_glob);
         const int edge = side == 0 ? z_lo : z_hi - 1;
         xi = cz == edge ? HALO_PACK(HALO_ECHO_SEND + side, k) : 0;
     }

@@ -33,7 +33,8 @@ void l_hash_count(State &s) {
 
 void l_scan(State &s) {
     const int G = s.c.G + (s.slab_active ? 1 : 0);   // + graveyard cell
-    const int nb = s.scan_blocks;
+    int nb = cdiv(G, SCAN_TILE);                      // <= s.scan_blocks (sized for the global grid)
+    if (nb < SPH_STAT_SLOTS / SCAN_TPB) nb = SPH_STAT_SLOTS / SCAN_TPB;   // k_scan_final also clears the statistics slots
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial,
                        s.cell_start, s.c.n, s.scal, 1 - s.c.stat_bank);
