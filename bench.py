@@ -56,6 +56,23 @@ def c2_scene(method="wcsph", scale_z=1):
     }
 
 
+def c4_scene(method="wcsph"):
+    """100 x 250 x 160 = 4,000,000 particles; the block spans the full z extent, so z-slabs stay
+    balanced while the dam breaks along x.  One fixed scene: sharding it over N GPUs is strong scaling."""
+    return {
+        "Configuration": {
+            "domainStart": [0.0, 0.0, 0.0], "domainEnd": [6.0, 6.0, 3.36], "addDomainBox": False,
+            "particleRadius": 0.01, "density0": 1000, "simulationMethod": method, "viscosityMethod": "standard",
+            "gravitation": [0.0, -9.81, 0.0], "timeStepSize": 4e-4, "viscosity": 10.0,
+        },
+        "FluidBlocks": [{
+            "objectId": 0, "start": [0.1, 0.1, 0.08], "end": [2.1, 5.1, 3.28], "translation": [0.0, 0.0, 0.0],
+            "scale": [1, 1, 1], "velocity": [0.0, -0.5, 0.0], "density": 1000.0, "color": [50, 100, 200],
+            "entryTime": -1.0,
+        }],
+    }
+
+
 def c1_scene(method="wcsph"):
     from tests import helpers as H
     return H.dam_break_scene(method=method)
@@ -83,7 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4"])
     ap.add_argument("--strict-math", action="store_true", help="IEEE div/sqrt build instead of the fast build")
     ap.add_argument("--no-deterministic", action="store_true")
     ap.add_argument("--force-global", action="store_true")
@@ -125,7 +142,7 @@ def main():
     method = "dfsph" if args.config == "c3" else "wcsph"
     sharded = world > 1 and not args.replicas and method == "wcsph"
     scale_z = world if (sharded and args.scaling == "weak" and args.config == "c2") else 1
-    cfg = c1_scene(method) if args.config == "c1" else c2_scene(method, scale_z=scale_z)
+    cfg = c1_scene(method) if args.config == "c1" else (c4_scene(method) if args.config == "c4" else c2_scene(method, scale_z=scale_z))
     from tests import helpers as H  # scene -> container/solver exactly like run_simulation.py
     slab_opt = None
     n_global = None
@@ -182,7 +199,7 @@ def main():
             container = solver = None
             sharded = False
             scale_z = 1
-            cfg = c2_scene(method) if args.config != "c1" else c1_scene(method)
+            cfg = c1_scene(method) if args.config == "c1" else (c4_scene(method) if args.config == "c4" else c2_scene(method))
     if container is None:
         container, solver = H.build_product(cfg, **opts)
     eng = container.engine
@@ -253,15 +270,16 @@ def main():
     out = {
         "metric": "particle-updates/sec", "value": value, "unit": "particle-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": args.scaling if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": ("strong" if args.config == "c4" else args.scaling) if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": {"c1": "C1 8,000-particle cube dam break", "c2": "C2 1,231,200-particle dam break" + (f" x{scale_z} in z" if scale_z > 1 else ""),
+                         "c4": "C4 4,000,000-particle dam break",
                          "c3": "C3 1,231,200-particle dam break, " + ("DFSPH iterations as measured" if args.measured_iterations else "2+2 fixed DFSPH iterations")}[args.config],
             "method": method, "particles": int(n_total), "grid_cells": int(container.grid_num.prod()),
             "dt": cfg["Configuration"]["timeStepSize"], "math": "strict" if args.strict_math else "fast",
             "deterministic_sort": not args.no_deterministic,
             "parallelism": "single-gpu" if world == 1 else
-                           (f"z-slab x{world}, RCCL halo exchange ({args.scaling} scaling)" if sharded else f"replicas x{world}"),
+                           (f"z-slab x{world}, RCCL halo exchange ({'strong' if args.config == 'c4' else args.scaling} scaling)" if sharded else f"replicas x{world}"),
             "pair_interactions_per_step": int(pairs),
             "pair_interactions_per_s": pairs * args.steps / elapsed,
             "lds_fallback_blocks_last_step": int(stats["lds_fallback_blocks"]),
