@@ -41,7 +41,7 @@ def c2_scene(method="wcsph", scale_z=1):
     """block identical to data/scenes/final_scene0.json:55-59 of the reference.
     scale_z = N (weak scaling over N GPUs): the block and the domain are N times as deep in z, i.e. N x 80 lattice
     planes = N x 1,231,200 particles, so every z-slab holds one C2's worth of work."""
-    dt = 4e-4 if method == "wcsph" else 6e-4
+    dt = 6e-4 if method == "dfsph" else 4e-4
     return {
         "Configuration": {
             "domainStart": [0.0, 0.0, 0.0], "domainEnd": [8.5, 8.0, 0.4 + 1.6 * scale_z], "addDomainBox": False,
@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4"])
+    ap.add_argument("--method", default=None, choices=["wcsph", "dfsph", "pcisph"],
+                    help="override the solver of the chosen scene (pcisph: no configuration of its own in BASELINE.json)")
     ap.add_argument("--strict-math", action="store_true", help="IEEE div/sqrt build instead of the fast build")
     ap.add_argument("--no-deterministic", action="store_true")
     ap.add_argument("--force-global", action="store_true")
@@ -139,7 +141,7 @@ def main():
         dist.all_reduce(t, op=op)
         return t.item()
 
-    method = "dfsph" if args.config == "c3" else "wcsph"
+    method = args.method or ("dfsph" if args.config == "c3" else "wcsph")
     sharded = world > 1 and not args.replicas and method == "wcsph"
     scale_z = world if (sharded and args.scaling == "weak" and args.config == "c2") else 1
     cfg = c1_scene(method) if args.config == "c1" else (c4_scene(method) if args.config == "c4" else c2_scene(method, scale_z=scale_z))
