@@ -1,0 +1,17 @@
+import sys, time
+sys.path.insert(0, '/root/repo')
+import bench
+from tests import helpers as H
+cfg = bench.c2_scene()
+container, solver = H.build_product(cfg, fast_math=1)
+solver.prepare()
+eng = container.engine
+for _ in range(20): solver.step()
+eng.synchronize()
+t0 = time.perf_counter()
+for _ in range(300): solver.step()
+eng.synchronize()
+t1 = time.perf_counter()
+eng.step_async(300); eng.synchronize()
+t2 = time.perf_counter()
+print("solver.step(): %.3f ms/step; engine.step_async: %.3f ms/step" % ((t1 - t0) / 300 * 1e3, (t2 - t1) / 300 * 1e3))
