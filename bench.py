@@ -3,23 +3,31 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one solver.step() of the reference (neighbour search + density/EOS + non-pressure
-forces + pressure forces + symplectic integration + boundary) over the whole particle set.
-N=1 workload = BASELINE.json configs[1] (SURVEY 8d "C2"): 1,231,200-particle dam break, WCSPH,
-f32, synthetic lattice (no RNG).  Prints ONE JSON line on rank 0.
+A "step" is one solver.step() of the reference (neighbour search + density/EOS + non-pressure forces + pressure
+forces + symplectic integration + boundary) over the whole particle set.  N=1 workload = BASELINE.json configs[1]
+(SURVEY 8d "C2"): 1,231,200-particle dam break, WCSPH, f32, synthetic lattice (no RNG).  Rank 0 prints ONE JSON line.
 
-Timing: W untimed warm-up steps, then exactly K steps enqueued on the library's HIP stream between
-two (barrier + device synchronise) fences; max over ranks.  `value` = fluid particles advanced per
-second by the whole job with all state resident in HBM (the scene upload is outside the region).
-Roofline leg: the dominant kernel (picked by a short all-kernel HIP-event pre-pass) is timed with
-HIP events on the library's own stream *inside* the timed region; achieved GB/s = algorithmic
-bytes per launch / average launch duration, against 8 TB/s HBM3E peak.
-CPU baseline leg (rank 0, N=1 only): the oracle (this repo's C restatement of the reference
-algorithm, OpenMP) timed on the host cores on a bounded sample of the same workload.
+N > 1: one process per GPU, no torch anywhere.  `python bench.py --gpus N` spawns its own N ranks; under a launcher
+that already did (torch.distributed.run exports RANK / LOCAL_RANK / WORLD_SIZE) every process is one rank.  The RCCL
+unique id travels through a file in /dev/shm, barriers and the max / sum reductions are RCCL all-reduces behind the
+C-ABI (sph_comm_barrier / sph_comm_allreduce).  WCSPH scenes are z-slab sharded (RCCL halo exchange); the other
+solvers run replicas and say so.  SPH_COMM_TRANSPORT=shm lets several ranks share one GPU (test rig).
+
+Timing: W untimed warm-up steps, then 3 repetitions of exactly K steps, each enqueued on the library's HIP stream
+between two (device synchronise + barrier) fences, max over ranks; `ms_per_step` is the MEDIAN repetition
+(`repeat_ms_per_step` lists all three).  `value` = fluid particles advanced per second by the whole job with all state
+resident in HBM (scene upload outside the region).  The same scene is then advanced to step 2500 and timed again
+(`in_motion`): the rest lattice holds 29 neighbours per particle, the collapsing column ~39.
+Roofline leg: the dominant kernel (picked by a short all-kernel HIP-event pre-pass) is timed with HIP events on the
+library's own stream inside the timed region; achieved GB/s = algorithmic bytes per launch /
+average launch duration, against 8 TB/s HBM3E peak.
+CPU baseline leg (rank 0, N=1 only): the oracle (this repo's C restatement of the reference algorithm, OpenMP) on
+the host cores, a bounded sample of the same workload, swept over thread counts; the best is reported.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,67 +43,10 @@ ALG_BYTES = {
     "dfsph_density_alpha": 24, "dfsph_rho_adv": 36, "dfsph_correct": 48,
     "pcisph_rho_star": 40, "pcisph_pressure_accel": 64,
 }
+N_KERNEL_IDS = 19
 
 
-def c2_scene(method="wcsph", scale_z=1):
-    """block identical to data/scenes/final_scene0.json:55-59 of the reference.
-    scale_z = N (weak scaling over N GPUs): the block and the domain are N times as deep in z, i.e. N x 80 lattice
-    planes = N x 1,231,200 particles, so every z-slab holds one C2's worth of work."""
-    dt = 6e-4 if method == "dfsph" else 4e-4
-    return {
-        "Configuration": {
-            "domainStart": [0.0, 0.0, 0.0], "domainEnd": [8.5, 8.0, 0.4 + 1.6 * scale_z], "addDomainBox": False,
-            "particleRadius": 0.01, "density0": 1000, "simulationMethod": method, "viscosityMethod": "standard",
-            "gravitation": [0.0, -9.81, 0.0], "timeStepSize": dt, "viscosity": 10.0,
-        },
-        "FluidBlocks": [{
-            "objectId": 0, "start": [0.09, 0.2, 0.2], "end": [1.7, 4.0, 0.2 + 1.6 * scale_z],
-            "translation": [0.0, 0.0, 0.0], "scale": [1, 1, 1], "velocity": [0.0, -0.5, 0.0], "density": 1000.0,
-            "color": [50, 100, 200], "entryTime": -1.0,
-        }],
-    }
-
-
-def c4_scene(method="wcsph"):
-    """100 x 250 x 160 = 4,000,000 particles; the block spans the full z extent, so z-slabs stay
-    balanced while the dam breaks along x.  One fixed scene: sharding it over N GPUs is strong scaling."""
-    return {
-        "Configuration": {
-            "domainStart": [0.0, 0.0, 0.0], "domainEnd": [6.0, 6.0, 3.36], "addDomainBox": False,
-            "particleRadius": 0.01, "density0": 1000, "simulationMethod": method, "viscosityMethod": "standard",
-            "gravitation": [0.0, -9.81, 0.0], "timeStepSize": 4e-4, "viscosity": 10.0,
-        },
-        "FluidBlocks": [{
-            "objectId": 0, "start": [0.1, 0.1, 0.08], "end": [2.1, 5.1, 3.28], "translation": [0.0, 0.0, 0.0],
-            "scale": [1, 1, 1], "velocity": [0.0, -0.5, 0.0], "density": 1000.0, "color": [50, 100, 200],
-            "entryTime": -1.0,
-        }],
-    }
-
-
-def c1_scene(method="wcsph"):
-    from tests import helpers as H
-    return H.dam_break_scene(method=method)
-
-
-def cpu_baseline(cfg, steps, threads):
-    """Oracle (kind "port") timed on the host.  Test infrastructure used as the *measured baseline
-    only*; nothing of it is on the product path."""
-    os.environ["OMP_NUM_THREADS"] = str(threads)
-    from tests import helpers as H
-    sim = H.build_oracle(cfg, fixed_iterations=2 if cfg["Configuration"]["simulationMethod"] != "wcsph" else 0)
-    sim.prepare()
-    sim.step(1)  # warm-up (page faults, thread pool)
-    t0 = time.perf_counter()
-    sim.step(steps)
-    dt = time.perf_counter() - t0
-    n = sim.fluid_particle_num
-    pairs = sim.last_pairs
-    sim.close()
-    return n * steps / dt, pairs / (dt / steps), dt
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -107,172 +58,264 @@ def main():
     ap.add_argument("--no-deterministic", action="store_true")
     ap.add_argument("--force-global", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=3, help="repetitions of the K timed steps (median reported)")
     ap.add_argument("--measured-iterations", action="store_true",
                     help="c3: the solver's own convergence tests (DFSPH.py:150/:239) instead of 2+2 fixed iterations; "
                          "iteration counts of the last step are reported in config")
     ap.add_argument("--presteps", type=int, default=0,
-                    help="untimed steps before the warm-up (tuning aid: time the passes on a dam break in motion instead of "
-                         "the rest lattice; the headline number is always quoted with 0)")
+                    help="untimed steps before the warm-up (the headline `value` is always quoted with 0)")
+    ap.add_argument("--motion-step", type=int, default=2500,
+                    help="after the headline measurement advance the scene to this step and time again (`in_motion`); 0: skip")
     ap.add_argument("--all-kernels", action="store_true", help="also print the per-kernel HIP-event table (stderr)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = every z-slab gets one C2 block (N x 1.23 M particles); strong = the 1.23 M scene is split")
-    ap.add_argument("--replicas", action="store_true", help="N>1: independent copies instead of z-slab sharding (debug)")
-    args = ap.parse_args()
+    ap.add_argument("--replicas", action="store_true", help="N>1: independent copies instead of z-slab sharding")
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    use_gloo = bool(os.environ.get("SPH_BENCH_GLOO"))  # test rig: several ranks on ONE GPU (with SPH_COMM_TRANSPORT=shm)
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if use_gloo:
-            local_rank = 0
-            dist.init_process_group(backend="gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    def _reduce(x, op, dtype):
-        import torch
-        t = torch.tensor([x], device="cpu" if use_gloo else "cuda", dtype=dtype)
-        dist.all_reduce(t, op=op)
-        return t.item()
+# ----------------------------------------------------------------------------------------------- launcher
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, relay rank 0's line."""
+    rdv = f"/dev/shm/sph_bench_{os.getpid()}_{int(time.time() * 1e6)}.id"
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SPH_BENCH_RDV=rdv)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    try:
+        os.unlink(rdv)
+    except OSError:
+        pass
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        print(f"[bench] rank exit codes {rcs}", file=sys.stderr)
+        sys.exit(1)
 
+
+def rendezvous_path():
+    p = os.environ.get("SPH_BENCH_RDV")
+    if p:
+        return p
+    # ranks started by one launcher share their parent; its start time makes the name unique across runs
+    ppid = os.getppid()
+    try:
+        start = open(f"/proc/{ppid}/stat").read().rsplit(")", 1)[1].split()[19]
+    except Exception:  # noqa: BLE001
+        start = "0"
+    return f"/dev/shm/sph_bench_{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}.id"
+
+
+def exchange_unique_id(lib, rank):
+    import ctypes
+    path = rendezvous_path()
+    if rank == 0:
+        buf = ctypes.create_string_buffer(128)
+        if lib.sph_comm_unique_id(buf) != 0:
+            raise RuntimeError("sph_comm_unique_id failed")
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(buf.raw)
+        os.rename(tmp, path)
+        return buf.raw
+    t0 = time.time()
+    while True:
+        try:
+            data = open(path, "rb").read()
+            if len(data) == 128:
+                return data
+        except OSError:
+            pass
+        if time.time() - t0 > 120:
+            raise RuntimeError(f"rank {rank}: no unique id at {path} after 120 s")
+        time.sleep(0.01)
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(cfg, steps):
+    """Oracle (kind "port") timed on the host.  Test infrastructure used as the *measured baseline only*; nothing of
+    it is on the product path.  Thread counts are swept (the OpenMP loops stop scaling long before 256 threads)."""
+    import ctypes
+    from tests import helpers as H
+    ncpu = os.cpu_count() or 1
+    sim = H.build_oracle(cfg, fixed_iterations=2 if cfg["Configuration"]["simulationMethod"] != "wcsph" else 0)
+    omp = ctypes.CDLL("libgomp.so.1")
+    sim.prepare()
+    sim.step(1)  # warm-up (page faults, thread pool)
+    sweep = sorted({t for t in (8, 16, 32, 64, ncpu // 2, ncpu) if 1 <= t <= ncpu})
+    best = None
+    table = {}
+    for t in sweep:
+        omp.omp_set_num_threads(int(t))
+        t0 = time.perf_counter()
+        sim.step(steps)
+        dt = time.perf_counter() - t0
+        table[t] = sim.fluid_particle_num * steps / dt
+        if best is None or table[t] > table[best]:
+            best = t
+        best_dt = dt if best == t else best_dt
+    n, pairs = sim.fluid_particle_num, sim.last_pairs
+    sim.close()
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=table[best], cores=best, secs=best_dt, pairs_per_s=pairs * steps / best_dt, sweep=table, model=model, ncpu=ncpu)
+
+
+# ----------------------------------------------------------------------------------------------- one rank
+def run_rank(args, rank, world, local_rank):
+    from sph_project_amd import _lib as L, product as P
+    lib = L.load()
     method = args.method or ("dfsph" if args.config == "c3" else "wcsph")
     sharded = world > 1 and not args.replicas and method == "wcsph"
     scale_z = world if (sharded and args.scaling == "weak" and args.config == "c2") else 1
-    cfg = c1_scene(method) if args.config == "c1" else (c4_scene(method) if args.config == "c4" else c2_scene(method, scale_z=scale_z))
-    from tests import helpers as H  # scene -> container/solver exactly like run_simulation.py
-    slab_opt = None
+    cfg = (P.dam_break_scene(method=method) if args.config == "c1" else
+           P.c4_scene(method) if args.config == "c4" else P.c2_scene(method, scale_z=scale_z))
+    ndev = lib.sph_device_count()
+    if ndev < 1:
+        raise RuntimeError("no HIP device visible (the product path has no CPU fallback)")
+    device = local_rank % ndev if world > 1 else -1   # several ranks per GPU only happen with SPH_COMM_TRANSPORT=shm
+    slab_opt = comm_opt = None
     n_global = None
-    if sharded:
-        import numpy as np
-        from sph_project_amd import _lib as L, slab
-        import ctypes
-        uid = [None]
-        if rank == 0:
-            buf = ctypes.create_string_buffer(128)
-            assert L.load().sph_comm_unique_id(buf) == 0
-            uid[0] = buf.raw
-        dist.broadcast_object_list(uid, src=0)
-        _, geo, batches = H.scene_particles(cfg)
-        z = np.concatenate([b["pos"][:, 2] for b in batches])
-        nz = int(geo.grid_num[2])
-        cuts = slab.plan_slabs(np.bincount(slab.cell_layer(z, geo.dh, nz), minlength=nz), world)
-        slab_opt = dict(rank=rank, nranks=world, unique_id=uid[0], cuts=cuts)
-        n_global = int(sum((b["material"] == 1).sum() for b in batches))
-        del batches, z
-    if world == 1 and os.environ.get("SPH_BENCH_FORCE_SLAB") and method == "wcsph":
-        # tuning aid: ONE rank in slab mode (classify / tables / ghost-aware kernels, no neighbour to talk to)
-        import numpy as np
-        _, geo, _b = H.scene_particles(cfg)
-        os.environ.setdefault("SPH_COMM_TRANSPORT", "shm")   # SPH_COMM_TRANSPORT=rccl: a one-rank RCCL communicator instead
-        uid = b"\0" * 128
-        if os.environ["SPH_COMM_TRANSPORT"] != "shm":
+    force_slab = world == 1 and os.environ.get("SPH_BENCH_FORCE_SLAB") and method == "wcsph"
+    if world > 1 or force_slab:
+        uid = exchange_unique_id(lib, rank) if world > 1 else None
+        if force_slab:   # tuning aid / RCCL self-test: ONE rank in slab mode (no neighbour to talk to)
+            os.environ.setdefault("SPH_COMM_TRANSPORT", "shm")
             import ctypes
-            from sph_project_amd import _lib as L
             buf = ctypes.create_string_buffer(128)
-            assert L.load().sph_comm_unique_id(buf) == 0
+            assert lib.sph_comm_unique_id(buf) == 0
             uid = buf.raw
-        slab_opt = dict(rank=0, nranks=1, unique_id=uid, cuts=[0, int(geo.grid_num[2])])
-        n_global = int(sum((b["material"] == 1).sum() for b in _b))
-        del _b
+        if sharded or force_slab:
+            import numpy as np
+            from sph_project_amd import slab
+            _, geo, batches = P.scene_particles(cfg)
+            z = np.concatenate([b["pos"][:, 2] for b in batches])
+            nz = int(geo.grid_num[2])
+            cuts = slab.plan_slabs(np.bincount(slab.cell_layer(z, geo.dh, nz), minlength=nz), world)
+            slab_opt = dict(rank=rank, nranks=world, unique_id=uid, cuts=cuts)
+            n_global = int(sum((b["material"] == 1).sum() for b in batches))
+            del batches, z
+        else:
+            comm_opt = dict(rank=rank, nranks=world, unique_id=uid)
     opts = dict(fast_math=0 if args.strict_math else 1, deterministic=0 if args.no_deterministic else 1,
-                force_global=int(os.environ.get('SPH_DEBUG_MODE', int(args.force_global))), device=local_rank if world > 1 else -1)
+                force_global=int(os.environ.get("SPH_DEBUG_MODE", int(args.force_global))), device=device)
     if method != "wcsph" and not args.measured_iterations:
         opts["fixed_iterations"] = 2
-    container = solver = None
-    if slab_opt and world == 1:
-        container, solver = H.build_product(cfg, slab=slab_opt, **opts)
-    elif slab_opt:
-        # every rank must agree on the mode: if the communicator cannot be set up anywhere, all fall back to replicas
-        import torch
-        err = ""
-        try:
-            container, solver = H.build_product(cfg, slab=slab_opt, **opts)
-        except Exception as exc:  # noqa: BLE001
-            err = f"{type(exc).__name__}: {exc}"
-        if _reduce(0 if err else 1, dist.ReduceOp.MIN, torch.int64) == 0:
-            if rank == 0 or err:
-                print(f"[bench] rank {rank}: slab sharding unavailable ({err or 'failed on another rank'}); running replicas", file=sys.stderr)
-            container = solver = None
-            sharded = False
-            scale_z = 1
-            cfg = c1_scene(method) if args.config == "c1" else (c4_scene(method) if args.config == "c4" else c2_scene(method))
-    if container is None:
-        container, solver = H.build_product(cfg, **opts)
+    if slab_opt:
+        opts["slab"] = slab_opt      # a failure here is fatal on every rank: no silent fall-back to replicas
+    if comm_opt:
+        opts["comm"] = comm_opt
+    container, solver = P.build_product(cfg, **opts)
     eng = container.engine
+    if os.environ.get("SPH_BENCH_SELFTEST") and (slab_opt or comm_opt):
+        eng.comm_selftest(1 << 16)
     solver.prepare()
     n_fluid = container.fluid_particle_num[None]
-    names = [eng.lib.sph_kernel_name(k).decode() for k in range(19)]
+    names = [lib.sph_kernel_name(k).decode() for k in range(N_KERNEL_IDS)]
+    multi = world > 1
 
     def fence():
         eng.synchronize()
-        if dist is not None:
-            import torch
-            dist.barrier()
-            if not use_gloo:
-                torch.cuda.synchronize()
+        if multi:
+            eng.comm_barrier()
+
+    def allmax(x):
+        return eng.comm_allreduce([x], "max")[0] if multi else x
+
+    def allsum(x):
+        return eng.comm_allreduce([x], "sum")[0] if multi else x
 
     run = eng.step if args.measured_iterations else eng.step_async   # convergence tests need the (batched) flag read-back
+    steps_done = 0
     if args.presteps:
-        run(args.presteps)
-    run(args.warmup)
+        run(args.presteps); steps_done += args.presteps
+    run(args.warmup); steps_done += args.warmup
     fence()
 
     # pre-pass: which kernel dominates?  (all-kernel events perturb the stream slightly -> untimed)
     eng.profile_enable(-1, True)
     eng.profile_reset()
-    run(5)
+    run(5); steps_done += 5
     eng.synchronize()
-    table = {names[k]: eng.profile_read(k) for k in range(19)}
+    table = {names[k]: eng.profile_read(k) for k in range(N_KERNEL_IDS)}
     table = {k: v for k, v in table.items() if v[0] > 0}
     dom = max((k for k in table if k in ALG_BYTES), key=lambda k: table[k][1])
     if args.all_kernels and rank == 0:
         for k, (n, ms) in sorted(table.items(), key=lambda kv: -kv[1][1]):
             print(f"  {k:24s} launches {n:5d}  avg {1e3 * ms / n:9.1f} us", file=sys.stderr)
     eng.profile_enable(-1, False)
-    eng.profile_enable(names.index(dom), not os.environ.get('SPH_BENCH_NO_EVENTS'))
+
+    def timed(reps):
+        """reps x (fence, K steps, fence); returns the per-repetition max-over-ranks seconds"""
+        out = []
+        for _ in range(reps):
+            fence()
+            t0 = time.perf_counter()
+            run(args.steps)
+            fence()
+            out.append(allmax(time.perf_counter() - t0))
+        return out
+
+    def median(v):
+        s = sorted(v)
+        return s[len(s) // 2]
+
+    eng.profile_enable(names.index(dom), not os.environ.get("SPH_BENCH_NO_EVENTS"))
     eng.profile_reset()
-
-    fence()
-    t0 = time.perf_counter()
-    run(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        elapsed = float(_reduce(elapsed, dist.ReduceOp.MAX, torch.float64))
-
+    reps = timed(args.repeats); steps_done += args.repeats * args.steps
+    elapsed = median(reps)
     launches, ms = eng.profile_read(names.index(dom))
+    eng.profile_enable(-1, False)
     stats = solver.stats()
-    pairs = stats["pair_interactions"]
-    if sharded:
+    pairs, evals = stats["pair_interactions"], stats["pair_evaluations"]
+    if sharded or force_slab:
         n_total = n_global  # every fluid particle is owned by exactly one rank
-        import torch
-        pairs = int(_reduce(pairs, dist.ReduceOp.SUM, torch.int64))
+        pairs, evals = int(allsum(pairs)), int(allsum(evals))
         n_fluid = n_global // world  # per-launch share for the roofline leg
     else:
         n_total = n_fluid * world  # replicas: every rank advances its own copy
-        pairs = pairs * world
+        pairs, evals = pairs * world, evals * world
     value = n_total * args.steps / elapsed
     avg_s = (ms / max(launches, 1)) * 1e-3
     achieved = ALG_BYTES[dom] * n_fluid / avg_s / 1e9 if launches else None
+
+    in_motion = None
+    if args.motion_step and not args.presteps and args.config in ("c2", "c4") and method == "wcsph" and steps_done < args.motion_step:
+        run(args.motion_step - steps_done); steps_done = args.motion_step
+        m_el = median(timed(args.repeats))
+        st2 = solver.stats()
+        p2 = int(allsum(st2["pair_interactions"])) if (sharded or force_slab) else st2["pair_interactions"] * world
+        e2 = int(allsum(st2["pair_evaluations"])) if (sharded or force_slab) else st2["pair_evaluations"] * world
+        in_motion = {"from_step": args.motion_step, "ms_per_step": 1e3 * m_el / args.steps,
+                     "value": n_total * args.steps / m_el, "pair_interactions_per_step": p2,
+                     "pair_interactions_per_s": p2 * args.steps / m_el, "pair_evaluations_per_s": e2 * args.steps / m_el,
+                     "neighbours_per_particle": e2 / max(n_total, 1) / 2.0,
+                     "lds_fallback_blocks_last_step": int(st2["lds_fallback_blocks"])}
+
     traffic = None
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tf):
         try:
             traffic = json.load(open(tf)).get(args.config, {}).get(dom)
-        except Exception:
+        except Exception:  # noqa: BLE001
             traffic = None
 
+    scaling = ("strong" if args.config == "c4" else args.scaling) if sharded else "weak"
+    transport = os.environ.get("SPH_COMM_TRANSPORT", "rccl")
     out = {
         "metric": "particle-updates/sec", "value": value, "unit": "particle-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": ("strong" if args.config == "c4" else args.scaling) if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "repeat_ms_per_step": [1e3 * r / args.steps for r in reps],
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": {"c1": "C1 8,000-particle cube dam break", "c2": "C2 1,231,200-particle dam break" + (f" x{scale_z} in z" if scale_z > 1 else ""),
                          "c4": "C4 4,000,000-particle dam break",
@@ -281,37 +324,61 @@ def main():
             "dt": cfg["Configuration"]["timeStepSize"], "math": "strict" if args.strict_math else "fast",
             "deterministic_sort": not args.no_deterministic,
             "parallelism": "single-gpu" if world == 1 else
-                           (f"z-slab x{world}, RCCL halo exchange ({'strong' if args.config == 'c4' else args.scaling} scaling)" if sharded else f"replicas x{world}"),
+                           (f"z-slab x{world}, {'RCCL' if transport != 'shm' else 'shared-memory (test rig)'} halo exchange ({scaling} scaling)" if sharded else f"replicas x{world}"),
+            "state": "steps %d..%d from the initial lattice" % (args.presteps + args.warmup + 5, args.presteps + args.warmup + 5 + args.repeats * args.steps),
             "pair_interactions_per_step": int(pairs),
-            "pair_interactions_per_s": pairs * args.steps / elapsed,
+            "pair_interactions_per_s": pairs * args.steps / elapsed,      # every accepted pair once per REFERENCE pass
+            "pair_evaluations_per_step": int(evals),
+            "pair_evaluations_per_s": evals * args.steps / elapsed,       # as evaluated: once per neighbour walk of this library
+            "neighbours_per_particle": evals / max(n_total, 1) / 2.0 if method == "wcsph" else None,   # density walk + force walk
             "lds_fallback_blocks_last_step": int(stats["lds_fallback_blocks"]),
             **({"solver_iterations_last_step": {"density": int(stats["iter_density"]), "divergence": int(stats["iter_divergence"])}} if method == "dfsph" else {}),
             "device": eng.device_info()["name"],
         },
+        "in_motion": in_motion,
         "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
             "launches": int(launches), "avg_launch_us": 1e6 * avg_s,
             "alg_bytes_per_launch": ALG_BYTES[dom] * n_fluid,
             "step_achieved": (204 * n_fluid + 12 * int(container.grid_num.prod())) / (elapsed / args.steps) / 1e9,
-            "note": "neighbour passes are VALU/LDS-bound, not HBM-bound (DESIGN.md)",
+            "note": "neighbour passes are VALU/LDS-issue-bound under the chip's power-limited clock, not HBM-bound (DESIGN.md 5)",
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = os.cpu_count() or 1
-        v, pairs_s, secs = cpu_baseline(cfg, args.cpu_steps, threads)
+        cb = cpu_baseline(cfg, args.cpu_steps)
         out["cpu_baseline"] = {
-            "value": v, "unit": "particle-updates/s", "cores": threads, "kind": "port",
-            "sample": f"{args.cpu_steps} steps of the same workload ({secs:.1f} s), oracle/sph_ref.c "
-                      f"(this repo's C restatement of the reference algorithm, OpenMP), not Taichi",
-            "pair_interactions_per_s": pairs_s,
+            "value": cb["value"], "unit": "particle-updates/s", "cores": cb["cores"], "kind": "port",
+            "sample": f"{args.cpu_steps} steps of the same workload per thread count ({cb['secs']:.1f} s at the best one), "
+                      f"oracle/sph_ref.c (this repo's C restatement of the reference algorithm, OpenMP), not Taichi",
+            "pair_interactions_per_s": cb["pairs_per_s"], "cpu": cb["model"], "hardware_threads": cb["ncpu"],
+            "threads_sweep": {str(k): v for k, v in cb["sweep"].items()},
         }
     elif rank == 0:
         out["cpu_baseline"] = None
+    if multi:
+        eng.comm_barrier()
+        if rank == 0 and not os.environ.get("SPH_BENCH_RDV"):
+            try:
+                os.unlink(rendezvous_path())
+            except OSError:
+                pass
     if rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return spawn_ranks(args.gpus)
+    world = int(env_world) if env_world is not None else 1
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    run_rank(args, int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0")))
 
 
 if __name__ == "__main__":

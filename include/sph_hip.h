@@ -120,6 +120,9 @@ typedef struct {
     float   err_divergence, err_density, err_pcisph, err_cg;
     int64_t lds_fallback_blocks; /* neighbour-pass workgroups that overflowed the LDS tile (last step) */
     double  total_time;          /* container.total_time, base_solver.py:694 */
+    int64_t pair_evaluations;    /* the same accepted pairs counted once per neighbour walk the library actually makes
+                                    (a fused kernel that does the work of k reference passes adds k to
+                                    pair_interactions and 1 here), last step */
 } SphStats;
 
 /* Kernel ids for the HIP-event profiler (sph_profile_*). */
@@ -163,6 +166,16 @@ int sph_step(SphHandle *h, int nsteps);
    per-iteration host read-back is needed (wcsph, or fixed_iterations > 0) */
 int sph_step_async(SphHandle *h, int nsteps);
 int sph_synchronize(SphHandle *h);
+/* One step in two halves, for hosts that act in the middle of _step() exactly where the reference does:
+   sph_step_begin runs _step() up to (not including) `self.rigid_solver.step()` (WCSPH.py:39, DFSPH.py:305,
+   PCISPH.py:179); the host then integrates rigid bodies (sph_get_rigid_wrench / sph_set_rigid_pose =
+   bullet_solver.py:144-167) and appends objects whose entryTime has come (sph_append_particles =
+   base_container.py:212-341); sph_step_end runs the rest: renew_rigid_particle_state + enforce_domain_boundary
+   (+ for DFSPH the neighbour search, density, alpha and divergence solve, DFSPH.py:311-319) and step()'s tail
+   (base_solver.py:694-696, including compute_rigid_particle_volume on the grid of the last sort).
+   sph_step(h, 1) == sph_step_begin(h); sph_step_end(h). */
+int sph_step_begin(SphHandle *h);
+int sph_step_end(SphHandle *h);
 /* one reference kernel group at a time (tests) */
 int sph_run_phase(SphHandle *h, int phase);
 
@@ -186,13 +199,25 @@ const char *sph_kernel_name(int kernel_id);
 int sph_device_info(SphHandle *h, char *name256, int *cu_count, int64_t *hbm_bytes);
 
 /* --- multi-GPU: z-slab sharding, one process per GPU, RCCL over xGMI ------------------- */
+/* number of HIP devices this process sees (launchers map local rank -> device without any other runtime) */
+int sph_device_count(void);
 /* 128-byte RCCL unique id, created on rank 0 and distributed by the host launcher */
 int sph_comm_unique_id(void *out128);
-/* attach this handle to a slab communicator.  The handle then owns the cell layers
-   [z_lo, z_hi) of the global grid plus one ghost layer on each interior side. */
+/* attach this handle to a communicator of `nranks` processes (RCCL ncclCommInitRank; SPH_COMM_TRANSPORT=shm:
+   POSIX shared memory, several ranks may then share one GPU -- test rig) */
 int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id128);
+/* turn the handle into one z-slab: it owns the cell layers [z_lo, z_hi) of the global grid plus one ghost
+   layer on each interior side; before any particle is appended */
 int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi);
 int sph_comm_get_slab(SphHandle *h, int *z_lo, int *z_hi, int *n_owned, int *n_ghost);
+/* host-visible collectives over the communicator (what a launcher otherwise needs MPI / torch.distributed for):
+   in-place all-reduce of <= 16 doubles, op 0 sum / 1 max / 2 min (ncclAllReduce); barrier = drain the stream,
+   then all-reduce; both synchronous.  The solver residuals of a sharded DFSPH / PCISPH step use the same path. */
+int sph_comm_allreduce(SphHandle *h, double *inout, int count, int op);
+int sph_comm_barrier(SphHandle *h);
+/* transport self-test: ring shift of n floats (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd; a self pair when
+   the communicator has one rank), every word checked, plus an all-reduce check */
+int sph_comm_selftest(SphHandle *h, int n);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,20 @@ sys.path.insert(1, ROOT)
 from tests.helpers import dam_break_scene  # noqa: E402  (scene dicts shared with the tests)
 
 OUT = os.path.join(ROOT, "tests", "golden")
+LATE_COLOR = [100000, 7, 7]   # sentinel colour of particles that enter late (replaced by persistent ids once they are in)
+
+
+def late_scene(method, dt):
+    """Block 0 present from the start, block 1 enters right on top of it (one lattice spacing away, so the two interact
+    at once) when total_time reaches 2.5 dt (= during the 4th step).  Its extents are not multiples of the spacing:
+    the reference budgets particle_max_num with the untranslated corners (base_container.py:89) and np.arange's
+    end-point rounding must not make the translated cube any larger."""
+    cfg = dam_break_scene(method=method, end=(0.12, 0.1, 0.12), dt=dt, velocity=(0.0, -0.5, 0.0))
+    cfg["FluidBlocks"].append({
+        "objectId": 1, "start": [0.0, 0.0, 0.0], "end": [0.07, 0.07, 0.09], "translation": [0.12, 0.2, 0.11],
+        "scale": [1, 1, 1], "velocity": [0.0, -1.0, 0.0], "density": 1000.0, "color": LATE_COLOR, "entryTime": 2.5 * dt,
+    })
+    return cfg
 
 SCENES = {
     # name: (scene dict, jitter amplitude, seed, checkpoints (steps))
@@ -60,6 +74,22 @@ SCENES = {
                                   end=(0.14, 0.16, 0.14), translation=(0.0, 0.0, 0.0), add_domain_box=True, dt=6e-4,
                                   viscosity_b=0.3),
                   0.003, 6, [1, 2, 3]),
+    # implicit viscosity with boundary particles: the rigid-neighbour terms of D_ii and b (base_solver.py:326-349) --
+    # the branch BASELINE config 5 (buckling sheet inside a sampled domain box) runs
+    "dfsph_implicit_box": (dam_break_scene(method="dfsph", domain_end=(0.32, 0.32, 0.32), start=(0.06, 0.06, 0.06),
+                                           end=(0.14, 0.14, 0.14), translation=(0.0, 0.0, 0.0), add_domain_box=True, dt=6e-4,
+                                           viscosity=50.0, viscosity_b=20.0, viscosity_method="implicit",
+                                           velocity=(0.2, -0.5, 0.1)), 0.003, 31, [1, 2]),
+    # implicit viscosity + emitter hack (gravitationUpper): frozen "rigid" fluid above the threshold enters D_ii / b as a
+    # boundary and is released step by step (base_solver.py:660-677)
+    "dfsph_implicit_emitter": (dam_break_scene(method="dfsph", end=(0.1, 0.2, 0.1), translation=(0.1, 0.2, 0.1), dt=6e-4,
+                                               viscosity=50.0, viscosity_method="implicit", velocity=(0.0, -2.5, 0.0),
+                                               gravitationUpper=0.31), 0.0, 0, [1, 6, 12]),
+    # late entry (base_container.py:218-221): a second block whose entryTime falls into the 4th step; inserted by
+    # _step() itself (WCSPH.py:41, DFSPH.py:307, PCISPH.py:181)
+    "wcsph_late": (late_scene("wcsph", 4e-4), 0.0, 0, [2, 4, 6]),
+    "dfsph_late": (late_scene("dfsph", 6e-4), 0.0, 0, [2, 4, 6]),
+    "pcisph_late": (late_scene("pcisph", 4e-4), 0.0, 0, [2, 4, 5]),
 }
 
 
@@ -158,6 +188,19 @@ def run_scene(name):
             with contextlib.redirect_stdout(log):
                 solver.step()
             step += 1
+            # late entrants: still carrying the sentinel colour; their persistent id = insertion index, i.e. the count so
+            # far + their rank in lattice order (x slowest, z fastest: base_container.py:769-777), whatever a sort did since
+            n_now = container.particle_num[None]
+            colors = container.particle_colors._data
+            late = np.nonzero((colors[:n_now, 0] == LATE_COLOR[0]) & (colors[:n_now, 1] == LATE_COLOR[1]))[0]
+            if len(late):
+                pos = container.particle_positions._data[late]
+                order = np.lexsort((pos[:, 2], pos[:, 1], pos[:, 0]))
+                first = n_now - len(late)
+                colors[late[order], 0] = first + np.arange(len(late))
+                colors[late, 1:] = 0
+                out[f"late_step"] = np.int64(step)   # the step during which they were inserted (1-based)
+                out[f"late_first_id"] = np.int64(first)
         for k, v in snapshot(container, solver, method, log).items():
             out[f"s{cp}_" + k] = v
         print(f"  {name}: step {step} done ({time.time() - t0:.0f} s)", flush=True)

@@ -65,7 +65,7 @@ def load():
                      "update_fluid_position", "compute_pressure_acceleration", "enforce_domain_boundary_3D",
                      "prepare_emitter", "renew_rigid_particle_state", "wcsph_compute_pressure",
                      "dfsph_compute_alpha", "dfsph_compute_density_derivative", "dfsph_compute_density_star",
-                     "pcisph_compute_k", "prepare", "step"):
+                     "pcisph_compute_k", "prepare", "step", "step_begin", "step_end"):
             fn = getattr(lib, "sphref_" + name)
             fn.restype = None
             fn.argtypes = [C.c_void_p]
@@ -175,3 +175,9 @@ class RefSim:
     def step(self, n=1):
         for _ in range(n):
             self.lib.sphref_step(self.h)
+
+    def step_begin(self):
+        self.lib.sphref_step_begin(self.h)
+
+    def step_end(self):
+        self.lib.sphref_step_end(self.h)

@@ -1101,51 +1101,52 @@ int sphref_pcisph_refine(SphRef *s) {
 
 /* -------------------------------------------------------- orchestration */
 
-static void step_tail(SphRef *s) {
-    /* rigid_solver.step() (bullet_solver.py:144) is host-side and a no-op without dynamic bodies;
-       container.insert_object() is driven by the host wrapper for late-entry scenes. */
-    sphref_renew_rigid_particle_state(s);
-    sphref_enforce_domain_boundary_3D(s);
+/* The reference calls rigid_solver.step(), container.insert_object() and rigid_solver.insert_rigid_object() in the
+   middle of _step() (WCSPH.py:39-42, DFSPH.py:305-308, PCISPH.py:179-182): both are host-side.  sphref_step_begin()
+   runs _step() up to that point, the host wrapper inserts what is due, sphref_step_end() runs the rest of _step()
+   and step()'s tail.  sphref_step() = begin + end (nothing to insert). */
+void sphref_step_begin(SphRef *s) {
+    s->last_pairs = 0;
+    if (s->prm.method == 0) {            /* WCSPH.py:27 _step */
+        sphref_prepare_neighborhood_search(s);
+        sphref_compute_density(s);
+        sphref_compute_non_pressure_acceleration(s);
+        sphref_update_fluid_velocity(s);
+        sphref_wcsph_compute_pressure(s);
+        sphref_compute_pressure_acceleration(s);
+        sphref_update_fluid_velocity(s);
+        sphref_update_fluid_position(s);
+    } else if (s->prm.method == 1) {     /* DFSPH.py:298 _step */
+        sphref_compute_non_pressure_acceleration(s);
+        sphref_update_fluid_velocity(s);
+        sphref_dfsph_correct_density_error(s);
+        sphref_update_fluid_position(s);
+    } else {                             /* PCISPH.py:165 _step */
+        sphref_prepare_neighborhood_search(s);
+        sphref_compute_density(s);
+        sphref_compute_non_pressure_acceleration(s);
+        pcisph_init_step(s);
+        sphref_pcisph_refine(s);
+        sphref_update_fluid_velocity(s);
+        sphref_compute_pressure_acceleration(s);
+        sphref_update_fluid_velocity(s);
+        sphref_update_fluid_position(s);
+    }
 }
 
-/* WCSPH.py:27 _step */
-static void wcsph_step(SphRef *s) {
-    sphref_prepare_neighborhood_search(s);
-    sphref_compute_density(s);
-    sphref_compute_non_pressure_acceleration(s);
-    sphref_update_fluid_velocity(s);
-    sphref_wcsph_compute_pressure(s);
-    sphref_compute_pressure_acceleration(s);
-    sphref_update_fluid_velocity(s);
-    sphref_update_fluid_position(s);
-    step_tail(s);
-}
-
-/* DFSPH.py:298 _step */
-static void dfsph_step(SphRef *s) {
-    sphref_compute_non_pressure_acceleration(s);
-    sphref_update_fluid_velocity(s);
-    sphref_dfsph_correct_density_error(s);
-    sphref_update_fluid_position(s);
-    step_tail(s);
-    sphref_prepare_neighborhood_search(s);
-    sphref_compute_density(s);
-    sphref_dfsph_compute_alpha(s);
-    sphref_dfsph_correct_divergence_error(s);
-}
-
-/* PCISPH.py:165 _step */
-static void pcisph_step(SphRef *s) {
-    sphref_prepare_neighborhood_search(s);
-    sphref_compute_density(s);
-    sphref_compute_non_pressure_acceleration(s);
-    pcisph_init_step(s);
-    sphref_pcisph_refine(s);
-    sphref_update_fluid_velocity(s);
-    sphref_compute_pressure_acceleration(s);
-    sphref_update_fluid_velocity(s);
-    sphref_update_fluid_position(s);
-    step_tail(s);
+void sphref_step_end(SphRef *s) {
+    sphref_renew_rigid_particle_state(s);     /* WCSPH.py:43, DFSPH.py:309, PCISPH.py:183 */
+    sphref_enforce_domain_boundary_3D(s);     /* WCSPH.py:45, DFSPH.py:311, PCISPH.py:185 */
+    if (s->prm.method == 1) {                 /* DFSPH.py:316-319 */
+        sphref_prepare_neighborhood_search(s);
+        sphref_compute_density(s);
+        sphref_dfsph_compute_alpha(s);
+        sphref_dfsph_correct_divergence_error(s);
+    }
+    s->total_time += (double)s->dt;           /* base_solver.py:694 */
+    /* :696 -- on the grid of the last sort: particles inserted since then are in no cell range, exactly as in the
+       reference (for_all_neighbors reads the prefix sums of the last prepare_neighborhood_search) */
+    sphref_compute_rigid_particle_volume(s);
 }
 
 /* base_solver.py:683 prepare (particles were inserted by the host before this call) */
@@ -1164,10 +1165,6 @@ void sphref_prepare(SphRef *s) {
 
 /* base_solver.py:692 step */
 void sphref_step(SphRef *s) {
-    s->last_pairs = 0;
-    if (s->prm.method == 0) wcsph_step(s);
-    else if (s->prm.method == 1) dfsph_step(s);
-    else pcisph_step(s);
-    s->total_time += (double)s->dt;
-    sphref_compute_rigid_particle_volume(s);
+    sphref_step_begin(s);
+    sphref_step_end(s);
 }

@@ -96,6 +96,8 @@ int  sphref_pcisph_refine(SphRef *s);             /* :110 */
 
 void sphref_prepare(SphRef *s);                   /* base_solver.py:683 (+ DFSPH.py:321, PCISPH.py:188) */
 void sphref_step(SphRef *s);                      /* base_solver.py:692 */
+void sphref_step_begin(SphRef *s);                /* _step() up to rigid_solver.step() / insert_object() */
+void sphref_step_end(SphRef *s);                  /* rest of _step() + step() tail */
 
 #ifdef __cplusplus
 }

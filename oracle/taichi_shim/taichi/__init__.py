@@ -63,6 +63,10 @@ def _loc(v):
     """kernel-local assignment: python / numpy floats become f32 (Taichi default_fp)."""
     if type(v) is float or (isinstance(v, np.floating) and not isinstance(v, np.float32)):
         return np.float32(v)
+    if isinstance(v, Vec) and v._f is not None:
+        # `pos = field[i]`: Taichi copies the element into the local; element writes on the local must not reach the
+        # field (only `field[i][k] = v`, which is not an assignment to a name, writes through)
+        return Vec(v.d, v.d.dtype.type)
     return v
 
 

@@ -149,6 +149,9 @@ class BaseContainer:
         self.slab = engine_opts.get("slab")
         self._global_ids = []
         self._next_global_id = 0
+        comm = engine_opts.get("comm")   # communicator without sharding (bench replicas: barrier / all-reduce only)
+        if comm and not self.slab:
+            self.engine.comm_init(comm["rank"], comm["nranks"], comm["unique_id"])
         if self.slab:
             from sph_project_amd import slab as _slab
             self._slab_mod = _slab

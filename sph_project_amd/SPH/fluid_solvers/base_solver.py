@@ -54,11 +54,28 @@ class BaseSolver:
         self.engine.prepare()
 
     def _step(self):
-        self.engine.step(1)
+        """WCSPH.py:27 / DFSPH.py:298 / PCISPH.py:165: the device runs _step() up to the point where the reference
+        calls rigid_solver.step(); the host then integrates the rigid bodies and inserts the objects whose entryTime
+        has come (base_container.py:218-221) exactly where the reference does; the device finishes the step
+        (renew_rigid_particle_state, boundary, DFSPH's neighbour search + density + alpha + divergence solve)."""
+        self.engine.step_begin()
         self.rigid_solver.step()
-        # late entries (base_container.py:218-221): appended after the step they become due in
         self.container.insert_object()
         self.rigid_solver.insert_rigid_object()
+        self.engine.step_end()
+        self._update_exported_meshes()
+
+    def _update_exported_meshes(self):
+        """base_solver.py:634-641 (renew_rigid_particle_state with exportObj): the mesh of every dynamic rigid body
+        follows its pose, so that run_simulation.py can write mesh_object_{id}.obj."""
+        if not self.cfg.get_cfg("exportObj"):
+            return
+        for oid, b in self.rigid_solver.bodies.items():
+            obj = self.container.object_collection.get(oid)
+            if not isinstance(obj, dict) or "mesh" not in obj:
+                continue
+            rest = np.asarray(obj["restPosition"], dtype=np.float64) - np.asarray(obj["restCenterOfMass"], dtype=np.float64)
+            obj["mesh"].vertices = (b.rot @ rest.T).T + b.com
 
     def step(self):
         """base_solver.py:692."""

@@ -62,7 +62,7 @@ class SphStats(C.Structure):
         ("fluid_particle_num", C.c_int32), ("iter_divergence", C.c_int32), ("iter_density", C.c_int32),
         ("iter_pcisph", C.c_int32), ("iter_cg", C.c_int32), ("err_divergence", C.c_float),
         ("err_density", C.c_float), ("err_pcisph", C.c_float), ("err_cg", C.c_float),
-        ("lds_fallback_blocks", C.c_int64), ("total_time", C.c_double),
+        ("lds_fallback_blocks", C.c_int64), ("total_time", C.c_double), ("pair_evaluations", C.c_int64),
     ]
 
 
@@ -86,6 +86,8 @@ _SIGNATURES = [
     ("sph_step", C.c_int, [_VP, C.c_int]),
     ("sph_step_async", C.c_int, [_VP, C.c_int]),
     ("sph_synchronize", C.c_int, [_VP]),
+    ("sph_step_begin", C.c_int, [_VP]),
+    ("sph_step_end", C.c_int, [_VP]),
     ("sph_run_phase", C.c_int, [_VP, C.c_int]),
     ("sph_download", C.c_int, [_VP, C.c_int, _VP, C.c_size_t]),
     ("sph_upload", C.c_int, [_VP, C.c_int, _VP, C.c_size_t]),
@@ -101,6 +103,10 @@ _SIGNATURES = [
     ("sph_comm_init", C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     ("sph_comm_set_slab", C.c_int, [_VP, C.c_int, C.c_int]),
     ("sph_comm_get_slab", C.c_int, [_VP] + [C.POINTER(C.c_int)] * 4),
+    ("sph_device_count", C.c_int, []),
+    ("sph_comm_allreduce", C.c_int, [_VP, C.POINTER(C.c_double), C.c_int, C.c_int]),
+    ("sph_comm_barrier", C.c_int, [_VP]),
+    ("sph_comm_selftest", C.c_int, [_VP, C.c_int]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -198,6 +204,12 @@ class Engine:
     def synchronize(self):
         self._chk(self.lib.sph_synchronize(self.h), "sph_synchronize")
 
+    def step_begin(self):
+        self._chk(self.lib.sph_step_begin(self.h), "sph_step_begin")
+
+    def step_end(self):
+        self._chk(self.lib.sph_step_end(self.h), "sph_step_end")
+
     def run_phase(self, phase):
         self._chk(self.lib.sph_run_phase(self.h, int(phase)), "sph_run_phase")
 
@@ -256,6 +268,19 @@ class Engine:
         v = [C.c_int() for _ in range(4)]
         self._chk(self.lib.sph_comm_get_slab(self.h, *[C.byref(x) for x in v]), "sph_comm_get_slab")
         return dict(z_lo=v[0].value, z_hi=v[1].value, n_owned=v[2].value, n_ghost=v[3].value)
+
+    def comm_allreduce(self, values, op="sum"):
+        """In-place all-reduce of up to 16 doubles over the communicator; returns the list of reduced values."""
+        vals = [float(v) for v in (values if isinstance(values, (list, tuple)) else [values])]
+        buf = (C.c_double * len(vals))(*vals)
+        self._chk(self.lib.sph_comm_allreduce(self.h, buf, len(vals), {"sum": 0, "max": 1, "min": 2}[op]), "sph_comm_allreduce")
+        return list(buf)
+
+    def comm_barrier(self):
+        self._chk(self.lib.sph_comm_barrier(self.h), "sph_comm_barrier")
+
+    def comm_selftest(self, n=4096):
+        self._chk(self.lib.sph_comm_selftest(self.h, int(n)), "sph_comm_selftest")
 
     def device_info(self):
         name = C.create_string_buffer(256)

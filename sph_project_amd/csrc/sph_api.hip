@@ -37,6 +37,10 @@ struct SphHandle {
     bool prepared = false;
     bool pose_dirty = false;
     bool rigid_volume_done = false;
+    bool sort_dirty = false;      // particles appended since the last sort
+    bool in_step = false;         // between sph_step_begin and sph_step_end
+    int n_mark = 0;               // particle count at the end of sph_step_begin: [n_mark, n) was appended mid-step
+    int fresh_state = 0;          // rigid particles appended after prepare(): 1 = the next post-sort volume pass leaves them alone, 2 = the one after includes them (see ph_rigid_volume)
     RigidPose pose_h;
     SphStats last;
     ProfSlot prof[SPH_K_COUNT_];
@@ -295,6 +299,7 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
         hp[k] = make_float4(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2], V0);
         hv[k] = make_float4(vel[3 * k], vel[3 * k + 1], vel[3 * k + 2], V0 * density[k]);
         hm[k] = META_PACK(object_id, material[k], is_dynamic[k] ? 1 : 0);
+        if (h->prepared && material[k] == SPH_MAT_RIGID) { hm[k] |= META_FRESH_BIT; h->fresh_state = 1; }
         hid[k] = h->n + k;
         unsigned r = color ? (unsigned)(color[3 * k] & 0xff) : 0, g = color ? (unsigned)(color[3 * k + 1] & 0xff) : 0,
                  b = color ? (unsigned)(color[3 * k + 2] & 0xff) : 0;
@@ -324,7 +329,8 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
     h->n += n;
     h->n_fluid += nfl;
     h->n_nonfluid += n - nfl;
-    h->rigid_volume_done = false;
+    if (!h->prepared) h->rigid_volume_done = false;   // later arrivals: see fresh_state
+    if (h->prepared) h->sort_dirty = true;
     s.masks_valid = 0;
     s.perm_n = -1; s.list_n = -1;
     refresh_counts(h);
@@ -446,14 +452,21 @@ static void ph_neighbor_search(SphHandle *h) {
     { ProfScope p(h, SPH_K_HASH_COUNT); h->L->hash_count(s); }
     { ProfScope p(h, SPH_K_SCAN); h->L->scan(s); }
     { ProfScope p(h, SPH_K_SCATTER); if (h->prm.deterministic) h->L->scatter_stable(s); else h->L->scatter(s); }
+    h->sort_dirty = false;
 }
 
 static void ph_rigid_volume(SphHandle *h) {
-    // base_solver.py:106.  Static boundaries: the sum only involves same-object (static) particles,
-    // so the value computed once after the first sort is bit-identical to recomputing every step
-    // (:696); with dynamic bodies it is recomputed after every sort.
+    // base_solver.py:106.  The reference runs it at the end of every step() (:696) on the grid of that step's sort.
+    // Static boundaries: the sum only involves same-object (static) particles, so the value computed once after the
+    // first sort is bit-identical to recomputing every step; with dynamic bodies it is recomputed after every sort.
+    // Rigid particles appended after prepare() (late entryTime) carry META_FRESH: the reference's pass at the end of
+    // their insertion step ran on a grid that did not contain them (WCSPH / PCISPH: V = 1 / W(0), set by post_insert;
+    // DFSPH: they were sorted in before :317, with V = V0 from add_particle), and only the pass one step later saw them.
     if (!h->st.has_rigid) return;
-    if (h->rigid_volume_done && !h->st.has_dynamic_rigid) return;
+    bool force = false;
+    if (h->fresh_state == 2) { h->L->clear_fresh(h->st); h->fresh_state = 0; force = true; }
+    else if (h->fresh_state == 1 && h->prm.method != SPH_METHOD_DFSPH) h->fresh_state = 2;   // this pass skips them (RigidVolumePass::begin)
+    if (!force && h->rigid_volume_done && !h->st.has_dynamic_rigid) return;
     ProfScope p(h, SPH_K_RIGID_VOLUME);
     h->L->rigid_volume(h->st);
     h->rigid_volume_done = true;
@@ -471,10 +484,14 @@ static void step_begin(SphHandle *h) {
 static int read_scalars(SphHandle *h) {
     HIPCHK(h, hipMemcpyAsync(h->scal_h, h->st.scal, sizeof(DevScalars), hipMemcpyDeviceToHost, h->st.stream));
     HIPCHK(h, hipStreamSynchronize(h->st.stream));
-    unsigned long long pairs = 0, fb = 0;
+    unsigned long long pairs = 0, evals = 0, fb = 0;
     const int bank = h->steps > 0 ? (int)((h->steps - 1) & 1) : 0;   // bank of the last completed step
-    for (int k = 0; k < SPH_STAT_SLOTS; ++k) { pairs += h->scal_h->pairs[bank][k]; fb += h->scal_h->fallback[bank][k]; }
+    for (int k = 0; k < SPH_STAT_SLOTS; ++k) {
+        pairs += h->scal_h->pairs[bank][k] & 0xffffffffull; evals += h->scal_h->pairs[bank][k] >> 32;
+        fb += h->scal_h->fallback[bank][k];
+    }
     h->last.pair_interactions = (int64_t)pairs;
+    h->last.pair_evaluations = (int64_t)evals;
     h->last.lds_fallback_blocks = (int64_t)fb;
     return SPH_OK;
 }
@@ -506,19 +523,65 @@ extern "C" int sph_prepare(SphHandle *h) {
     return SPH_OK;
 }
 
-static int step_once(SphHandle *h, bool allow_readback) {
+// First half of a step: everything the reference's _step() does before `self.rigid_solver.step()`.
+static int step_first_half(SphHandle *h, bool allow_readback) {
+    if (h->in_step) return fail(h, SPH_ERR_INVALID, "sph_step_begin: the previous step was not ended");
     if (h->st.slab_active && h->prm.method != SPH_METHOD_WCSPH) return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding: wcsph only");
     step_begin(h);
     int rc;
     switch (h->prm.method) {
-        case SPH_METHOD_WCSPH: rc = wcsph_step(h); break;
-        case SPH_METHOD_DFSPH: rc = dfsph_step(h, allow_readback); break;
-        default: rc = pcisph_step(h, allow_readback); break;
+        case SPH_METHOD_WCSPH: rc = wcsph_step(h); break;                     // WCSPH.py:28-36 (:45 boundary fused into the position update)
+        case SPH_METHOD_DFSPH: rc = dfsph_step_begin(h, allow_readback); break;
+        default: rc = pcisph_step(h, allow_readback); break;                  // PCISPH.py:166-177
     }
     if (rc) return rc;
-    h->total_time += (double)h->st.c.dt;  // base_solver.py:694
+    h->n_mark = h->n;
+    h->in_step = true;
+    return SPH_OK;
+}
+
+// Second half: renew_rigid_particle_state (:616) for a pose the host pushed in between, the boundary (and the stale-grid
+// rigid volume) for particles the host appended in between, DFSPH's post-insertion passes, then step()'s tail.
+static int step_second_half(SphHandle *h, bool allow_readback) {
+    if (!h->in_step) return fail(h, SPH_ERR_INVALID, "sph_step_end without sph_step_begin");
+    State &s = h->st;
+    h->in_step = false;
+    if (h->pose_dirty) { ProfScope p(h, SPH_K_MISC); h->L->renew_rigid(s); h->pose_dirty = false; }
+    if (h->n > h->n_mark) {
+        if (s.slab_active) return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding: objects must be present at prepare() (late entry is single-GPU)");
+        ProfScope p(h, SPH_K_MISC);
+        h->L->post_insert(s, h->n_mark, h->prm.method != SPH_METHOD_DFSPH);
+    }
+    if (h->prm.method == SPH_METHOD_DFSPH) {
+        int rc = dfsph_step_end(h, allow_readback); if (rc) return rc;
+        if (h->fresh_state == 1) { h->fresh_state = 2; ph_rigid_volume(h); }  // base_solver.py:696 on the fresh grid: now it sees them
+    }
+    h->total_time += (double)s.c.dt;  // base_solver.py:694
     h->steps++;
     return SPH_OK;
+}
+
+static int step_once(SphHandle *h, bool allow_readback) {
+    int rc = step_first_half(h, allow_readback); if (rc) return rc;
+    return step_second_half(h, allow_readback);
+}
+
+extern "C" int sph_step_begin(SphHandle *h) {
+    if (!h) return SPH_ERR_INVALID;
+    if (!h->prepared) return fail(h, SPH_ERR_INVALID, "sph_step_begin before sph_prepare");
+    HIPCHK(h, hipSetDevice(h->device));
+    refresh_counts(h);
+    int rc = step_first_half(h, true); if (rc) return rc;
+    return check_async(h);
+}
+
+extern "C" int sph_step_end(SphHandle *h) {
+    if (!h) return SPH_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    refresh_counts(h);
+    int rc = step_second_half(h, true); if (rc) return rc;
+    rc = check_async(h); if (rc) return rc;
+    return read_scalars(h);
 }
 
 extern "C" int sph_step_async(SphHandle *h, int nsteps) {

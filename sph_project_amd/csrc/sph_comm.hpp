@@ -12,7 +12,14 @@ struct ShmMailbox {           // one per (writer rank, direction); written by `r
     uint64_t nbytes;
     uint64_t pad[5];
 };
-struct ShmHeader { std::atomic<int> attached; std::atomic<int> detached; int nranks; int pad; uint64_t mbox_cap; };
+#define SHM_MAX_RANKS 64
+#define SHM_RED_MAX 16
+struct ShmHeader {
+    std::atomic<int> attached; std::atomic<int> detached; int nranks; int pad; uint64_t mbox_cap;
+    // sph_comm_barrier / sph_comm_allreduce of the shm transport: arrival counter + generation, one row of doubles per rank
+    std::atomic<uint64_t> bar_count, bar_gen;
+    double red[SHM_MAX_RANKS][SHM_RED_MAX];
+};
 
 struct SlabComm {
     int kind = 0;             // 0 none, 1 rccl, 2 shm
@@ -24,5 +31,9 @@ struct SlabComm {
     int n_send[2] = {0, 0}, n_recv[2] = {0, 0};
     int *cnt_dev = nullptr;   // 4 ints: send counts [0..1], recv counts [2..3] (rccl size exchange)
     int *cnt_host = nullptr;  // pinned mirror
+    double *red_dev = nullptr;   // SHM_RED_MAX doubles: sph_comm_allreduce (rccl)
+    double *red_host = nullptr;  // pinned mirror
+    float *self_dev = nullptr;   // sph_comm_selftest buffers (send | recv)
+    int slab_ready = 0;          // halo buffers allocated (sph_comm_set_slab)
     unsigned char id[128];
 };

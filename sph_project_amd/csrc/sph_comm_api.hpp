@@ -29,6 +29,9 @@ static void slab_comm_destroy(SlabComm &c) {
     }
     if (c.cnt_dev) hipFree(c.cnt_dev);
     if (c.cnt_host) hipHostFree(c.cnt_host);
+    if (c.red_dev) hipFree(c.red_dev);
+    if (c.red_host) hipHostFree(c.red_host);
+    if (c.self_dev) hipFree(c.self_dev);
     c = SlabComm();
 }
 
@@ -81,11 +84,16 @@ static int shm_attach(SphHandle *h, SlabComm &c, size_t mbox_cap) {
     return SPH_OK;
 }
 
+extern "C" int sph_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+// Communicator only: rank / size / transport.  Usable without slab sharding (bench replicas: barrier + all-reduce);
+// sph_comm_set_slab() turns the handle into one z-slab of the global grid.
 extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id128) {
     if (!h || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, SPH_ERR_INVALID, "comm_init: bad arguments");
     if (h->comm.kind) return fail(h, SPH_ERR_INVALID, "comm_init: already initialised");
-    if (h->prm.method != SPH_METHOD_WCSPH || h->prm.viscosity_implicit)
-        return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding is built for WCSPH with explicit viscosity in this round");
     HIPCHK(h, hipSetDevice(h->device));
     State &s = h->st;
     SlabComm &c = h->comm;
@@ -97,18 +105,13 @@ extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id1
     if (cap > (size_t)s.cap) cap = (size_t)s.cap;
     if (cap < 1024) cap = 1024;
     s.halo_cap = (int)cap;
-    for (int k = 0; k < 2; ++k) {
-        int rc = dalloc(h, &s.xidx[k], (size_t)s.cap); if (rc) return rc;
-        rc = dalloc(h, &s.sendbuf[k], 3 * cap); if (rc) return rc;
-        rc = dalloc(h, &s.recvbuf[k], 3 * cap); if (rc) return rc;
-    }
-    for (int k = 0; k < 8; ++k) { int rc = dalloc(h, &s.halo_tab[k], cap); if (rc) return rc; }
-    { int rc = dalloc(h, &s.halo_counts, 4); if (rc) return rc; }
     HIPCHK(h, hipMalloc((void **)&c.cnt_dev, 4 * sizeof(int)));
     HIPCHK(h, hipHostMalloc((void **)&c.cnt_host, 8 * sizeof(int), hipHostMallocDefault));
-    s.xcur = 0;
+    HIPCHK(h, hipMalloc((void **)&c.red_dev, SHM_RED_MAX * sizeof(double)));
+    HIPCHK(h, hipHostMalloc((void **)&c.red_host, SHM_RED_MAX * sizeof(double), hipHostMallocDefault));
     const char *t = getenv("SPH_COMM_TRANSPORT");
     if (t && !strcmp(t, "shm")) {
+        if (nranks > SHM_MAX_RANKS) return fail(h, SPH_ERR_INVALID, "shm transport: at most %d ranks", SHM_MAX_RANKS);
         int rc = shm_attach(h, c, cap * 48);
         if (rc) return rc;
         c.kind = 2;
@@ -121,18 +124,33 @@ extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id1
         c.nccl = comm;
         c.kind = 1;
     }
-    s.slab_active = 1;
-    s.has_down = rank > 0; s.has_up = rank < nranks - 1;
-    s.z_lo = 0; s.z_hi = s.c.nz_glob;
     return SPH_OK;
 }
 
 extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
     if (!h || !h->comm.kind) return fail(h, SPH_ERR_INVALID, "comm_set_slab: communicator not initialised");
     Consts &c = h->st.c;
+    State &s = h->st;
+    if (h->prm.viscosity_implicit)
+        return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding: implicit viscosity (CG ghost exchange) is not built");
     if (z_lo < 0 || z_hi > c.nz_glob || z_hi - z_lo < 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: a slab needs >= 2 cell layers inside the grid");
     if (h->n > 0) return fail(h, SPH_ERR_INVALID, "comm_set_slab: set the slab before particles are appended");
-    h->st.z_lo = z_lo; h->st.z_hi = z_hi;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->comm.slab_ready) {
+        const size_t cap = (size_t)s.halo_cap;
+        for (int k = 0; k < 2; ++k) {
+            int rc = dalloc(h, &s.xidx[k], (size_t)s.cap); if (rc) return rc;
+            rc = dalloc(h, &s.sendbuf[k], 3 * cap); if (rc) return rc;
+            rc = dalloc(h, &s.recvbuf[k], 3 * cap); if (rc) return rc;
+        }
+        for (int k = 0; k < 8; ++k) { int rc = dalloc(h, &s.halo_tab[k], cap); if (rc) return rc; }
+        { int rc = dalloc(h, &s.halo_counts, 4); if (rc) return rc; }
+        s.xcur = 0;
+        h->comm.slab_ready = 1;
+    }
+    s.slab_active = 1;
+    s.has_down = h->comm.rank > 0; s.has_up = h->comm.rank < h->comm.nranks - 1;
+    s.z_lo = z_lo; s.z_hi = z_hi;
     // the cell lists cover the own layers plus one ghost layer per interior side only: G, and with it the histogram, the
     // scan and the cell windows, shrink from the global grid to the slab (weak scaling would otherwise scan N times as
     // many cells on every rank)
@@ -170,6 +188,106 @@ static int shm_wait(std::atomic<uint64_t> &a, uint64_t want, SphHandle *h, const
             usleep(50);
         }
     }
+    return SPH_OK;
+}
+
+// ---- host-visible collectives of the communicator (bench launcher, solver residuals under sharding)
+static int shm_barrier(SphHandle *h, SlabComm &c) {
+    ShmHeader *hd = (ShmHeader *)c.shm_base;
+    const uint64_t gen = hd->bar_gen.load(std::memory_order_acquire);
+    if (hd->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint64_t)c.nranks) {
+        hd->bar_count.store(0, std::memory_order_relaxed);
+        hd->bar_gen.fetch_add(1, std::memory_order_release);
+        return SPH_OK;
+    }
+    struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0; hd->bar_gen.load(std::memory_order_acquire) == gen; ++spins) {
+        if ((spins & 255) == 255) {
+            struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (t1.tv_sec - t0.tv_sec > 120) return fail(h, SPH_ERR_COMM, "shm transport: barrier timed out");
+            usleep(20);
+        }
+    }
+    return SPH_OK;
+}
+
+// op: 0 sum, 1 max, 2 min over all ranks, in place; count <= SHM_RED_MAX doubles.  Synchronous.
+extern "C" int sph_comm_allreduce(SphHandle *h, double *inout, int count, int op) {
+    if (!h || !inout || count < 0 || count > SHM_RED_MAX || op < 0 || op > 2) return fail(h, SPH_ERR_INVALID, "comm_allreduce: bad arguments");
+    SlabComm &c = h->comm;
+    if (!c.kind) return fail(h, SPH_ERR_INVALID, "comm_allreduce: communicator not initialised");
+    if (count == 0) return SPH_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (c.kind == 2) {
+        ShmHeader *hd = (ShmHeader *)c.shm_base;
+        for (int k = 0; k < count; ++k) hd->red[c.rank][k] = inout[k];
+        int rc = shm_barrier(h, c); if (rc) return rc;
+        for (int k = 0; k < count; ++k) {
+            double v = hd->red[0][k];
+            for (int r = 1; r < c.nranks; ++r) { const double w = hd->red[r][k]; v = op == 0 ? v + w : (op == 1 ? (w > v ? w : v) : (w < v ? w : v)); }
+            inout[k] = v;
+        }
+        return shm_barrier(h, c);   // nobody overwrites its row before everyone has read it
+    }
+    State &s = h->st;
+    memcpy(c.red_host, inout, sizeof(double) * count);
+    HIPCHK(h, hipMemcpyAsync(c.red_dev, c.red_host, sizeof(double) * count, hipMemcpyHostToDevice, s.stream));
+    NCCLCHK(h, ncclAllReduce(c.red_dev, c.red_dev, (size_t)count, ncclDouble, op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin), (ncclComm_t)c.nccl, s.stream));
+    HIPCHK(h, hipMemcpyAsync(c.red_host, c.red_dev, sizeof(double) * count, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(h, hipStreamSynchronize(s.stream));
+    memcpy(inout, c.red_host, sizeof(double) * count);
+    return SPH_OK;
+}
+
+// all ranks' streams drained, then everybody leaves together
+extern "C" int sph_comm_barrier(SphHandle *h) {
+    if (!h || !h->comm.kind) return fail(h, SPH_ERR_INVALID, "comm_barrier: communicator not initialised");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->st.stream));
+    if (h->comm.kind == 2) return shm_barrier(h, h->comm);
+    double one = 1.0;
+    return sph_comm_allreduce(h, &one, 1, 0);
+}
+
+// Transport self-test: every rank sends n floats of a rank-tagged pattern to rank + 1 (mod size) and receives from
+// rank - 1 (a self send/recv pair when size == 1), checks every word, then checks a sum all-reduce.  RCCL: the same
+// ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd sequence the halo exchange uses.
+extern "C" int sph_comm_selftest(SphHandle *h, int n) {
+    if (!h || !h->comm.kind || n < 1 || n > (1 << 24)) return fail(h, SPH_ERR_INVALID, "comm_selftest: bad arguments");
+    SlabComm &c = h->comm;
+    State &s = h->st;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int to = (c.rank + 1) % c.nranks, from = (c.rank + c.nranks - 1) % c.nranks;
+    std::vector<float> src((size_t)n), dst((size_t)n, -1.0f);
+    for (int k = 0; k < n; ++k) src[k] = (float)(c.rank * 1000 + (k % 997));
+    if (c.kind == 1) {
+        if (c.self_dev) { hipFree(c.self_dev); c.self_dev = nullptr; }
+        HIPCHK(h, hipMalloc((void **)&c.self_dev, sizeof(float) * 2 * (size_t)n));
+        HIPCHK(h, hipMemcpyAsync(c.self_dev, src.data(), sizeof(float) * n, hipMemcpyHostToDevice, s.stream));
+        HIPCHK(h, hipMemsetAsync(c.self_dev + n, 0xff, sizeof(float) * n, s.stream));
+        NCCLCHK(h, ncclGroupStart());
+        NCCLCHK(h, ncclSend(c.self_dev, (size_t)n, ncclFloat, to, (ncclComm_t)c.nccl, s.stream));
+        NCCLCHK(h, ncclRecv(c.self_dev + n, (size_t)n, ncclFloat, from, (ncclComm_t)c.nccl, s.stream));
+        NCCLCHK(h, ncclGroupEnd());
+        HIPCHK(h, hipMemcpyAsync(dst.data(), c.self_dev + n, sizeof(float) * n, hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+    } else {
+        // shm: the mailbox pair of the "up" direction, wrapped around (rank size-1 -> rank 0 uses its unused up box)
+        if ((size_t)n * 4 > c.mbox_cap) return fail(h, SPH_ERR_CAPACITY, "comm_selftest: %d floats exceed the mailbox", n);
+        ShmMailbox *out = shm_mbox(c, c.rank, 1);
+        memcpy((char *)(out + 1), src.data(), sizeof(float) * n);
+        out->nbytes = (uint64_t)n * 4;
+        int rc = shm_barrier(h, c); if (rc) return rc;
+        ShmMailbox *in = shm_mbox(c, from, 1);
+        if (in->nbytes != (uint64_t)n * 4) return fail(h, SPH_ERR_COMM, "comm_selftest: size mismatch");
+        memcpy(dst.data(), (char *)(in + 1), sizeof(float) * n);
+        rc = shm_barrier(h, c); if (rc) return rc;
+    }
+    for (int k = 0; k < n; ++k)
+        if (dst[k] != (float)(from * 1000 + (k % 997))) return fail(h, SPH_ERR_COMM, "comm_selftest: word %d from rank %d is %g", k, from, (double)dst[k]);
+    double v[2] = {(double)(c.rank + 1), 1.0};
+    int rc = sph_comm_allreduce(h, v, 2, 0); if (rc) return rc;
+    if (v[0] != 0.5 * c.nranks * (c.nranks + 1) || v[1] != (double)c.nranks) return fail(h, SPH_ERR_COMM, "comm_selftest: all-reduce gave %g, %g", v[0], v[1]);
     return SPH_OK;
 }
 

@@ -23,6 +23,8 @@
 #define META_PACK(obj, mat, dyn) ((((obj) + 1) & 0xff) | (((mat) & 0x3) << 8) | (((dyn) & 1) << 10))
 #define META_GHOST(m) (((m) >> 11) & 0x1)   /* slab sharding: copy of a neighbour rank's boundary particle */
 #define META_DEAD(m) (((m) >> 12) & 0x1)    /* slab sharding: left this rank (or last step's ghost); sorted into the graveyard cell G */
+#define META_FRESH(m) (((m) >> 13) & 0x1)   /* rigid particle appended after prepare(): the reference's end-of-step volume pass saw it on a stale grid */
+#define META_FRESH_BIT (1 << 13)
 #define META_ACTIVE_FLUID(m) ((((m) >> 8) & 0xB) == 1) /* material fluid and not a ghost */
 #define META_SET_MAT(m, mat) (((m) & ~(0x3 << 8)) | (((mat) & 0x3) << 8))
 
@@ -154,6 +156,8 @@ struct Launch {
     void (*rigid_volume)(State &);
     void (*renew_rigid)(State &);
     void (*prepare_emitter)(State &);
+    void (*post_insert)(State &, int first, int stale_volume);   // appended particles [first, n): boundary (+ V = 1 / W(0) for rigid ones)
+    void (*clear_fresh)(State &);
     // DFSPH
     void (*dfsph_density_alpha)(State &);
     void (*dfsph_rho_adv)(State &, int mode);   // 0: density derivative (+kappa_v), 1: density star (+kappa)

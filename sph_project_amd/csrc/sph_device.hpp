@@ -886,7 +886,10 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         if (P::COUNT_PAIRS) {
             float fp = wave_sum((float)npairs);  // <= 64 * few hundred: exact in f32
             if ((tid & 63) == 0 && fp > 0.0f)
-                atomicAdd(&scal->pairs[c.stat_bank][(b * (BLOCK / 64) + (tid >> 6)) & (SPH_STAT_SLOTS - 1)], (unsigned long long)fp * P::PAIR_WEIGHT);
+                // one atomic carries both tallies of the slot: low word = pairs weighted by the reference passes this walk
+                // stands for (SURVEY 8d metric), high word = pairs as evaluated (a slot sees < 2^32 of either per step)
+                atomicAdd(&scal->pairs[c.stat_bank][(b * (BLOCK / 64) + (tid >> 6)) & (SPH_STAT_SLOTS - 1)],
+                          (unsigned long long)fp * P::PAIR_WEIGHT + ((unsigned long long)fp << 32));
         }
     }
     NBR_STAMP(14);

@@ -262,6 +262,37 @@ void l_prepare_emitter(State &s) {
                        s.meta.cur());
 }
 
+// Particles appended mid-step by the host (base_container.py:212 insert_object, called from _step()): what the rest of
+// the reference's step does to them.  Fluid: enforce_domain_boundary_3D (:575).  Rigid, WCSPH / PCISPH only: step()'s
+// compute_rigid_particle_volume (:696) runs on the grid of the last sort, which does not contain them, so the sum
+// over same-object neighbours is empty: V = 1 / W(0), m = rho0 V (:113-:115).
+__global__ void __launch_bounds__(256)
+k_post_insert(const Consts c, int first, float4 *posv, float4 *velm, const int *meta, int stale_volume) {
+    const int i = first + blockIdx.x * 256 + threadIdx.x;
+    if (i >= c.n) return;
+    const int m = meta[i];
+    float4 p = posv[i], v = velm[i];
+    if (META_MAT(m) == 1) {
+        if (META_DYN(m)) { enforce_boundary(c, p.x, p.y, p.z, v.x, v.y, v.z); posv[i] = p; velm[i] = v; }
+    } else if (stale_volume && META_MAT(m) == 2 && p.y <= c.g_upper) {
+        const float V = 1.0f / c.W0;
+        p.w = V; v.w = c.rho0 * V;
+        posv[i] = p; velm[i] = v;
+    }
+}
+void l_post_insert(State &s, int first, int stale_volume) {
+    if (s.c.n <= first) return;
+    hipLaunchKernelGGL(k_post_insert, dim3(cdiv(s.c.n - first, 256)), dim3(256), 0, s.stream, s.c, first, s.posv.cur(),
+                       s.velm.cur(), s.meta.cur(), stale_volume);
+}
+__global__ void __launch_bounds__(256) k_clear_fresh(int n, int *meta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const int m = meta[i]; if (m & META_FRESH_BIT) meta[i] = m & ~META_FRESH_BIT; }
+}
+void l_clear_fresh(State &s) {
+    if (s.c.n > 0) hipLaunchKernelGGL(k_clear_fresh, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur());
+}
+
 #include "sph_solvers_impl.hpp"
 #include "sph_halo_impl.hpp"
 }  // namespace SPH_NS
@@ -283,6 +314,8 @@ const Launch *SPH_LAUNCH_FN() {
         L.rigid_volume = l_rigid_volume;
         L.renew_rigid = l_renew_rigid;
         L.prepare_emitter = l_prepare_emitter;
+        L.post_insert = l_post_insert;
+        L.clear_fresh = l_clear_fresh;
         register_solver_launchers(L);
         L.halo_classify_pack = l_halo_classify_pack; L.halo_unpack_append = l_halo_unpack_append;
         L.halo_build_tables = l_halo_build_tables; L.halo_pack_fields = l_halo_pack_fields;

@@ -409,7 +409,7 @@ struct RigidVolumePass {
     __device__ float4 stage(const Consts &, int j, BT &) const { return stage_impl(j); }
     __device__ bool begin(const Consts &c, int i, const float4 &pi, Own &o) const {
         const int m = meta[i];
-        if (META_MAT(m) != 2 || META_GHOST(m) || !(pi.y <= c.g_upper)) return false;
+        if (META_MAT(m) != 2 || META_GHOST(m) || META_FRESH(m) || !(pi.y <= c.g_upper)) return false;
         o.obj = META_OBJ(m);
         o.sum = c.W0;
         return true;

@@ -144,11 +144,26 @@ static int dfsph_density(SphHandle *h, bool allow_readback) {
     return SPH_OK;
 }
 
-static int dfsph_step(SphHandle *h, bool allow_readback) {
+// DFSPH.py:298 _step, first half: up to (not including) rigid_solver.step() / insert_object() at :305-:308
+static int dfsph_step_begin(SphHandle *h, bool allow_readback) {
     State &s = h->st;
+    if (h->sort_dirty) {
+        // particles were appended outside a step (plain C-ABI use): the passes below walk the cell lists, so bring them
+        // (and density / alpha, which the reference refreshes after every sort, DFSPH.py:316-318) up to date first
+        ph_neighbor_search(h);
+        ph_rigid_volume(h);
+        { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha(s); }
+    }
     int rc = run_non_pressure(h); if (rc) return rc;                          // DFSPH.py:299-300
     rc = dfsph_density(h, allow_readback); if (rc) return rc;                 // :301
-    { ProfScope p(h, SPH_K_MISC); h->L->advect_boundary(s); }                 // :303, :311-314
+    { ProfScope p(h, SPH_K_MISC); h->L->advect_boundary(s); }                 // :303, :311-314 (boundary fused: it only looks at the particle itself)
+    return SPH_OK;
+}
+
+// second half: :309 renew_rigid_particle_state and :311 boundary for what the host just inserted (step_insert_tail),
+// then :316-:319
+static int dfsph_step_end(SphHandle *h, bool allow_readback) {
+    State &s = h->st;
     ph_neighbor_search(h);                                                    // :316
     ph_rigid_volume(h);
     { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha(s); } // :317-318

@@ -26,6 +26,15 @@ class Mesh:
     def bounds(self):
         return np.stack([self.vertices.min(axis=0), self.vertices.max(axis=0)])
 
+    def export(self, file_type="obj"):
+        """Wavefront OBJ text (`v` / `f` records, 1-based indices): what run_simulation.py:146-150 writes per rigid body."""
+        if file_type != "obj":
+            raise NotImplementedError(file_type)
+        lines = ["# sph_project_amd"]
+        lines += ["v %.8f %.8f %.8f" % tuple(v) for v in self.vertices]
+        lines += ["f %d %d %d" % tuple(f + 1) for f in self.faces]
+        return "\n".join(lines) + "\n"
+
 
 def load_obj(path):
     """Wavefront OBJ: `v` and `f` records (polygons are fan-triangulated, `v/vt/vn` and negative indices accepted)."""

@@ -6,7 +6,8 @@ run_simulation.py (:13-44 argument + interval arithmetic, :116-155 loop, :137-14
 
 Frames go to {scene_name}_output/{cnt:06}/particle_object_{id}.ply (ASCII PLY, x y z per vertex -- the
 layout Taichi's PLYWriter.export_ascii produces and surface_reconstruction.py / splashsurf consume).
-PNG frames (exportFrame) need the reference's GGUI window and are not produced."""
+Rigid bodies: mesh_object_{id}.obj per frame with exportObj (:146-150).  PNG frames (exportFrame) need the reference's
+GGUI window and are not produced."""
 import argparse
 import os
 import sys
@@ -53,6 +54,7 @@ def main(argv=None):
     if config.get_cfg("outputInterval"):
         output_interval = config.get_cfg("outputInterval")
     output_ply = config.get_cfg("exportPly")
+    output_obj = config.get_cfg("exportObj")
     out_dir = args.output_dir or f"{scene_name}_output"
     os.makedirs(out_dir, exist_ok=True)
 
@@ -74,6 +76,13 @@ def main(argv=None):
             os.makedirs(f"{out_dir}/{cnt:06}", exist_ok=True)
             for f_body_id in container.object_id_fluid_body:
                 write_ply_ascii(f"{out_dir}/{cnt:06}/particle_object_{f_body_id}.ply", container.dump(obj_id=f_body_id)["position"])
+        if cnt % output_interval == 0 and output_obj:   # run_simulation.py:146-150
+            os.makedirs(f"{out_dir}/{cnt:06}", exist_ok=True)
+            for r_body_id in container.object_id_rigid_body:
+                if "mesh" not in container.object_collection[r_body_id]:   # body given as pre-voxelised points only
+                    continue
+                with open(f"{out_dir}/{cnt:06}/mesh_object_{r_body_id}.obj", "w") as f:
+                    f.write(container.object_collection[r_body_id]["mesh"].export(file_type="obj"))
         cnt += 1
         if cnt >= total_rounds or (args.max_steps is not None and cnt >= args.max_steps):
             break

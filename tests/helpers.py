@@ -6,28 +6,9 @@ import numpy as np
 
 from oracle import ref as oracle_ref
 from sph_project_amd import scene
+from sph_project_amd.product import dam_break_scene, scene_particles  # noqa: F401 (shared with bench.py / smoke())
+from sph_project_amd import product as _product
 from sph_project_amd.SPH.utils import SimConfig  # noqa: F401 (re-exported for tests)
-
-
-def dam_break_scene(method="wcsph", domain_end=(1.0, 1.0, 1.0), start=(0.0, 0.0, 0.0), end=(0.4, 0.4, 0.4),
-                    translation=(0.1, 0.1, 0.1), velocity=(0.0, 0.0, 0.0), dt=4e-4, viscosity=10.0,
-                    add_domain_box=False, viscosity_method="standard", radius=0.01, **extra):
-    """SURVEY 8(d) config C1 by default: 20^3 = 8000-particle cube, WCSPH."""
-    cfg = {
-        "Configuration": {
-            "domainStart": [0.0, 0.0, 0.0], "domainEnd": list(domain_end), "addDomainBox": add_domain_box,
-            "particleRadius": radius, "density0": 1000, "simulationMethod": method,
-            "viscosityMethod": viscosity_method, "gravitation": [0.0, -9.81, 0.0], "timeStepSize": dt,
-            "viscosity": viscosity,
-        },
-        "FluidBlocks": [{
-            "objectId": 0, "start": list(start), "end": list(end), "translation": list(translation),
-            "scale": [1, 1, 1], "velocity": list(velocity), "density": 1000.0, "color": [50, 100, 200],
-            "entryTime": -1.0,
-        }],
-    }
-    cfg["Configuration"].update(extra)
-    return cfg
 
 
 def perturb(pos, amplitude, seed=0):
@@ -35,51 +16,52 @@ def perturb(pos, amplitude, seed=0):
     return (pos + rng.uniform(-amplitude, amplitude, pos.shape)).astype(np.float32)
 
 
-def scene_particles(cfg_dict):
-    """Host lattice of every object in the scene, in the reference's insertion order
-    (domain box first: base_container.py:192, then FluidBlocks: :215)."""
-    cfg = SimConfig(config=copy.deepcopy(cfg_dict))
-    geo = scene.derive_geometry(cfg)
-    batches = []
-    blocks = cfg.get_fluid_blocks()
-    n_obj = len(blocks)
-    if geo.add_domain_box:
-        pos = scene.box_lattice(geo.domain_box_start, geo.domain_box_size, geo.domain_box_thickness, geo.particle_spacing)
-        n = pos.shape[0]
-        # BaseSolver.prepare() -> init_object_id() (base_solver.py:680) runs after the box was added in
-        # BaseContainer.__init__, so the reference's box particles carry object id -1
-        batches.append(dict(object_id=-1, pos=pos, vel=np.zeros((n, 3), np.float32),
-                            density=np.full(n, 1000.0, np.float32), material=np.full(n, 2, np.int32),
-                            is_dynamic=np.zeros(n, np.int32)))
-    for blk in blocks:
-        off = np.array(blk["translation"])
-        s, e = np.array(blk["start"]) + off, np.array(blk["end"]) + off
-        pos = scene.cube_lattice(s, (e - s) * np.array(blk["scale"]), geo.particle_spacing)
-        n = pos.shape[0]
-        batches.append(dict(object_id=blk["objectId"], pos=pos, vel=np.tile(np.asarray(blk["velocity"], np.float32), (n, 1)),
-                            density=np.full(n, blk["density"], np.float32), material=np.full(n, 1, np.int32),
-                            is_dynamic=np.ones(n, np.int32)))
-    return cfg, geo, batches
+def _oracle_insert(sim, b, jitter=0.0, seed=0):
+    n = b["pos"].shape[0]
+    pos = perturb(b["pos"], jitter, seed) if (jitter > 0 and b["material"][0] == 1) else b["pos"]
+    color = np.zeros((n, 3), np.int32)
+    color[:, 0] = np.arange(sim._next_id, sim._next_id + n)
+    sim._next_id += n
+    if b["object_id"] >= 0:
+        sim.set_object(b["object_id"], int(b["material"][0]), 0)
+    sim.add_particles(b["object_id"], pos, b["vel"], b["density"], np.zeros(n, np.float32), b["material"],
+                      b["is_dynamic"], color)
 
 
 def build_oracle(cfg_dict, jitter=0.0, seed=0, fixed_iterations=0):
+    """Oracle fed like BaseSolver.prepare() feeds the reference: objects whose entryTime has come at t = 0 are inserted
+    now, the others wait in sim._pending for oracle_step() (base_container.py:218-221)."""
     cfg, geo, batches = scene_particles(cfg_dict)
     sol = scene.derive_solver_constants(cfg)
     total = sum(b["pos"].shape[0] for b in batches)
     pd = scene.params_dict(geo, sol, cfg.get_cfg("simulationMethod"), total, fixed_iterations=fixed_iterations)
     sim = oracle_ref.RefSim(pd)
-    next_id = 0
+    sim._next_id = 0
+    sim._pending = []
+    sim._time = 0.0
+    sim._dt = float(np.float32(sol.dt))   # solver.dt[None] is an f32 field (base_solver.py:35-36)
     for b in batches:
-        n = b["pos"].shape[0]
-        pos = perturb(b["pos"], jitter, seed) if (jitter > 0 and b["material"][0] == 1) else b["pos"]
-        color = np.zeros((n, 3), np.int32)
-        color[:, 0] = np.arange(next_id, next_id + n)
-        next_id += n
-        if b["object_id"] >= 0:
-            sim.set_object(b["object_id"], int(b["material"][0]), 0)
-        sim.add_particles(b["object_id"], pos, b["vel"], b["density"], np.zeros(n, np.float32), b["material"],
-                          b["is_dynamic"], color)
+        if b["entry_time"] > sim._time:
+            sim._pending.append(b)
+        else:
+            _oracle_insert(sim, b, jitter, seed)
     return sim
+
+
+def oracle_step(sim, n=1):
+    """solver.step() of the reference with its host part: _step() inserts the objects that are due in the middle of the
+    step (WCSPH.py:41, DFSPH.py:307, PCISPH.py:181), then total_time advances (base_solver.py:694)."""
+    for _ in range(n):
+        if not sim._pending:
+            sim.step(1)
+        else:
+            sim.step_begin()
+            due = [b for b in sim._pending if not (b["entry_time"] > sim._time)]
+            sim._pending = [b for b in sim._pending if b["entry_time"] > sim._time]
+            for b in due:
+                _oracle_insert(sim, b)
+            sim.step_end()
+        sim._time += sim._dt
 
 
 def oracle_ids(sim):
@@ -87,14 +69,9 @@ def oracle_ids(sim):
 
 
 def build_product(cfg_dict, jitter=0.0, seed=0, **engine_opts):
-    """Product containers driven exactly like run_simulation.py drives the reference."""
-    from sph_project_amd.SPH import containers, fluid_solvers
-    cfg = SimConfig(config=copy.deepcopy(cfg_dict))
-    method = cfg.get_cfg("simulationMethod")
-    ccls = {"wcsph": containers.WCSPHContainer, "dfsph": containers.DFSPHContainer, "pcisph": containers.PCISPHContainer}[method]
-    scls = {"wcsph": fluid_solvers.WCSPHSolver, "dfsph": fluid_solvers.DFSPHSolver, "pcisph": fluid_solvers.PCISPHSolver}[method]
-    container = ccls(cfg, GGUI=False, **engine_opts)
-    solver = scls(container)
+    """Product containers driven exactly like run_simulation.py drives the reference (sph_project_amd.product), plus the
+    tests' seeded perturbation of the fluid lattice."""
+    container, solver = _product.build_product(cfg_dict, **engine_opts)
     if jitter > 0:
         # same perturbed fluid lattice as build_oracle: insert, then overwrite positions before prepare()
         container.insert_object()

@@ -69,6 +69,8 @@ def test_hip_matches_golden(gpu, path, fast_math):
                 # boundary particle keep stale values of earlier steps in the reference)
                 if slot_fluid_step != cp - 1 and not slot_fluid.all():
                     continue
+                if slot_fluid.shape[0] != raw.shape[0]:   # a late entryTime block came in since the last checkpoint
+                    continue
                 scale = max(float(np.abs(z[pre + key]).max()), 1e-30)
                 worst[key] = float(np.abs(raw.astype(np.float64) - z[pre + key].astype(np.float64))[slot_fluid].max()) / scale
                 continue

@@ -212,7 +212,7 @@ def test_c2_full_size_20_steps(gpu):
     """the headline configuration C2 (1,231,200 particles, bench.py's workload, fast build) against the
     oracle for N = 20 steps, plus size-independent checks at full size: accepted-pair counts identical to the oracle's,
     the sort is a permutation (every id once), positions stay inside the clamped domain, no NaNs."""
-    import bench
+    from sph_project_amd import product as bench
     cfg = bench.c2_scene()
     container, solver = H.build_product(cfg, fast_math=1)
     solver.prepare()

@@ -37,8 +37,12 @@ def _oracle_from_fixture(z, cfg):
     geo = scene.derive_geometry(c)
     sol = scene.derive_solver_constants(c)
     n = z["init_positions"].shape[0]
-    pd = scene.params_dict(geo, sol, c.get_cfg("simulationMethod"), n)
+    pd = scene.params_dict(geo, sol, c.get_cfg("simulationMethod"), int(z["geo_particle_max_num"]))
     sim = oracle_ref.RefSim(pd)
+    # objects with a late entryTime are not part of the fixture's initial state: they come from the host lattice
+    # (pinned by test_host_scene_matches_reference_container) and are inserted by H.oracle_step when due
+    sim._next_id, sim._time, sim._dt = n, 0.0, float(np.float32(sol.dt))
+    sim._pending = [b for b in H.scene_particles(cfg)[2] if b["entry_time"] > 0.0]
     obj = z["init_object_ids"]
     for o in np.unique(obj):  # insertion order = ascending index blocks per object
         m = np.nonzero(obj == o)[0]
@@ -73,8 +77,10 @@ def test_host_scene_matches_reference_container(path):
     assert geo.padding == float(z["geo_padding"])
     np.testing.assert_array_equal(geo.grid_num, z["geo_grid_num"])
     _, _, batches = H.scene_particles(cfg)
+    assert sum(b["pos"].shape[0] for b in batches) == int(z["geo_particle_max_num"])
+    batches = [b for b in batches if not b["entry_time"] > 0.0]   # present at prepare()
     pos = np.concatenate([b["pos"] for b in batches])
-    assert pos.shape[0] == int(z["geo_particle_max_num"]) == z["init_positions"].shape[0]
+    assert pos.shape[0] == z["init_positions"].shape[0]
     if float(z["jitter"]) == 0.0:
         np.testing.assert_array_equal(pos, z["init_positions"])
     else:  # jitter is applied by the generator to fluid particles only
@@ -130,9 +136,11 @@ def test_oracle_matches_reference_source(path):
     report = {}
     for cp in z["checkpoints"]:
         while step < cp:
-            sim.step(1)
+            H.oracle_step(sim, 1)
             step += 1
         pre = f"s{cp}_"
+        assert sim.particle_num == z[pre + "ids"].shape[0], (cp, sim.particle_num, z[pre + "ids"].shape[0])
+        np.testing.assert_array_equal(np.sort(H.oracle_ids(sim)), np.sort(z[pre + "ids"]))
         w = _compare(sim, z, pre, geo)
         report[int(cp)] = w
         # iteration counts of the python-side loops (printed by the reference)

@@ -4,7 +4,7 @@ for mode in ${MODES:-0 2 3}; do
   echo "== force_global/debug mode $mode"
   python - <<PY 2>&1 | grep -v "No rigid"
 import sys; sys.path.insert(0,'.')
-import bench
+from sph_project_amd import product as bench
 from tests import helpers as H
 cfg = bench.c2_scene()
 c, s = H.build_product(cfg, fast_math=1, force_global=$mode)

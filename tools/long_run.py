@@ -3,7 +3,7 @@ finite and inside the clamped domain, that the ids are a permutation, and prints
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import bench
+from sph_project_amd import product as bench
 from sph_project_amd import _lib as L
 from tests import helpers as H
 

@@ -1,6 +1,6 @@
 import sys, time
 sys.path.insert(0, '/root/repo')
-import bench
+from sph_project_amd import product as bench
 from tests import helpers as H
 cfg = bench.c2_scene()
 container, solver = H.build_product(cfg, fast_math=1)
