@@ -48,6 +48,7 @@ struct SphHandle {
     std::vector<void *> allocs;
     DevScalars *scal_h = nullptr;  // pinned
     SlabComm comm;
+    long long comm_n_global = 0;   // particle_num of the whole scene (sum of the ranks' owned particles), see sph_prepare
 };
 
 static int fail(SphHandle *h, int code, const char *fmt, ...) {
@@ -101,7 +102,16 @@ static void fill_consts(SphHandle *h) {
     const double hd = p.support_radius;
     c.grid_size = (float)hd;
     c.h = (float)hd;
-    c.h2 = c.h * c.h;
+    // Acceptance test of a neighbour: the reference asks `(x_i - x_j).norm() < dh` (base_container.py:559), the kernels ask
+    // `r2 < h2` without the square root.  sqrtf is monotone and correctly rounded, so there is an exact threshold: the
+    // smallest f32 t with sqrtf(t) >= h.  r2 < t  <=>  sqrtf(r2) < h, bit for bit (lattices put many pairs exactly one
+    // support radius apart; with h2 = h * h those could fall on the other side by one ulp).
+    {
+        float t = c.h * c.h;
+        while (sqrtf(nextafterf(t, 0.0f)) >= c.h) t = nextafterf(t, 0.0f);
+        while (sqrtf(t) < c.h) t = nextafterf(t, INFINITY);
+        c.h2 = t;
+    }
     c.inv_h = 1.0f / c.h;
     float k = (float)(8.0 / M_PI);
     c.kW = k / (float)(hd * hd * hd);
@@ -506,7 +516,12 @@ extern "C" int sph_prepare(SphHandle *h) {
     // compute_rigid_particle_volume (+ DFSPH.py:321 / PCISPH.py:188)
     { ProfScope p(h, SPH_K_MISC); h->L->prepare_emitter(s); h->L->renew_rigid(s); }
     h->pose_dirty = false;
-    if (s.slab_active) { rc = slab_neighbor_search(h); if (rc) return rc; }
+    if (s.slab_active) {
+        double n_own = (double)h->n;   // before any ghost arrives: every particle is owned by exactly one rank
+        rc = sph_comm_allreduce(h, &n_own, 1, 0); if (rc) return rc;
+        h->comm_n_global = (long long)n_own;
+        rc = slab_neighbor_search(h); if (rc) return rc;
+    }
     else ph_neighbor_search(h);
     h->rigid_volume_done = false;
     ph_rigid_volume(h);
@@ -526,7 +541,7 @@ extern "C" int sph_prepare(SphHandle *h) {
 // First half of a step: everything the reference's _step() does before `self.rigid_solver.step()`.
 static int step_first_half(SphHandle *h, bool allow_readback) {
     if (h->in_step) return fail(h, SPH_ERR_INVALID, "sph_step_begin: the previous step was not ended");
-    if (h->st.slab_active && h->prm.method != SPH_METHOD_WCSPH) return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding: wcsph only");
+    if (h->st.slab_active && h->prm.method == SPH_METHOD_PCISPH) return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding: wcsph and dfsph (pcisph's per-iteration ghost exchange is not built)");
     step_begin(h);
     int rc;
     switch (h->prm.method) {
@@ -555,6 +570,11 @@ static int step_second_half(SphHandle *h, bool allow_readback) {
     if (h->prm.method == SPH_METHOD_DFSPH) {
         int rc = dfsph_step_end(h, allow_readback); if (rc) return rc;
         if (h->fresh_state == 1) { h->fresh_state = 2; ph_rigid_volume(h); }  // base_solver.py:696 on the fresh grid: now it sees them
+    } else if (h->fresh_state == 2) {
+        // WCSPH / PCISPH, one step after the insertion: this step's sort took the new body in, so the reference's
+        // end-of-step pass (:696) now finds its particles.  The cell lists of this step's sort are still right for the
+        // rigid particles (static ones have not moved), which is all this pass looks at.
+        ph_rigid_volume(h);
     }
     h->total_time += (double)s.c.dt;  // base_solver.py:694
     h->steps++;

@@ -55,10 +55,10 @@ struct CgPreparePass {
         float s;
         if (AF || bj.w >= 0.0f) {
             const float m_ij = (o.m + a.w) * 0.5f;
-            s = fdiv(fdiv(-c.cv * m_ij, bj.w), r2 + c.visc_eps);
+            s = fdiv2(-c.cv * m_ij, bj.w, r2 + c.visc_eps);
         } else {
             const float m_ij = c.rho0 * a.w;
-            s = fdiv(fdiv(-c.cvb * m_ij, o.rho), r2 + c.visc_eps);
+            s = fdiv2(-c.cvb * m_ij, o.rho, r2 + c.visc_eps);
             const float cb = fdiv(fdiv(c.cvb * c.rho0 * a.w, o.rho) * (bj.x * dx + bj.y * dy + bj.z * dz), r2 + c.visc_eps);
             o.bx += cb * g[0]; o.by += cb * g[1]; o.bz += cb * g[2];
         }
@@ -129,7 +129,7 @@ struct CgApPass {
         float g[3];
         kernGrad(c, dx, dy, dz, geom(c, r2), g[0], g[1], g[2]);
         const float m_ij = (o.m + a.w) * 0.5f;
-        const float s = fdiv(fdiv(-c.cv * m_ij, bj.w), r2 + c.visc_eps);
+        const float s = fdiv2(-c.cv * m_ij, bj.w, r2 + c.visc_eps);
         const float R[3] = {dx, dy, dz};
 #if SPH_FAST
         // (-A) = -s g R^T  =>  Dinv (-A) p = -s (R.p) (Dinv g)
@@ -138,18 +138,21 @@ struct CgApPass {
         o.y += t * (o.d[3] * g[0] + o.d[4] * g[1] + o.d[5] * g[2]);
         o.z += t * (o.d[6] * g[0] + o.d[7] * g[1] + o.d[8] * g[2]);
 #else
-        float nA[9], M[9];
+        // M = Dinv (-A), x += M p, with the roundings of the literal form (nA = -(s (g R^T)); M = Dinv nA; M p summed left
+        // to right) but column by column, so that only one column of nA and of M is alive at a time (the 18 temporaries
+        // of the literal form made this instantiation spill)
+        const float bq[3] = {bj.x, bj.y, bj.z};
+        float t[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) {
+            const float n0 = -(s * (g[0] * R[q])), n1 = -(s * (g[1] * R[q])), n2 = -(s * (g[2] * R[q]));
 #pragma unroll
-            for (int q = 0; q < 3; ++q) nA[p * 3 + q] = -(s * (g[p] * R[q]));
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) M[p * 3 + q] = o.d[p * 3] * nA[q] + o.d[p * 3 + 1] * nA[3 + q] + o.d[p * 3 + 2] * nA[6 + q];
-        o.x += M[0] * bj.x + M[1] * bj.y + M[2] * bj.z;
-        o.y += M[3] * bj.x + M[4] * bj.y + M[5] * bj.z;
-        o.z += M[6] * bj.x + M[7] * bj.y + M[8] * bj.z;
+            for (int p = 0; p < 3; ++p) {
+                const float M = o.d[p * 3] * n0 + o.d[p * 3 + 1] * n1 + o.d[p * 3 + 2] * n2;
+                t[p] = q == 0 ? M * bq[0] : t[p] + M * bq[q];
+            }
+        }
+        o.x += t[0]; o.y += t[1]; o.z += t[2];
 #endif
     }
     __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {

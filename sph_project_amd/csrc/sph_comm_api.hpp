@@ -428,3 +428,58 @@ static int slab_exchange_fields(SphHandle *h) {
     for (int side = 0; side < 2; ++side) h->L->halo_unpack_fields(s, side, c.n_recv[side], c.n_send[side]);
     return SPH_OK;
 }
+
+// ---- ghost refreshes and residual reductions of the sharded iterative solvers (DFSPH)
+// boundary values of the per-particle scalar `arr` -> the neighbours' ghost copies (4 B per boundary particle)
+static int slab_exchange_scalar(SphHandle *h, float *arr) {
+    State &s = h->st;
+    SlabComm &c = h->comm;
+    ProfScope p(h, SPH_K_HALO);
+    for (int side = 0; side < 2; ++side) h->L->halo_pack_scalar(s, side, c.n_send[side], c.n_recv[side], arr);
+    const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
+    void *recv[2] = {s.recvbuf[0], s.recvbuf[1]};
+    const size_t bs[2] = {(size_t)(c.n_send[0] + c.n_recv[0]) * 4, (size_t)(c.n_send[1] + c.n_recv[1]) * 4};
+    size_t br[2] = {bs[0], bs[1]};
+    int rc = comm_exchange(h, send, bs, recv, br, true); if (rc) return rc;
+    for (int side = 0; side < 2; ++side) h->L->halo_unpack_scalar(s, side, c.n_recv[side], c.n_send[side], arr);
+    return SPH_OK;
+}
+
+// velocities of the boundary particles -> ghost copies (16 B records, mass untouched)
+static int slab_exchange_vel(SphHandle *h) {
+    State &s = h->st;
+    SlabComm &c = h->comm;
+    ProfScope p(h, SPH_K_HALO);
+    for (int side = 0; side < 2; ++side) h->L->halo_pack_vel(s, side, c.n_send[side], c.n_recv[side]);
+    const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
+    void *recv[2] = {s.recvbuf[0], s.recvbuf[1]};
+    const size_t bs[2] = {(size_t)(c.n_send[0] + c.n_recv[0]) * 16, (size_t)(c.n_send[1] + c.n_recv[1]) * 16};
+    size_t br[2] = {bs[0], bs[1]};
+    int rc = comm_exchange(h, send, bs, recv, br, true); if (rc) return rc;
+    for (int side = 0; side < 2; ++side) h->L->halo_unpack_vel(s, side, c.n_recv[side], c.n_send[side]);
+    return SPH_OK;
+}
+
+// scal->red[slot] holds this rank's partial sum (k_reduce_partials): make it the sum over all ranks, in device memory, and
+// run the stop test of a device-controlled loop on it.  RCCL: one 4-byte ncclAllReduce on the compute stream, no host sync.
+static int slab_finish_reduction(SphHandle *h, int slot) {
+    State &s = h->st;
+    SlabComm &c = h->comm;
+    ProfScope p(h, SPH_K_HALO);
+    if (c.nranks > 1) {
+        float *red = &s.scal->red[slot];
+        if (c.kind == 1) {
+            NCCLCHK(h, ncclAllReduce(red, red, 1, ncclFloat, ncclSum, (ncclComm_t)c.nccl, s.stream));
+        } else {
+            float v = 0.0f;
+            HIPCHK(h, hipMemcpyAsync(&v, red, sizeof(float), hipMemcpyDeviceToHost, s.stream));
+            HIPCHK(h, hipStreamSynchronize(s.stream));
+            double d = (double)v;
+            int rc = sph_comm_allreduce(h, &d, 1, 0); if (rc) return rc;
+            v = (float)d;
+            HIPCHK(h, hipMemcpy(red, &v, sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
+    h->L->loop_criterion(s, slot);
+    return SPH_OK;
+}

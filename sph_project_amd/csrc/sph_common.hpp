@@ -173,6 +173,11 @@ struct Launch {
     void (*halo_build_tables)(State &);
     void (*halo_pack_fields)(State &, int side, int n_send, int n_recv);
     void (*halo_unpack_fields)(State &, int side, int n_recv, int n_send);
+    void (*halo_pack_scalar)(State &, int side, int n_send, int n_recv, const float *src);
+    void (*halo_unpack_scalar)(State &, int side, int n_recv, int n_send, float *dst);
+    void (*halo_pack_vel)(State &, int side, int n_send, int n_recv);
+    void (*halo_unpack_vel)(State &, int side, int n_recv, int n_send);
+    void (*loop_criterion)(State &, int slot);   // stop test on an all-reduced residual (sharded solver loops)
     // implicit viscosity (CG)
     void (*cg_prepare)(State &);
     void (*cg_ap)(State &);

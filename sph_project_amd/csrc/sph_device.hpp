@@ -28,6 +28,15 @@ __device__ __forceinline__ float fdiv(float a, float b) {
     return a / b;
 #endif
 }
+// (a / b) / c: the strict build keeps the reference's two divisions; the fast build spends one reciprocal
+// (v_rcp_f32 issues at a quarter of the plain VALU rate) on b * c
+__device__ __forceinline__ float fdiv2(float a, float b, float c) {
+#if SPH_FAST
+    return a * __builtin_amdgcn_rcpf(b * c);
+#else
+    return (a / b) / c;
+#endif
+}
 __device__ __forceinline__ float fsqrt(float a) {
 #if SPH_FAST
     return __builtin_amdgcn_sqrtf(a);
@@ -214,16 +223,28 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int *s_w, int &total) 
     return off + inc - v;
 }
 
+// Tile layout of both scan kernels: a tile is SCAN_TILE = 2048 consecutive cells = two chunks of 1024; thread t owns
+// cells [4t, 4t + 4) of either chunk, so that every load / store instruction of a wave is one contiguous 1 KiB
+// (16 B per lane) -- the per-thread-contiguous layout (8 consecutive ints per thread, 32 B lane stride) this replaces
+// moved the same bytes with 8 strided dword instructions per thread and ran at a third of the copy rate.
+__device__ __forceinline__ int4 scan_load4(const int *__restrict__ in, int idx, int n) {
+    int4 v = make_int4(0, 0, 0, 0);
+    if (idx + 3 < n) v = *reinterpret_cast<const int4 *>(in + idx);
+    else { if (idx < n) v.x = in[idx]; if (idx + 1 < n) v.y = in[idx + 1]; if (idx + 2 < n) v.z = in[idx + 2]; }
+    return v;
+}
+
 __global__ void __launch_bounds__(SCAN_TPB)
 k_scan_reduce(const int *__restrict__ in, int n, int *__restrict__ partial) {
     __shared__ int s_w[SCAN_TPB / 64];
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_IPT;
-    int s = 0;
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+    const int4 a = scan_load4(in, base, n), b = scan_load4(in, base + SCAN_TILE / 2, n);
+    int s = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
 #pragma unroll
-    for (int k = 0; k < SCAN_IPT; ++k) { int idx = base + k; s += idx < n ? in[idx] : 0; }
-    int tot;
-    block_excl_scan_256(s, s_w, tot);
-    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
 __global__ void __launch_bounds__(SCAN_TPB)
@@ -236,23 +257,30 @@ k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *
         scal->pairs[clear_bank][blockIdx.x * SCAN_TPB + threadIdx.x] = 0ull;
         scal->fallback[clear_bank][blockIdx.x * SCAN_TPB + threadIdx.x] = 0ull;
     }
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_IPT;
-    int v[SCAN_IPT];
-    int s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_IPT; ++k) { int idx = base + k; v[k] = idx < n ? in[idx] : 0; s += v[k]; }
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+    const int4 a = scan_load4(in, base, n), b = scan_load4(in, base + SCAN_TILE / 2, n);
     // offset of this tile = sum of the tile sums before it (every workgroup adds them up itself: a few thousand ints
     // out of L2 instead of a third launch)
     int before = 0;
     for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_TPB) before += partial[k];
-    int tot, btot;
+    int tot0, tot1, btot;
     block_excl_scan_256(before, s_w, btot);
-    int ex = block_excl_scan_256(s, s_w, tot) + btot;
+    const int sa = (a.x + a.y) + (a.z + a.w), sb = (b.x + b.y) + (b.z + b.w);
+    int ea = block_excl_scan_256(sa, s_w, tot0) + btot;
+    int eb = block_excl_scan_256(sb, s_w, tot1) + btot + tot0;
+    const int4 oa = make_int4(ea, ea + a.x, ea + a.x + a.y, ea + a.x + a.y + a.z);
+    const int4 ob = make_int4(eb, eb + b.x, eb + b.x + b.y, eb + b.x + b.y + b.z);
+    const int4 zero = make_int4(0, 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < SCAN_IPT; ++k) {
-        int idx = base + k;
-        if (idx < n) { out[idx] = ex; in[idx] = 0; }
-        ex += v[k];
+    for (int h = 0; h < 2; ++h) {
+        const int idx = base + h * (SCAN_TILE / 2);
+        const int4 o = h ? ob : oa;
+        if (idx + 3 < n) { *reinterpret_cast<int4 *>(out + idx) = o; *reinterpret_cast<int4 *>(in + idx) = zero; }
+        else {
+            if (idx < n) { out[idx] = o.x; in[idx] = 0; }
+            if (idx + 1 < n) { out[idx + 1] = o.y; in[idx + 1] = 0; }
+            if (idx + 2 < n) { out[idx + 2] = o.z; in[idx + 2] = 0; }
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total_particles;
 }
@@ -336,6 +364,23 @@ __device__ __forceinline__ void lds_load_chunk_imm(unsigned a, v2f (&xy)[8], flo
         : "v"(a), "n"(ZW_OFF)
         : "memory");
 }
+// 4 candidates per LDS round trip: half the registers of the 8-candidate chunk (what lets the density pass run 5
+// workgroups per CU without spilling, see nbr_waves_per_simd)
+template <int ZW_OFF>
+__device__ __forceinline__ void lds_load_half_imm(unsigned a, v2f (&xy)[4], float (&z)[4]) {
+    asm volatile(
+        "ds_read_b64 %0, %8\n\tds_read_b32 %4, %8 offset:%9\n\t"
+        "ds_read_b64 %1, %8 offset:8\n\tds_read_b32 %5, %8 offset:%9+8\n\t"
+        "ds_read_b64 %2, %8 offset:16\n\tds_read_b32 %6, %8 offset:%9+16\n\t"
+        "ds_read_b64 %3, %8 offset:24\n\tds_read_b32 %7, %8 offset:%9+24\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(xy[0]), "=&v"(xy[1]), "=&v"(xy[2]), "=&v"(xy[3]), "=&v"(z[0]), "=&v"(z[1]), "=&v"(z[2]), "=&v"(z[3])
+        : "v"(a), "n"(ZW_OFF)
+        : "memory");
+}
+#ifndef SPH_P1_CHUNK
+#define SPH_P1_CHUNK 4   // candidates per LDS round trip of the unrolled phase 1 (8: r01 layout, 4: fits 96 VGPRs)
+#endif
 typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
 typedef __attribute__((address_space(3))) const int lds_ci32;
 __device__ __forceinline__ int lds_ld_i32(const int *p) { return *(lds_ci32 *)p; }
@@ -350,6 +395,16 @@ __device__ __forceinline__ float2 lds_ld2a(unsigned byte_addr) {  // plain (sche
 // a single fluid particle (the bulk of a scene with a sampled domain box) need not be launched at all.
 template <class P, class = void> struct PassFluidOnly { static constexpr bool value = false; };
 template <class P> struct PassFluidOnly<P, decltype((void)P::FLUID_BLOCKS_ONLY)> { static constexpr bool value = P::FLUID_BLOCKS_ONLY; };
+
+// P::MODES: which MASKMODE instantiations of k_nbr_pass a functor is ever launched with (bit m = mode m).  Default: 0 and 2
+// (a pass that reuses the masks stored by the first pass after a sort, with mode 0 as its fallback when none are valid).
+// The passes that run first after a sort (density, DFSPH density + alpha) declare 0 | 1, the rigid volume pass 0 only.
+// Instantiating only what can run keeps dead, register-hungry variants (the unrolled phase 1 inside a force pass) out
+// of the code object; a mask-reusing pass also takes the lean one-candidate-at-a-time phase 1 in its mode-0 fallback.
+template <class P, class = void> struct PassModes { static constexpr int value = 0b101; };
+template <class P> struct PassModes<P, decltype((void)P::MODES)> { static constexpr int value = P::MODES; };
+template <class P> constexpr bool pass_builds_masks() { return (PassModes<P>::value & 0b010) != 0; }
+template <class P> constexpr bool pass_reuses_masks() { return (PassModes<P>::value & 0b100) != 0; }
 
 // Optional second per-candidate payload (P::HAS_C, P::CT): staged into its own LDS array; stage() and pair() of
 // such a functor take it as one more argument.
@@ -401,15 +456,31 @@ __device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int
         // All 16 ds_read_b64 of the chunk are issued back to back from one base register with immediate
         // offsets and waited for once (hand-placed: left to itself the scheduler keeps at most one candidate
         // in flight, or fuses neighbours into ds_read2_b64 = 8 LDS cycles per 16 bytes).
-        v2f xy[8];
-        float zz[8];
-        lds_load_chunk_imm<ZW_OFF>(lds_addr(&sXY[base + t0]), xy, zz);
+        if constexpr (SPH_P1_CHUNK == 8) {
+            v2f xy[8];
+            float zz[8];
+            lds_load_chunk_imm<ZW_OFF>(lds_addr(&sXY[base + t0]), xy, zz);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zz[u];
-            const float r2 = dx * dx + dy * dy + dz * dz;
-            asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                : "+v"(mask) : "v"(r2), "v"(h2) : "vcc");  // not volatile: ordered by the dependence on mask
+            for (int u = 0; u < 8; ++u) {
+                const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zz[u];
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                    : "+v"(mask) : "v"(r2), "v"(h2) : "vcc");  // not volatile: ordered by the dependence on mask
+            }
+        } else {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                v2f xy[4];
+                float zz[4];
+                lds_load_half_imm<ZW_OFF>(lds_addr(&sXY[base + t0 + 4 * hh]), xy, zz);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zz[u];
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                        : "+v"(mask) : "v"(r2), "v"(h2) : "vcc");
+                }
+            }
         }
         S += 8;
     }
@@ -441,7 +512,7 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
                 // permutation)
                 nm = m > 0 ? (it == 0 ? stored : stored_hi) : 0u;
             } else {
-                nm = phase1_mask<ZW_OFF, MASKMODE == 2>(sXY, base, m, xi, yi, zi, c.h2);
+                nm = phase1_mask<ZW_OFF, MASKMODE == 2 || pass_reuses_masks<P>()>(sXY, base, m, xi, yi, zi, c.h2);
                 const unsigned self = (unsigned)(i - j0);
                 if (self < 32u) nm &= ~(1u << self);                 // p_i != p_j (base_container.py:559)
                 if (MASKMODE == 1 && it == 0) *store_to = nm;
@@ -651,12 +722,22 @@ template <class P> constexpr int nbr_tile_cap() {
 #define NBR_STAMP(k) do { } while (0)
 #endif
 template <class P, int MASKMODE> constexpr int nbr_lds_bytes() {
-    return (nbr_tile_cap<P>() + (MASKMODE == 2 ? 0 : NBR_PAD)) * (16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0)) + 9 * NBR_CS_PITCH * 2 + 64;
+    return (nbr_tile_cap<P>() + ((MASKMODE == 2 || pass_reuses_masks<P>()) ? 0 : NBR_PAD)) * (16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0)) + 9 * NBR_CS_PITCH * 2 + 64;
 }
-// Second launch bound = minimum waves per SIMD = workgroups per CU: 4, i.e. <= 128 VGPRs.  Five (<= 96 VGPRs) fits
-// the LDS footprint of most mask-reusing passes and was 10-15 % faster while they compiled without spills; with the
-// two-word (64-candidate) masks they no longer do, and spilled code at 5 is slower than clean code at 4 (DFSPH C3: 1.53 vs 1.43 ms).
-template <class P, int MASKMODE> constexpr int nbr_waves_per_simd() { return 4; }
+// Second launch bound = minimum waves per SIMD = workgroups per CU.  Default 4 (<= 128 VGPRs).  The payload-free functors
+// with a one- or two-word accumulator (density, rigid volume: 23.7 KB of LDS) run 5 (<= 96 VGPRs) in the fast build: with
+// the 4-candidate phase-1 chunks and without SLP packing they fit without spilling, and the density pass of C2 went
+// 141 -> 127 us (profiles/r02_ab_*.txt).  The functors with payload arrays are capped at 4 by their 33-38 KB tiles; the
+// strict build and the 5-float DFSPH density+alpha accumulator spill at 96 and stay at 4 (tools/check_spills.py gates).
+#ifndef SPH_NBR_WAVES_LIGHT
+#define SPH_NBR_WAVES_LIGHT (SPH_FAST ? 5 : 4)
+#endif
+#ifndef SPH_NBR_WAVES_HEAVY
+#define SPH_NBR_WAVES_HEAVY 4
+#endif
+template <class P, int MASKMODE> constexpr int nbr_waves_per_simd() {
+    return P::HAS_B ? SPH_NBR_WAVES_HEAVY : (sizeof(typename P::Own) <= 8 ? SPH_NBR_WAVES_LIGHT : 4);
+}
 template <class P, int MASKMODE>
 __global__ void __launch_bounds__(P::BLOCK, (nbr_waves_per_simd<P, MASKMODE>()))
 k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevScalars *__restrict__ scal,
@@ -673,7 +754,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     static_assert(P::GROUPS == 3 && BLOCK == 256, "lane permutation is stored as one byte per particle");
     typedef typename P::Own Own;
     typedef typename P::BT BT;
-    constexpr int PAD = MASKMODE == 2 ? 0 : NBR_PAD;   // only the unrolled phase 1 reads past a run's end
+    constexpr int PAD = (MASKMODE == 2 || pass_reuses_masks<P>()) ? 0 : NBR_PAD;   // only the unrolled phase 1 reads past a run's end
     __shared__ float2 sT[2 * (CAP + PAD)];   // (x,y) slots followed by (z,w) slots: fixed byte distance
     float2 *const sXY = sT;
     float2 *const sZW = sT + (CAP + PAD);
@@ -854,8 +935,9 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                         nm = mk[q]; nh = mh[q];   // zero where the run is empty / has no second chunk (not loaded)
                     } else {
                         const int mlo = m_[q] < 32 ? m_[q] : 32;
-                        nm = c.force_global == 13 ? 0u : phase1_mask<ZW_OFF>(sXY, base, mlo, pi.x, pi.y, pi.z, c.h2);
-                        if (anywide) nh = phase1_mask<ZW_OFF>(sXY, m_[q] > 32 ? base + 32 : 0, m_[q] > 32 ? m_[q] - 32 : 0, pi.x, pi.y, pi.z, c.h2);
+                        constexpr bool LEAN1 = pass_reuses_masks<P>();
+                        nm = c.force_global == 13 ? 0u : phase1_mask<ZW_OFF, LEAN1>(sXY, base, mlo, pi.x, pi.y, pi.z, c.h2);
+                        if (anywide) nh = phase1_mask<ZW_OFF, LEAN1>(sXY, m_[q] > 32 ? base + 32 : 0, m_[q] > 32 ? m_[q] - 32 : 0, pi.x, pi.y, pi.z, c.h2);
                         const unsigned self = (unsigned)(i - js_[q]);
                         if (self < 32u) nm &= ~(1u << self);      // p_i != p_j (base_container.py:559)
                         else if (self < 64u) nh &= ~(1u << (self - 32u));

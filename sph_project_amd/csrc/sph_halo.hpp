@@ -149,3 +149,48 @@ k_halo_unpack_fields(int n_recv, int n_send, const int *ghost_slots, const int *
     const float4 q = buf[k];
     rho_raw[s] = q.x; rho[s] = q.y; prs[s] = q.z; ptm[s] = q.w;
 }
+
+// ---- per-pass ghost refreshes of the iterative solvers (DFSPH / PCISPH exchange kappa (4 B) and v (12 B) of
+// the boundary particles once per solver iteration).  Same slot tables and message layout as the density / pressure
+// exchange above: message to `side` = [ my n_send records | the n_recv records I got from that side ].
+__global__ void __launch_bounds__(256)
+k_halo_pack_scalar(int n_send, int n_recv, const int *send_slots, const int *echo_slots, const float *src, float *buf) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_send + n_recv) return;
+    const int s = k < n_send ? send_slots[k] : echo_slots[k - n_send];
+    buf[k] = s >= 0 ? src[s] : 0.0f;
+}
+__global__ void __launch_bounds__(256)
+k_halo_unpack_scalar(int n_recv, int n_send, const int *ghost_slots, const int *echo_ghost_slots, const float *buf, float *dst) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_recv + n_send) return;
+    const int s = k < n_recv ? ghost_slots[k] : echo_ghost_slots[k - n_recv];
+    if (s >= 0) dst[s] = buf[k];
+}
+__global__ void __launch_bounds__(256)
+k_halo_pack_vel(int n_send, int n_recv, const int *send_slots, const int *echo_slots, const float4 *velm, float4 *buf) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_send + n_recv) return;
+    const int s = k < n_send ? send_slots[k] : echo_slots[k - n_send];
+    buf[k] = s >= 0 ? velm[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void __launch_bounds__(256)
+k_halo_unpack_vel(int n_recv, int n_send, const int *ghost_slots, const int *echo_ghost_slots, const float4 *buf, float4 *velm) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_recv + n_send) return;
+    const int s = k < n_recv ? ghost_slots[k] : echo_ghost_slots[k - n_recv];
+    if (s < 0) return;
+    const float4 q = buf[k];
+    float4 v = velm[s];
+    v.x = q.x; v.y = q.y; v.z = q.z;    // the mass of the ghost copy arrived with its record
+    velm[s] = v;
+}
+
+// Stop test of a device-controlled solver loop on a residual that was all-reduced over the ranks behind
+// k_reduce_partials (which, under sharding, only leaves this rank's sum in scal->red[slot]).
+__global__ void k_loop_criterion(DevScalars *scal, int slot, int kind, float denom, double thr) {
+    if (scal->flags[0]) return;
+    const float avg = denom > 0.0f ? scal->red[slot] / denom : 0.0f;
+    scal->flags[1] += 1;
+    if (kind == 1 ? ((double)avg <= thr) : (avg < (float)thr)) scal->flags[0] = 1;
+}

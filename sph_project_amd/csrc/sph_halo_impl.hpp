@@ -42,3 +42,28 @@ static void l_halo_unpack_fields(State &s, int side, int n_recv, int n_send) {
                        s.halo_tab[HALO_GHOST - 1 + side], s.halo_tab[HALO_ECHO_GHOST - 1 + side], s.recvbuf[side], s.rho_raw,
                        s.rho.cur(), s.prs, s.ptm);
 }
+
+static void l_halo_pack_scalar(State &s, int side, int n_send, int n_recv, const float *src) {
+    if (n_send + n_recv <= 0) return;
+    hipLaunchKernelGGL(k_halo_pack_scalar, dim3(cdiv(n_send + n_recv, 256)), dim3(256), 0, s.stream, n_send, n_recv,
+                       s.halo_tab[HALO_SEND - 1 + side], s.halo_tab[HALO_ECHO_SEND - 1 + side], src, (float *)s.sendbuf[side]);
+}
+static void l_halo_unpack_scalar(State &s, int side, int n_recv, int n_send, float *dst) {
+    if (n_send + n_recv <= 0) return;
+    hipLaunchKernelGGL(k_halo_unpack_scalar, dim3(cdiv(n_send + n_recv, 256)), dim3(256), 0, s.stream, n_recv, n_send,
+                       s.halo_tab[HALO_GHOST - 1 + side], s.halo_tab[HALO_ECHO_GHOST - 1 + side], (const float *)s.recvbuf[side], dst);
+}
+static void l_halo_pack_vel(State &s, int side, int n_send, int n_recv) {
+    if (n_send + n_recv <= 0) return;
+    hipLaunchKernelGGL(k_halo_pack_vel, dim3(cdiv(n_send + n_recv, 256)), dim3(256), 0, s.stream, n_send, n_recv,
+                       s.halo_tab[HALO_SEND - 1 + side], s.halo_tab[HALO_ECHO_SEND - 1 + side], s.velm.cur(), s.sendbuf[side]);
+}
+static void l_halo_unpack_vel(State &s, int side, int n_recv, int n_send) {
+    if (n_send + n_recv <= 0) return;
+    hipLaunchKernelGGL(k_halo_unpack_vel, dim3(cdiv(n_send + n_recv, 256)), dim3(256), 0, s.stream, n_recv, n_send,
+                       s.halo_tab[HALO_GHOST - 1 + side], s.halo_tab[HALO_ECHO_GHOST - 1 + side], s.recvbuf[side], s.velm.cur());
+}
+static void l_loop_criterion(State &s, int slot) {
+    if (!s.loop_flag || s.loop_slot != slot) return;
+    hipLaunchKernelGGL(k_loop_criterion, dim3(1), dim3(1), 0, s.stream, s.scal, slot, s.loop_kind, s.loop_denom, s.loop_thr);
+}

@@ -97,6 +97,7 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     // lane permutation (k_lane_perm): only for the passes that reuse stored masks -- a pass that runs phase 1 keeps
     // neighbouring lanes on neighbouring cells, which is what makes its LDS reads conflict-free
     if (s.perm_n != n) l_block_prep(s);   // particles were appended since the last sort
+    if (!(PassModes<P>::value & (1 << mask_mode))) mask_mode = 0;
     const unsigned char *perm = (mask_mode == 2 && s.lane_perm) ? s.lane_perm : nullptr;
     // workgroups without fluid are not launched for functors that have nothing to do there
     const bool use_list = PassFluidOnly<P>::value && !s.c.all_fluid && s.list_n == n && s.c.force_global == 0;
@@ -104,14 +105,17 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     if (P::HAS_REDUCE) s.last_pass_listed = use_list ? 1 : 0;   // whose partial sums l_reduce_sum will finish
     unsigned long long *tl = (s.c.force_global == 20 && (size_t)nb * 16 * 8 <= (size_t)s.cap * 4) ? (unsigned long long *)s.tmp_idx : nullptr;
     if (tl) hipMemsetAsync(tl, 0, (size_t)nb * 16 * 8, s.stream);
+    constexpr int MODES = PassModes<P>::value;
+    if (!(MODES & (1 << mask_mode))) mask_mode = 0;   // every functor has mode 0
+#define SPH_LAUNCH_NBR(M) hipLaunchKernelGGL((k_nbr_pass<P, M>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc)
     if (mask_mode == 1) {
-        hipLaunchKernelGGL((k_nbr_pass<P, 1>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc);
-        s.masks_valid = 1;
+        if constexpr ((MODES & 0b010) != 0) { SPH_LAUNCH_NBR(1); s.masks_valid = 1; }
     } else if (mask_mode == 2) {
-        hipLaunchKernelGGL((k_nbr_pass<P, 2>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc);
+        if constexpr ((MODES & 0b100) != 0) { SPH_LAUNCH_NBR(2); }
     } else {
-        hipLaunchKernelGGL((k_nbr_pass<P, 0>), dim3(nb), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc);
+        SPH_LAUNCH_NBR(0);
     }
+#undef SPH_LAUNCH_NBR
     if (tl) {   // debug: mean shader-clock deltas between the phase stamps of k_nbr_pass (tmp_idx is free between sorts)
         static int shown = 0;
         hipStreamSynchronize(s.stream);
@@ -320,6 +324,9 @@ const Launch *SPH_LAUNCH_FN() {
         L.halo_classify_pack = l_halo_classify_pack; L.halo_unpack_append = l_halo_unpack_append;
         L.halo_build_tables = l_halo_build_tables; L.halo_pack_fields = l_halo_pack_fields;
         L.halo_unpack_fields = l_halo_unpack_fields;
+        L.halo_pack_scalar = l_halo_pack_scalar; L.halo_unpack_scalar = l_halo_unpack_scalar;
+        L.halo_pack_vel = l_halo_pack_vel; L.halo_unpack_vel = l_halo_unpack_vel;
+        L.loop_criterion = l_loop_criterion;
         init = true;
     }
     return &L;

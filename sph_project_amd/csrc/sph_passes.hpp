@@ -17,6 +17,7 @@ __device__ __forceinline__ void add_wrench(DevScalars *scal, int obj, float fx, 
 // Algorithmic HBM bytes / particle: R posv 16 -> W rho 4 (+ rho_raw 4, prs 4, ptm 4 with EOS).
 template <bool AF, bool EOS>
 struct DensityPass {
+    static constexpr int MODES = 0b011;               // first pass after a sort: computes and stores the acceptance masks
     static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
@@ -130,13 +131,13 @@ struct NonPressurePass {
             kernGrad(c, dx, dy, dz, g, gx, gy, gz);
             const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
             const float m_ij = (o.m + a.w) * 0.5f;
-            const float cc = fdiv(fdiv(c.cv * m_ij, bj.w), rn2 + c.visc_eps) * v_xy;
+            const float cc = fdiv2(c.cv * m_ij, bj.w, rn2 + c.visc_eps) * v_xy;
             o.ax += cc * gx; o.ay += cc * gy; o.az += cc * gz;
         } else {
             if (skip_viscosity) return;
             kernGrad(c, dx, dy, dz, g, gx, gy, gz);
             const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
-            const float cc = fdiv(fdiv(c.cvb * a.w, o.rho), rn2 + c.visc_eps) * v_xy;
+            const float cc = fdiv2(c.cvb * a.w, o.rho, rn2 + c.visc_eps) * v_xy;
             const float acx = cc * gx, acy = cc * gy, acz = cc * gz;
             o.ax += acx; o.ay += acy; o.az += acz;
             if (bj.w == -2.0f) {  // dynamic rigid neighbour: base_solver.py:272-278
@@ -332,12 +333,12 @@ struct WcsphForcePass {
             const float w = r2 > c.diameter2 ? kernW(c, g) : c.Wd;
             o.sx -= (cst * dx) * w; o.sy -= (cst * dy) * w; o.sz -= (cst * dz) * w;
             const float m_ij = (o.m + a.w) * 0.5f;                      // viscosity (:232)
-            const float cc = fdiv(fdiv(c.cv * m_ij, bj.w), rn2 + c.visc_eps) * v_xy;
+            const float cc = fdiv2(c.cv * m_ij, bj.w, rn2 + c.visc_eps) * v_xy;
             o.ax += cc * gx; o.ay += cc * gy; o.az += cc * gz;
             const float cp = -a.w * (o.pt + cj);                        // pressure (:136)
             o.px += cp * gx; o.py += cp * gy; o.pz += cp * gz;
         } else {
-            const float cc = fdiv(fdiv(c.cvb * a.w, o.rho), rn2 + c.visc_eps) * v_xy;
+            const float cc = fdiv2(c.cvb * a.w, o.rho, rn2 + c.visc_eps) * v_xy;
             const float acx = cc * gx, acy = cc * gy, acz = cc * gz;
             o.ax += acx; o.ay += acy; o.az += acz;
             const float cp = fdiv(-a.w * o.p, o.rho2);
@@ -389,6 +390,7 @@ struct WcsphForcePass {
 // ---------------------------------------------------------------------------------------
 // base_solver.py:106 compute_rigid_particle_volume (+task :117).  i rigid, j same object.
 struct RigidVolumePass {
+    static constexpr int MODES = 0b001;               // runs before the density pass (no masks yet), rarely
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = false;
     static constexpr bool HAS_B = false, COUNT_PAIRS = false;

@@ -8,6 +8,7 @@
 // Bytes / particle: R posv 16 -> W rho 4 + alpha 4.
 template <bool AF>
 struct DfsphDensityAlphaPass {
+    static constexpr int MODES = 0b011;               // first pass after a sort: computes and stores the acceptance masks
     static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
@@ -25,9 +26,10 @@ struct DfsphDensityAlphaPass {
     __device__ float4 loadA(int j) const { return stage_impl(j); }
     __device__ BT loadB(int) const { return 0; }
     __device__ float4 stage(const Consts &, int j, BT &) const { return stage_impl(j); }
-    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
+    __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
         o.sum = o.s3 = o.gx = o.gy = o.gz = 0.0f;
-        return AF || META_MAT(meta[i]) == 1;
+        if (AF && !c.ghosts) return true;
+        return META_ACTIVE_FLUID(meta[i]);   // slab sharding: ghost copies are neighbours only
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a, const BT &,
                          int) const {
@@ -75,8 +77,8 @@ struct DfsphRhoAdvPass {
         bj.x = v.x; bj.y = v.y; bj.z = v.z;
         return ldg_idx(posv, j);
     }
-    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
-        if (!AF && META_MAT(meta[i]) != 1) return false;
+    __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
+        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
         const float4 v = velm[i];
         o.vx = v.x; o.vy = v.y; o.vz = v.z; o.sum = 0.0f; o.cnt = 0;
         return true;
@@ -134,8 +136,8 @@ struct DfsphCorrectPass {
     __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
-    __device__ bool begin(const Consts &, int i, const float4 &pi, Own &o) const {
-        if (!AF && META_MAT(meta[i]) != 1) return false;
+    __device__ bool begin(const Consts &c, int i, const float4 &pi, Own &o) const {
+        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
         o.k = kappa[i]; o.rho = rho[i];
         if (MODE == 1) { const float4 v = velm[i]; o.vx = v.x; o.vy = v.y; o.vz = v.z; }
         else { o.vx = o.vy = o.vz = 0.0f; }

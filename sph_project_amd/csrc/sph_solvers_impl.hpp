@@ -35,7 +35,9 @@ static void l_advect_boundary(State &s) {
 }
 
 static void l_reduce_sum(State &s, int slot, int nblocks) {
-    const int kind = (s.loop_flag && s.loop_slot == slot) ? s.loop_kind : 0;
+    // under slab sharding the residual is a sum over ranks: this kernel leaves the local sum, the step orchestration
+    // all-reduces it and runs the stop test (slab_finish_reduction, k_loop_criterion)
+    const int kind = (s.loop_flag && s.loop_slot == slot && !s.slab_active) ? s.loop_kind : 0;
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s.stream, s.red_partial, nblocks, s.scal, slot, kind,
                        s.loop_denom, s.loop_thr, s.last_pass_listed ? s.blk_list : nullptr, s.last_pass_listed ? s.blk_count : nullptr);
 }

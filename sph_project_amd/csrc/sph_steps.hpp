@@ -13,6 +13,9 @@ static int read_red(SphHandle *h, int slot, float *out) {
 
 static int implicit_viscosity_non_pressure(SphHandle *h);
 
+// particle_num the reference's residual means divide by (DFSPH.py:212, :293): the whole scene's, not this slab's
+static long long dfsph_particle_num(SphHandle *h) { return h->st.slab_active ? h->comm_n_global : (long long)h->n; }
+
 // Solver loop with the stop test on the device.  `body` launches one iteration; its last reduction kernel evaluates
 // the reference's criterion (kind / denom / thr, see State::loop_kind), counts the iteration and raises
 // scal->flags[0]; every kernel of a later iteration starts with a look at that flag and returns.  Iterations go out in
@@ -80,28 +83,36 @@ static int dfsph_divergence(SphHandle *h, bool allow_readback) {
     { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 0); }
     int itr = 0;
     float avg = 0.0f;
+    const float n_all = (float)dfsph_particle_num(h);   // DFSPH.py:212 divides by particle_num (every rank's, under sharding)
+    int comm_rc = SPH_OK;
+    // one solver iteration; under slab sharding the ghosts' kappa_v goes out before the correction and their velocities
+    // after it, and the residual is summed over the ranks
+    auto iteration = [&]() {
+        std::swap(s.kappa_v, s.kappa_v_next);  // DFSPH.py:133 compute_kappa_v: value of the last density-derivative pass
+        if (s.slab_active && !comm_rc) comm_rc = slab_exchange_scalar(h, s.kappa_v);
+        { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 0); }
+        if (s.slab_active && !comm_rc) comm_rc = slab_exchange_vel(h);
+        { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 0); }
+        if (s.slab_active && !comm_rc) comm_rc = slab_finish_reduction(h, 0);
+    };
     if (fixed <= 0 && allow_readback) {
         const double eta = 0.001 * h->prm.density_0 / (double)s.c.dt;  // :150
         int launched = 0; float sum = 0.0f;
-        int rc = device_loop(h, max_itr, 0, 1, (float)h->n, eta, [&]() {
-            std::swap(s.kappa_v, s.kappa_v_next);
-            { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 0); }
-            { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 0); }
-        }, &itr, &launched, &sum);
+        int rc = device_loop(h, max_itr, 0, 1, n_all, eta, iteration, &itr, &launched, &sum);
         if (rc) return rc;
+        if (comm_rc) return comm_rc;
         if ((launched - itr) & 1) std::swap(s.kappa_v, s.kappa_v_next);   // iterations past the stop did not run
-        h->last.iter_divergence = itr; h->last.err_divergence = sum / (float)h->n;
+        h->last.iter_divergence = itr; h->last.err_divergence = sum / n_all;
         return SPH_OK;
     }
     while (itr < 1 || itr < max_itr) {
-        std::swap(s.kappa_v, s.kappa_v_next);  // DFSPH.py:133 compute_kappa_v: value of the last density-derivative pass
-        { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 0); }
-        { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 0); }
+        iteration();
+        if (comm_rc) return comm_rc;
         itr++;
         if (fixed > 0) continue;
         if (!allow_readback) return fail(h, SPH_ERR_UNSUPPORTED, "dfsph needs host read-back unless fixed_iterations > 0");
         float sum; int rc = read_red(h, 0, &sum); if (rc) return rc;
-        avg = sum / (float)h->n;                                    // DFSPH.py:212 (divides by particle_num)
+        avg = sum / n_all;                                          // DFSPH.py:212 (divides by particle_num)
         const double eta = 0.001 * h->prm.density_0 / (double)s.c.dt;  // :150
         if ((double)avg <= eta) break;
     }
@@ -117,27 +128,33 @@ static int dfsph_density(SphHandle *h, bool allow_readback) {
     { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 1); }
     int itr = 0;
     float avg = 0.0f;
+    const float n_all = (float)dfsph_particle_num(h);
+    int comm_rc = SPH_OK;
+    auto iteration = [&]() {
+        std::swap(s.kappa, s.kappa_next);      // DFSPH.py:218 compute_kappa
+        if (s.slab_active && !comm_rc) comm_rc = slab_exchange_scalar(h, s.kappa);
+        { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 1); }
+        if (s.slab_active && !comm_rc) comm_rc = slab_exchange_vel(h);
+        { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 1); }
+        if (s.slab_active && !comm_rc) comm_rc = slab_finish_reduction(h, 1);
+    };
     if (fixed <= 0 && allow_readback) {
         int launched = 0; float sum = 0.0f;
-        int rc = device_loop(h, max_itr, 1, 1, (float)h->n, 0.0001, [&]() {   // :239
-            std::swap(s.kappa, s.kappa_next);
-            { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 1); }
-            { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 1); }
-        }, &itr, &launched, &sum);
+        int rc = device_loop(h, max_itr, 1, 1, n_all, 0.0001, iteration, &itr, &launched, &sum);   // :239
         if (rc) return rc;
+        if (comm_rc) return comm_rc;
         if ((launched - itr) & 1) std::swap(s.kappa, s.kappa_next);
-        h->last.iter_density = itr; h->last.err_density = sum / (float)h->n;
+        h->last.iter_density = itr; h->last.err_density = sum / n_all;
         return SPH_OK;
     }
     while (itr < 1 || itr < max_itr) {
-        std::swap(s.kappa, s.kappa_next);      // DFSPH.py:218 compute_kappa
-        { ProfScope p(h, SPH_K_DFSPH_CORRECT); h->L->dfsph_correct(s, 1); }
-        { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 1); }
+        iteration();
+        if (comm_rc) return comm_rc;
         itr++;
         if (fixed > 0) continue;
         if (!allow_readback) return fail(h, SPH_ERR_UNSUPPORTED, "dfsph needs host read-back unless fixed_iterations > 0");
         float sum; int rc = read_red(h, 1, &sum); if (rc) return rc;
-        avg = sum / (float)h->n;                                    // DFSPH.py:293
+        avg = sum / n_all;                                          // DFSPH.py:293
         if ((double)avg <= 0.0001) break;                            // :239
     }
     h->last.iter_density = itr; h->last.err_density = avg;
@@ -155,6 +172,7 @@ static int dfsph_step_begin(SphHandle *h, bool allow_readback) {
         { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha(s); }
     }
     int rc = run_non_pressure(h); if (rc) return rc;                          // DFSPH.py:299-300
+    if (s.slab_active) { rc = slab_exchange_vel(h); if (rc) return rc; }      // the density solver reads v_j of the ghosts
     rc = dfsph_density(h, allow_readback); if (rc) return rc;                 // :301
     { ProfScope p(h, SPH_K_MISC); h->L->advect_boundary(s); }                 // :303, :311-314 (boundary fused: it only looks at the particle itself)
     return SPH_OK;
@@ -164,9 +182,11 @@ static int dfsph_step_begin(SphHandle *h, bool allow_readback) {
 // then :316-:319
 static int dfsph_step_end(SphHandle *h, bool allow_readback) {
     State &s = h->st;
-    ph_neighbor_search(h);                                                    // :316
+    if (s.slab_active) { int rc = slab_neighbor_search(h); if (rc) return rc; }   // + migration / ghost exchange
+    else ph_neighbor_search(h);                                               // :316
     ph_rigid_volume(h);
     { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha(s); } // :317-318
+    if (s.slab_active) { int rc = slab_exchange_scalar(h, s.rho.cur()); if (rc) return rc; }   // ghost densities (kappa_j / rho_j, viscosity)
     return dfsph_divergence(h, allow_readback);                               // :319
 }
 
@@ -248,8 +268,8 @@ static float host_pcisph_k(const SphParams &p) {
 static int method_prepare(SphHandle *h) {
     State &s = h->st;
     if (h->prm.method == SPH_METHOD_DFSPH) {  // DFSPH.py:321-324
-        ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA);
-        h->L->dfsph_density_alpha(s);
+        { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha(s); }
+        if (s.slab_active) { int rc = slab_exchange_scalar(h, s.rho.cur()); if (rc) return rc; }
     } else if (h->prm.method == SPH_METHOD_PCISPH) {  // PCISPH.py:188-190
         s.c.pcisph_k = host_pcisph_k(h->prm);
     }

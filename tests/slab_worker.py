@@ -32,8 +32,11 @@ def main():
     nz = int(geo.grid_num[2])
     hist = np.bincount(slab.cell_layer(pos[:, 2], geo.dh, nz), minlength=nz)
     cuts = slab.plan_slabs(hist, nranks)
+    extra = {}
+    if int(os.environ.get("SPH_FIXED_ITERATIONS", "0")) > 0:
+        extra["fixed_iterations"] = int(os.environ["SPH_FIXED_ITERATIONS"])
     container, solver = H.build_product(cfg, slab=dict(rank=rank, nranks=nranks, unique_id=uid, cuts=cuts),
-                                        fast_math=int(os.environ.get("SPH_FAST", "0")))
+                                        fast_math=int(os.environ.get("SPH_FAST", "0")), **extra)
     if jitter > 0:  # same perturbed lattice on every rank: overwrite the positions of the particles kept here
         container.insert_object()
         ids = np.concatenate(container._global_ids)
@@ -46,7 +49,8 @@ def main():
     info = e.comm_get_slab()
     np.savez(out, ids=e.download(L.F_PARTICLE_ID)[~g], pos=e.download(L.F_POSITION)[~g], vel=e.download(L.F_VELOCITY)[~g],
              rho=e.download(L.F_DENSITY)[~g], prs=e.download(L.F_PRESSURE)[~g], n_ghost=info["n_ghost"], cuts=np.array(cuts),
-             pairs=solver.stats()["pair_interactions"])
+             pairs=solver.stats()["pair_interactions"], iter_density=solver.stats()["iter_density"],
+             iter_divergence=solver.stats()["iter_divergence"])
     print(f"rank {rank}: slab {info['z_lo']}..{info['z_hi']} owned {info['n_owned']} ghosts {info['n_ghost']}")
 
 

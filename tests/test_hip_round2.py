@@ -140,7 +140,7 @@ def test_run_simulation_driver_on_scene_file(gpu, tmp_path):
 
 
 # --------------------------------------------------------------------------------------------- BASELINE configs
-def _full_size_vs_oracle(cfg, steps, fixed, tol):
+def _full_size_vs_oracle(cfg, steps, fixed, tol, pair_rtol=0.0):
     container, solver = H.build_product(cfg, fast_math=1, **({"fixed_iterations": fixed} if fixed else {}))
     solver.prepare()
     ref = H.build_oracle(cfg, fixed_iterations=fixed)
@@ -159,13 +159,15 @@ def _full_size_vs_oracle(cfg, steps, fixed, tol):
     st = solver.stats()
     print("full size n=%d: drift max %.3e p99 %.3e; pairs/step %d" % (n, d.max(), np.percentile(d, 99), st["pair_interactions"]))
     assert d.max() <= tol, d.max()
-    assert st["pair_interactions"] == ref.last_pairs
+    assert abs(st["pair_interactions"] - ref.last_pairs) <= pair_rtol * ref.last_pairs, (st["pair_interactions"], ref.last_pairs)
     return container, solver, ref
 
 
 def test_c3_full_size_dfsph(gpu):
     """BASELINE configs[2]: 1,231,200 particles, DFSPH, 2 + 2 fixed solver iterations (bench.py --config c3), 5 steps."""
-    container, solver, ref = _full_size_vs_oracle(P.c2_scene("dfsph"), 5, 2, 1e-4)
+    # fast-math DFSPH positions differ from the oracle's in the last bit, which flips a few of the lattice's exactly-2d-apart
+    # pairs (|x_ij| = h up to rounding; W and grad W vanish there): pair counts agree to ~1e-6, not exactly as for WCSPH
+    container, solver, ref = _full_size_vs_oracle(P.c2_scene("dfsph"), 5, 2, 1e-4, pair_rtol=2e-6)
     ids = container.engine.download(L.F_PARTICLE_ID)
     rho = H.by_id(ids, container.engine.download(L.F_DENSITY))
     rho_r = H.by_id(H.oracle_ids(ref), ref.field("particle_densities").copy())
@@ -191,7 +193,11 @@ def test_c5_scaled_buckling_scene(gpu):
     for step in range(1, 7):
         solver.step()
         ref.step(1)
-        assert solver.stats()["pair_interactions"] == ref.last_pairs, step
+        print("C5 scaled step %d: pairs hip %d oracle %d, cg iterations %d" % (step, solver.stats()["pair_interactions"], ref.last_pairs, solver.stats()["iter_cg"]))
+        # the CG dot products are reduced in a different order than the oracle's serial sums, so velocities -- and with them
+        # positions -- differ in the last bit; the sheet is a lattice with many pairs exactly one support radius apart
+        # (W = grad W = 0 there), a few of which land on the other side of the test: counts agree to ~3e-4, not exactly
+        assert abs(solver.stats()["pair_interactions"] - ref.last_pairs) <= 1e-3 * ref.last_pairs, step
     e = container.engine
     ids = e.download(L.F_PARTICLE_ID)
     mat = H.by_id(ids, e.download(L.F_MATERIAL))
@@ -296,16 +302,14 @@ def test_dynamic_rigid_body_scene_runs_end_to_end(gpu, tmp_path):
     cfg = H.dam_break_scene(domain_end=(0.6, 0.8, 0.6), end=(0.3, 0.16, 0.3), translation=(0.12, 0.06, 0.12), dt=4e-4, viscosity_b=0.5)
     cfg["Configuration"].update(exportPly=True, exportObj=True, fps=250, totalTime=0.024)   # 60 rounds, a frame every 10
     cfg["RigidBodies"] = [{"objectId": 1, "geometryFile": str(tmp_path / "cube.obj"), "isDynamic": True, "entryTime": -1.0,
-                           "density": 600.0, "color": [200, 50, 50], "velocity": [0.0, -1.0, 0.0], "translation": [0.27, 0.33, 0.27],
+                           "density": 600.0, "color": [200, 50, 50], "velocity": [0.0, -1.0, 0.0], "translation": [0.27, 0.29, 0.27],
                            "scale": [1, 1, 1], "rotationAngle": 0.0, "rotationAxis": [0, 1, 0]}]
     container, solver = H.build_product(cfg)
     solver.prepare()
     e = container.engine
     rigid = e.download(L.F_MATERIAL) == 2
     assert 64 <= rigid.sum() <= 400
-    y0 = H.by_id(e.download(L.F_PARTICLE_ID), e.download(L.F_POSITION))[:, 1]
-    got_wrench = False
-    for _ in range(150):
+    for _ in range(250):
         solver.step()
     b = solver.rigid_solver.bodies[1]
     ids = e.download(L.F_PARTICLE_ID)
@@ -313,15 +317,12 @@ def test_dynamic_rigid_body_scene_runs_end_to_end(gpu, tmp_path):
     mat = H.by_id(ids, e.download(L.F_MATERIAL))
     r = mat == 2
     assert np.isfinite(x).all()
-    # the body fell into the fluid (it started 0.11 above the surface at 1 m/s), was decelerated by it, and its
+    # the body fell into the fluid (it started 0.04 above the surface at 1 m/s), was decelerated by it, and its
     # particles moved rigidly with the pose the host pushed
-    assert b.com[1] < 0.33 - 0.05, b.com
-    assert b.vel[1] > -1.0 - 9.81 * 150 * 4e-4 + 0.05, ("the fluid never pushed back", b.vel)
-    np.testing.assert_allclose(x[r].mean(0), b.com, atol=2e-3)
-    d0 = np.linalg.norm(x[r][0] - x[r][-1])
-    assert abs(d0 - np.linalg.norm((y0[r][0] - y0[r][-1]))) < 1.0   # finite; exact rigidity checked through the spread below
-    spread = x[r].max(0) - x[r].min(0)
-    assert (spread < 0.1 * np.sqrt(3) + 0.03).all() and (spread > 0.06).all(), spread
+    assert b.com[1] < 0.29 - 0.05, b.com
+    assert b.vel[1] > -1.0 - 9.81 * 250 * 4e-4 + 0.2, ("the fluid never pushed back", b.vel)
+    pts = np.asarray(container.rigid_bodies[0]["voxelizedPoints"], dtype=np.float64)   # body frame = insertion order
+    np.testing.assert_allclose(x[r], b.com + pts @ b.rot.T, atol=2e-6, err_msg="particles = com + R (rest position)")
     del container, solver
     # the driver writes the OBJ / PLY tree
     scene_file = tmp_path / "float_cube.json"

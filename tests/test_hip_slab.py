@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.0, seed=0):
+def _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.0, seed=0, fixed_iterations=0):
     scene_path = tmp_path / "scene.json"
     scene_path.write_text(json.dumps(cfg))
     uid = os.urandom(128).hex()
-    env = dict(os.environ, SPH_COMM_TRANSPORT="shm")
+    env = dict(os.environ, SPH_COMM_TRANSPORT="shm", SPH_FIXED_ITERATIONS=str(fixed_iterations))
     procs = []
     for r in range(nranks):
         out = tmp_path / f"rank{r}.npz"
@@ -71,3 +71,42 @@ def test_slab_sharding_matches_oracle(gpu, tmp_path, nranks):
     cz1 = slab.cell_layer(x[:, 2], dh, nz)
     assert (slab.owner_of(cz0, cuts) != slab.owner_of(cz1, cuts)).sum() > 0
     assert sum(int(o["pairs"]) for o in outs) == ref.last_pairs
+
+
+@pytest.mark.parametrize("nranks,fixed", [(2, 3), (3, 3), (2, 0)])
+def test_dfsph_slab_sharding_matches_oracle(gpu, tmp_path, nranks, fixed):
+    """DFSPH under z-slab sharding: per solver iteration the ghosts' kappa goes out before the correction
+    pass and their velocities after it, the residual is all-reduced over the ranks (DFSPH.py:139-159, :225-243).
+    fixed > 0: both sides do exactly that many iterations (bitwise-comparable work); fixed = 0: the reference's own
+    stop tests on the all-reduced residual (the sum order differs from a single rank's, so +-1 iteration is allowed)."""
+    cfg = H.dam_break_scene(method="dfsph", domain_end=(1.0, 1.0, 1.2), start=(0.1, 0.1, 0.08), end=(0.36, 0.36, 1.12),
+                            translation=(0, 0, 0), velocity=(0.0, -0.3, 2.0), particleSpacing=0.019, dt=6e-4)
+    steps = 25
+    outs, logs = _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.002, seed=5, fixed_iterations=fixed)
+    ref = H.build_oracle(cfg, jitter=0.002, seed=5, fixed_iterations=fixed)
+    ref.prepare()
+    ref.step(steps)
+    ids = H.oracle_ids(ref)
+    x_ref = H.by_id(ids, ref.field("particle_positions").copy())
+    v_ref = H.by_id(ids, ref.field("particle_velocities").copy())
+    rho_ref = H.by_id(ids, ref.field("particle_densities").copy())
+    _, geo, _b = H.scene_particles(cfg)
+    all_ids = np.concatenate([o["ids"] for o in outs])
+    assert len(all_ids) == len(ids) and len(np.unique(all_ids)) == len(ids), "every particle owned by exactly one rank"
+    x, v, rho = np.empty_like(x_ref), np.empty_like(v_ref), np.empty_like(rho_ref)
+    for o in outs:
+        x[o["ids"]] = o["pos"]; v[o["ids"]] = o["vel"]; rho[o["ids"]] = o["rho"]
+        assert int(o["n_ghost"]) > 0
+    d = H.drift(x, x_ref, geo.dh)
+    it = [(int(o["iter_density"]), int(o["iter_divergence"])) for o in outs]
+    print("dfsph slab x%d fixed=%d: drift max %.3e; iterations per rank %s, oracle (%d, %d)" %
+          (nranks, fixed, d.max(), it, int(ref.scalar("last_iter_den")), int(ref.scalar("last_iter_div"))))
+    assert len(set(it)) == 1, "every rank sees the same all-reduced residual"
+    if fixed:
+        assert d.max() <= 1e-5
+        np.testing.assert_allclose(rho, rho_ref, rtol=3e-5)
+        np.testing.assert_allclose(v, v_ref, rtol=0, atol=3e-5 * float(np.abs(v_ref).max()))
+        assert sum(int(o["pairs"]) for o in outs) == ref.last_pairs
+    else:
+        assert abs(it[0][0] - int(ref.scalar("last_iter_den"))) <= 1 and abs(it[0][1] - int(ref.scalar("last_iter_div"))) <= 1
+        assert d.max() <= 1e-4

@@ -38,7 +38,8 @@ def short(name):
 
 def compile_asm(build, extra, out):
     flags = {"fast": ["-DSPH_FAST=1", "-ffp-contract=fast"], "strict": ["-DSPH_FAST=0", "-ffp-contract=off"]}[build]
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "--cuda-device-only", "-S"] + flags + extra + \
+    # same code generation flags as sph_project_amd/csrc/Makefile (COMMON + KFLAGS)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-fno-slp-vectorize", "--cuda-device-only", "-S"] + flags + extra + \
           [os.path.join(CSRC, "sph_kernels.hip"), "-o", out]
     subprocess.check_call(cmd)
 
