@@ -71,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = every z-slab gets one C2 block (N x 1.23 M particles); strong = the 1.23 M scene is split")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent copies instead of z-slab sharding")
+    ap.add_argument("--no-c4", action="store_true", help="N>1: skip the extra C4 (4 M particles, strong scaling) measurement")
     return ap.parse_args(argv)
 
 
@@ -109,9 +110,9 @@ def rendezvous_path():
     return f"/dev/shm/sph_bench_{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}.id"
 
 
-def exchange_unique_id(lib, rank):
+def exchange_unique_id(lib, rank, suffix=""):
     import ctypes
-    path = rendezvous_path()
+    path = rendezvous_path() + suffix
     if rank == 0:
         buf = ctypes.create_string_buffer(128)
         if lib.sph_comm_unique_id(buf) != 0:
@@ -168,6 +169,50 @@ def cpu_baseline(cfg, steps):
     except OSError:
         pass
     return dict(value=table[best], cores=best, secs=best_dt, pairs_per_s=pairs * steps / best_dt, sweep=table, model=model, ncpu=ncpu)
+
+
+# ----------------------------------------------------------------------------------------------- C4 on N GPUs
+def c4_sharded(args, rank, world, device, lib):
+    """BASELINE configs[3]: the 4,000,000-particle WCSPH dam break z-slab sharded over the N ranks of this job (one fixed
+    scene: strong scaling).  Runs after the headline measurement with a communicator of its own; reported as an extra
+    object of the JSON line (`c4_strong_scaling`), never as `value`."""
+    import numpy as np
+    from sph_project_amd import product as P, slab
+    cfg = P.c4_scene("wcsph")
+    uid = exchange_unique_id(lib, rank, suffix=".c4")
+    _, geo, batches = P.scene_particles(cfg)
+    z = np.concatenate([b["pos"][:, 2] for b in batches])
+    nz = int(geo.grid_num[2])
+    cuts = slab.plan_slabs(np.bincount(slab.cell_layer(z, geo.dh, nz), minlength=nz), world)
+    n_global = int(sum((b["material"] == 1).sum() for b in batches))
+    del batches, z
+    container, solver = P.build_product(cfg, fast_math=0 if args.strict_math else 1, deterministic=0 if args.no_deterministic else 1,
+                                        device=device, slab=dict(rank=rank, nranks=world, unique_id=uid, cuts=cuts))
+    eng = container.engine
+    solver.prepare()
+    eng.step_async(args.warmup)
+    times = []
+    for _ in range(args.repeats):
+        eng.synchronize(); eng.comm_barrier()
+        t0 = time.perf_counter()
+        eng.step_async(args.steps)
+        eng.synchronize(); eng.comm_barrier()
+        times.append(eng.comm_allreduce([time.perf_counter() - t0], "max")[0])
+    el = sorted(times)[len(times) // 2]
+    pairs = int(eng.comm_allreduce([solver.stats()["pair_interactions"]], "sum")[0])
+    info = eng.comm_get_slab()
+    owned = [int(v) for v in eng.comm_allreduce([info["n_owned"] if r == rank else 0 for r in range(min(world, 16))], "sum")]
+    eng.comm_barrier()
+    if rank == 0 and not os.environ.get("SPH_BENCH_RDV"):
+        try:
+            os.unlink(rendezvous_path() + ".c4")
+        except OSError:
+            pass
+    eng.close()
+    return {"workload": "C4 4,000,000-particle dam break, WCSPH", "scaling": "strong", "particles": n_global, "n_gpus": world,
+            "ms_per_step": 1e3 * el / args.steps, "value": n_global * args.steps / el, "unit": "particle-updates/s",
+            "pair_interactions_per_s": pairs * args.steps / el, "slab_cuts": [int(c) for c in cuts], "owned_per_rank": owned,
+            "steps": args.steps, "warmup": args.warmup}
 
 
 # ----------------------------------------------------------------------------------------------- one rank
@@ -356,8 +401,13 @@ def run_rank(args, rank, world, local_rank):
         }
     elif rank == 0:
         out["cpu_baseline"] = None
-    if multi:
+    if multi and sharded and args.config == "c2" and method == "wcsph" and not args.no_c4:
         eng.comm_barrier()
+        eng.close()
+        out["c4_strong_scaling"] = c4_sharded(args, rank, world, device, lib)
+    elif multi:
+        eng.comm_barrier()
+    if multi:
         if rank == 0 and not os.environ.get("SPH_BENCH_RDV"):
             try:
                 os.unlink(rendezvous_path())

@@ -210,6 +210,10 @@ int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id128);
    layer on each interior side; before any particle is appended */
 int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi);
 int sph_comm_get_slab(SphHandle *h, int *z_lo, int *z_hi, int *n_owned, int *n_ghost);
+/* slab cuts follow the fluid: every `every_steps` steps (default 64, env SPH_SLAB_REBALANCE; 0 = never) the ranks
+   all-reduce their per-layer particle histograms and move each interior cut by at most one cell layer towards the
+   balanced plan; the layer that changes hands migrates through the ordinary per-step exchange */
+int sph_comm_set_rebalance(SphHandle *h, int every_steps);
 /* host-visible collectives over the communicator (what a launcher otherwise needs MPI / torch.distributed for):
    in-place all-reduce of <= 16 doubles, op 0 sum / 1 max / 2 min (ncclAllReduce); barrier = drain the stream,
    then all-reduce; both synchronous.  The solver residuals of a sharded DFSPH / PCISPH step use the same path. */

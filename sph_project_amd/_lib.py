@@ -103,6 +103,7 @@ _SIGNATURES = [
     ("sph_comm_init", C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     ("sph_comm_set_slab", C.c_int, [_VP, C.c_int, C.c_int]),
     ("sph_comm_get_slab", C.c_int, [_VP] + [C.POINTER(C.c_int)] * 4),
+    ("sph_comm_set_rebalance", C.c_int, [_VP, C.c_int]),
     ("sph_device_count", C.c_int, []),
     ("sph_comm_allreduce", C.c_int, [_VP, C.POINTER(C.c_double), C.c_int, C.c_int]),
     ("sph_comm_barrier", C.c_int, [_VP]),
@@ -263,6 +264,9 @@ class Engine:
 
     def comm_set_slab(self, z_lo, z_hi):
         self._chk(self.lib.sph_comm_set_slab(self.h, int(z_lo), int(z_hi)), "sph_comm_set_slab")
+
+    def comm_set_rebalance(self, every_steps):
+        self._chk(self.lib.sph_comm_set_rebalance(self.h, int(every_steps)), "sph_comm_set_rebalance")
 
     def comm_get_slab(self):
         v = [C.c_int() for _ in range(4)]

@@ -32,6 +32,8 @@ static void slab_comm_destroy(SlabComm &c) {
     if (c.red_dev) hipFree(c.red_dev);
     if (c.red_host) hipHostFree(c.red_host);
     if (c.self_dev) hipFree(c.self_dev);
+    if (c.hist_dev) hipFree(c.hist_dev);
+    if (c.hist_host) hipHostFree(c.hist_host);
     c = SlabComm();
 }
 
@@ -99,12 +101,16 @@ extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id1
     SlabComm &c = h->comm;
     c.rank = rank; c.nranks = nranks;
     memcpy(c.id, id128, 128);
-    // message capacity: a z-face holds nx*ny cells; allow 24 particles per cell and two layers (migrants + copies)
-    const size_t face = (size_t)s.c.nx * s.c.ny;
-    size_t cap = face * 24 * 2;
-    if (cap > (size_t)s.cap) cap = (size_t)s.cap;
-    if (cap < 1024) cap = 1024;
+    // Message capacity = particle capacity: a face message can never hold more records than this rank has particles, so
+    // no pile-up in the boundary layers can overflow it (192 + 32 bytes per particle of capacity for the four message
+    // buffers and the eight slot tables: ~2 GB at 10 M particles, nothing next to 288 GB of HBM).
+    size_t cap = (size_t)s.cap < 1024 ? 1024 : (size_t)s.cap;
     s.halo_cap = (int)cap;
+    // the shared-memory test transport keeps its mailboxes at a z-face's worth (24 particles per cell, two layers)
+    const size_t face = (size_t)s.c.nx * s.c.ny;
+    size_t mbox_records = face * 24 * 2;
+    if (mbox_records > cap) mbox_records = cap;
+    if (mbox_records < 1024) mbox_records = 1024;
     HIPCHK(h, hipMalloc((void **)&c.cnt_dev, 4 * sizeof(int)));
     HIPCHK(h, hipHostMalloc((void **)&c.cnt_host, 8 * sizeof(int), hipHostMallocDefault));
     HIPCHK(h, hipMalloc((void **)&c.red_dev, SHM_RED_MAX * sizeof(double)));
@@ -112,7 +118,7 @@ extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id1
     const char *t = getenv("SPH_COMM_TRANSPORT");
     if (t && !strcmp(t, "shm")) {
         if (nranks > SHM_MAX_RANKS) return fail(h, SPH_ERR_INVALID, "shm transport: at most %d ranks", SHM_MAX_RANKS);
-        int rc = shm_attach(h, c, cap * 48);
+        int rc = shm_attach(h, c, mbox_records * 48);
         if (rc) return rc;
         c.kind = 2;
     } else {
@@ -146,6 +152,10 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
         for (int k = 0; k < 8; ++k) { int rc = dalloc(h, &s.halo_tab[k], cap); if (rc) return rc; }
         { int rc = dalloc(h, &s.halo_counts, 4); if (rc) return rc; }
         s.xcur = 0;
+        HIPCHK(h, hipMalloc((void **)&h->comm.hist_dev, sizeof(int) * (size_t)(c.nz_glob + h->comm.nranks)));
+        HIPCHK(h, hipHostMalloc((void **)&h->comm.hist_host, sizeof(int) * (size_t)(c.nz_glob + h->comm.nranks), hipHostMallocDefault));
+        const char *rb = getenv("SPH_SLAB_REBALANCE");
+        h->comm.rebalance_every = rb ? atoi(rb) : 64;
         h->comm.slab_ready = 1;
     }
     s.slab_active = 1;
@@ -167,11 +177,11 @@ extern "C" int sph_comm_get_slab(SphHandle *h, int *z_lo, int *z_hi, int *n_owne
     if (z_lo) *z_lo = h->st.z_lo;
     if (z_hi) *z_hi = h->st.z_hi;
     if (n_owned || n_ghost) {
-        HIPCHK(h, hipStreamSynchronize(h->st.stream));
-        std::vector<int> m((size_t)h->n);
-        HIPCHK(h, hipMemcpy(m.data(), h->st.meta.cur(), sizeof(int) * (size_t)h->n, hipMemcpyDeviceToHost));
+        refresh_counts(h);
+        h->L->count_ghosts(h->st, h->comm.cnt_dev + 3);   // 4 bytes come back, not the whole meta array
         int g = 0;
-        for (int v : m) g += META_GHOST(v);
+        HIPCHK(h, hipMemcpyAsync(&g, h->comm.cnt_dev + 3, sizeof(int), hipMemcpyDeviceToHost, h->st.stream));
+        HIPCHK(h, hipStreamSynchronize(h->st.stream));
         if (n_ghost) *n_ghost = g;
         if (n_owned) *n_owned = h->n - g;
     }
@@ -347,10 +357,90 @@ static int comm_exchange(SphHandle *h, const void *send[2], const size_t bytes_s
     return SPH_OK;
 }
 
+// Slab cuts that follow the fluid (SURVEY 8e "slab cuts from a per-z-layer histogram"): every rebalance_every steps the
+// ranks add up their owned-particle histograms over the global z layers, re-plan balanced cuts exactly like
+// sph_project_amd/slab.py:plan_slabs does for the initial lattice, and move every interior cut by AT MOST ONE layer
+// towards its target.  One layer is what the per-step protocol already handles: the particles of the layer that changed
+// hands are migrants of the next classify (kept behind as echo ghosts), nothing else is needed.
+static void plan_cuts(const std::vector<long long> &hist, int nranks, std::vector<int> &cuts) {
+    const int nz = (int)hist.size(), min_layers = 2;
+    std::vector<double> cum(nz + 1, 0.0);
+    for (int k = 0; k < nz; ++k) cum[k + 1] = cum[k] + (double)hist[k];
+    const double total = cum[nz];
+    cuts.assign(1, 0);
+    for (int r = 1; r < nranks; ++r) {
+        const double target = total * r / nranks;
+        int k = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        if (k > 0 && fabs(cum[k - 1] - target) <= fabs(cum[std::min(k, nz)] - target)) k -= 1;
+        k = std::max(k, cuts.back() + min_layers);
+        k = std::min(k, nz - (nranks - r) * min_layers);
+        cuts.push_back(k);
+    }
+    cuts.push_back(nz);
+}
+
+static int slab_rebalance(SphHandle *h) {
+    State &s = h->st;
+    SlabComm &c = h->comm;
+    Consts &k = s.c;
+    if (c.nranks < 2) return SPH_OK;
+    const int nz = k.nz_glob, len = nz + c.nranks;
+    ProfScope p(h, SPH_K_HALO);
+    h->L->layer_hist(s, c.hist_dev);
+    HIPCHK(h, hipMemsetAsync(c.hist_dev + nz, 0, sizeof(int) * c.nranks, s.stream));
+    HIPCHK(h, hipMemcpyAsync(c.hist_dev + nz + c.rank, &s.z_lo, sizeof(int), hipMemcpyHostToDevice, s.stream));
+    if (c.kind == 1) {
+        NCCLCHK(h, ncclAllReduce(c.hist_dev, c.hist_dev, (size_t)len, ncclInt32, ncclSum, (ncclComm_t)c.nccl, s.stream));
+        HIPCHK(h, hipMemcpyAsync(c.hist_host, c.hist_dev, sizeof(int) * len, hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(c.hist_host, c.hist_dev, sizeof(int) * len, hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        for (int o = 0; o < len; o += SHM_RED_MAX) {
+            double v[SHM_RED_MAX];
+            const int m = std::min(SHM_RED_MAX, len - o);
+            for (int q = 0; q < m; ++q) v[q] = (double)c.hist_host[o + q];
+            int rc = sph_comm_allreduce(h, v, m, 0); if (rc) return rc;
+            for (int q = 0; q < m; ++q) c.hist_host[o + q] = (int)v[q];
+        }
+    }
+    std::vector<long long> hist(nz);
+    for (int q = 0; q < nz; ++q) hist[q] = c.hist_host[q];
+    std::vector<int> target, cur(c.nranks + 1);
+    plan_cuts(hist, c.nranks, target);
+    for (int r = 0; r < c.nranks; ++r) cur[r] = c.hist_host[nz + r];
+    cur[c.nranks] = nz;
+    std::vector<int> next(cur);
+    for (int r = 1; r < c.nranks; ++r) {
+        const int d = target[r] - cur[r];
+        next[r] = cur[r] + (d > 0 ? 1 : (d < 0 ? -1 : 0));
+        next[r] = std::max(next[r], next[r - 1] + 2);                       // >= 2 layers below ...
+        next[r] = std::min(next[r], nz - (c.nranks - r) * 2);               // ... and room above
+        if (next[r] > cur[r] + 1 || next[r] < cur[r] - 1) next[r] = cur[r]; // never more than one layer per event
+    }
+    const int z_lo = next[c.rank], z_hi = next[c.rank + 1];
+    c.rebalance_moves += (z_lo != s.z_lo) + (z_hi != s.z_hi);
+    s.z_lo = z_lo; s.z_hi = z_hi;
+    k.cz_off = z_lo > 0 ? z_lo - 1 : 0;
+    const int top = z_hi < k.nz_glob ? z_hi + 1 : k.nz_glob;
+    k.nz = top - k.cz_off;
+    k.G = k.nx * k.ny * k.nz;
+    return SPH_OK;
+}
+
+extern "C" int sph_comm_set_rebalance(SphHandle *h, int every_steps) {
+    if (!h || !h->comm.kind || every_steps < 0) return fail(h, SPH_ERR_INVALID, "comm_set_rebalance: bad arguments");
+    h->comm.rebalance_every = every_steps;
+    return SPH_OK;
+}
+
 // replaces ph_neighbor_search in slab mode: migrate + ghost exchange, then the usual sort, then the slot tables
 static int slab_neighbor_search(SphHandle *h) {
     State &s = h->st;
     SlabComm &c = h->comm;
+    if (c.rebalance_every > 0 && h->prepared && h->steps > 0 && h->steps % c.rebalance_every == 0 && !h->any_rigid_object) {
+        int rc = slab_rebalance(h); if (rc) return rc;
+    }
     { ProfScope p(h, SPH_K_HALO); h->L->halo_classify_pack(s, h->n); }
     const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
     void *recv[2] = {s.recvbuf[0], s.recvbuf[1]};

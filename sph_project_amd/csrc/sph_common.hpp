@@ -177,6 +177,8 @@ struct Launch {
     void (*halo_unpack_scalar)(State &, int side, int n_recv, int n_send, float *dst);
     void (*halo_pack_vel)(State &, int side, int n_send, int n_recv);
     void (*halo_unpack_vel)(State &, int side, int n_recv, int n_send);
+    void (*count_ghosts)(State &, int *out);
+    void (*layer_hist)(State &, int *hist);      // owned particles per global cell layer
     void (*loop_criterion)(State &, int slot);   // stop test on an all-reduced residual (sharded solver loops)
     // implicit viscosity (CG)
     void (*cg_prepare)(State &);

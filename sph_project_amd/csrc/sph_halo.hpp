@@ -194,3 +194,20 @@ __global__ void k_loop_criterion(DevScalars *scal, int slot, int kind, float den
     scal->flags[1] += 1;
     if (kind == 1 ? ((double)avg <= thr) : (avg < (float)thr)) scal->flags[0] = 1;
 }
+
+// owned particles per global cell layer (slab rebalancing: the cuts follow the fluid)
+__global__ void __launch_bounds__(256)
+k_layer_hist(const Consts c, int n, const float4 *posv, const int *meta, int *hist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int m = meta[i];
+    if (META_GHOST(m) || META_DEAD(m)) return;
+    atomicAdd(&hist[cell_coord(posv[i].z, c.grid_size, c.nz_glob)], 1);
+}
+
+// number of ghost copies among the first n particles (sph_comm_get_slab): one atomic per wave
+__global__ void __launch_bounds__(256) k_count_ghosts(int n, const int *meta, int *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && META_GHOST(meta[i]));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+}

@@ -67,3 +67,13 @@ static void l_loop_criterion(State &s, int slot) {
     if (!s.loop_flag || s.loop_slot != slot) return;
     hipLaunchKernelGGL(k_loop_criterion, dim3(1), dim3(1), 0, s.stream, s.scal, slot, s.loop_kind, s.loop_denom, s.loop_thr);
 }
+
+static void l_layer_hist(State &s, int *hist) {
+    hipMemsetAsync(hist, 0, sizeof(int) * (size_t)s.c.nz_glob, s.stream);
+    if (s.c.n > 0) hipLaunchKernelGGL(k_layer_hist, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.c.n, s.posv.cur(), s.meta.cur(), hist);
+}
+
+static void l_count_ghosts(State &s, int *out) {
+    hipMemsetAsync(out, 0, sizeof(int), s.stream);
+    if (s.c.n > 0) hipLaunchKernelGGL(k_count_ghosts, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), out);
+}

@@ -327,6 +327,8 @@ const Launch *SPH_LAUNCH_FN() {
         L.halo_pack_scalar = l_halo_pack_scalar; L.halo_unpack_scalar = l_halo_unpack_scalar;
         L.halo_pack_vel = l_halo_pack_vel; L.halo_unpack_vel = l_halo_unpack_vel;
         L.loop_criterion = l_loop_criterion;
+        L.layer_hist = l_layer_hist;
+        L.count_ghosts = l_count_ghosts;
         init = true;
     }
     return &L;

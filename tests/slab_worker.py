@@ -50,7 +50,7 @@ def main():
     np.savez(out, ids=e.download(L.F_PARTICLE_ID)[~g], pos=e.download(L.F_POSITION)[~g], vel=e.download(L.F_VELOCITY)[~g],
              rho=e.download(L.F_DENSITY)[~g], prs=e.download(L.F_PRESSURE)[~g], n_ghost=info["n_ghost"], cuts=np.array(cuts),
              pairs=solver.stats()["pair_interactions"], iter_density=solver.stats()["iter_density"],
-             iter_divergence=solver.stats()["iter_divergence"])
+             iter_divergence=solver.stats()["iter_divergence"], z_lo=info["z_lo"], z_hi=info["z_hi"])
     print(f"rank {rank}: slab {info['z_lo']}..{info['z_hi']} owned {info['n_owned']} ghosts {info['n_ghost']}")
 
 

@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.0, seed=0, fixed_iterations=0):
+def _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.0, seed=0, fixed_iterations=0, rebalance=0):
     scene_path = tmp_path / "scene.json"
     scene_path.write_text(json.dumps(cfg))
     uid = os.urandom(128).hex()
-    env = dict(os.environ, SPH_COMM_TRANSPORT="shm", SPH_FIXED_ITERATIONS=str(fixed_iterations))
+    env = dict(os.environ, SPH_COMM_TRANSPORT="shm", SPH_FIXED_ITERATIONS=str(fixed_iterations), SPH_SLAB_REBALANCE=str(rebalance))
     procs = []
     for r in range(nranks):
         out = tmp_path / f"rank{r}.npz"
@@ -110,3 +110,34 @@ def test_dfsph_slab_sharding_matches_oracle(gpu, tmp_path, nranks, fixed):
     else:
         assert abs(it[0][0] - int(ref.scalar("last_iter_den"))) <= 1 and abs(it[0][1] - int(ref.scalar("last_iter_div"))) <= 1
         assert d.max() <= 1e-4
+
+
+def test_slab_cuts_follow_the_fluid(gpu, tmp_path):
+    """Rebalancing (cuts from a per-z-layer histogram): a block that flies along +z leaves the lower slabs
+    empty unless the cuts follow it.  With re-planning every 4 steps (one layer per event) the result is still the
+    undecomposed oracle's, every particle has exactly one owner, and the cuts have moved with the fluid."""
+    cfg = H.dam_break_scene(domain_end=(0.6, 0.6, 2.4), start=(0.1, 0.1, 0.1), end=(0.3, 0.3, 0.9), translation=(0, 0, 0),
+                            velocity=(0.0, 0.0, 8.0), particleSpacing=0.019, gravitation=[0.0, 0.0, 0.0])
+    steps, nranks = 100, 3
+    outs, logs = _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.002, seed=7, rebalance=4)
+    ref = H.build_oracle(cfg, jitter=0.002, seed=7)
+    ref.prepare()
+    ref.step(steps)
+    ids = H.oracle_ids(ref)
+    x_ref = H.by_id(ids, ref.field("particle_positions").copy())
+    _, geo, _b = H.scene_particles(cfg)
+    all_ids = np.concatenate([o["ids"] for o in outs])
+    assert len(all_ids) == len(ids) and len(np.unique(all_ids)) == len(ids)
+    x = np.empty_like(x_ref)
+    for o in outs:
+        x[o["ids"]] = o["pos"]
+    d = H.drift(x, x_ref, geo.dh)
+    cuts0 = [int(v) for v in outs[0]["cuts"]]
+    cuts1 = [int(outs[0]["z_lo"])] + [int(o["z_hi"]) for o in outs]
+    owned = [len(o["ids"]) for o in outs]
+    print("rebalance: cuts %s -> %s, owned %s, drift %.2e" % (cuts0, cuts1, owned, d.max()))
+    assert d.max() <= 1e-5
+    assert sum(int(o["pairs"]) for o in outs) == ref.last_pairs
+    assert all(cuts1[k + 1] == int(outs[k + 1]["z_lo"]) for k in range(nranks - 1)), "neighbours agree on their common face"
+    assert cuts1[1] > cuts0[1] and cuts1[2] > cuts0[2], "the fluid moved up by 8 layers, the cuts followed"
+    assert max(owned) <= 1.6 * min(owned), "still balanced"
