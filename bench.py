@@ -10,8 +10,8 @@ forces + symplectic integration + boundary) over the whole particle set.  N=1 wo
 N > 1: one process per GPU, no torch anywhere.  `python bench.py --gpus N` spawns its own N ranks; under a launcher
 that already did (torch.distributed.run exports RANK / LOCAL_RANK / WORLD_SIZE) every process is one rank.  The RCCL
 unique id travels through a file in /dev/shm, barriers and the max / sum reductions are RCCL all-reduces behind the
-C-ABI (sph_comm_barrier / sph_comm_allreduce).  WCSPH and DFSPH scenes are z-slab sharded (RCCL halo exchange, DFSPH with
-its per-iteration ghost kappa / velocity refresh and all-reduced residuals); PCISPH runs replicas and says so.  SPH_COMM_TRANSPORT=shm lets several ranks share one GPU (test rig).
+C-ABI (sph_comm_barrier / sph_comm_allreduce).  Scenes are z-slab sharded (RCCL halo exchange; DFSPH / PCISPH with their
+per-iteration ghost refreshes and all-reduced residuals); --replicas runs independent copies instead and says so.  SPH_COMM_TRANSPORT=shm lets several ranks share one GPU (test rig).
 
 Timing: W untimed warm-up steps, then 3 repetitions of exactly K steps, each enqueued on the library's HIP stream
 between two (device synchronise + barrier) fences, max over ranks; `ms_per_step` is the MEDIAN repetition
@@ -220,7 +220,7 @@ def run_rank(args, rank, world, local_rank):
     from sph_project_amd import _lib as L, product as P
     lib = L.load()
     method = args.method or ("dfsph" if args.config == "c3" else "wcsph")
-    sharded = world > 1 and not args.replicas and method in ("wcsph", "dfsph")   # pcisph: replicas (no per-iteration ghost exchange built)
+    sharded = world > 1 and not args.replicas   # every solver shards (implicit viscosity, which no bench config uses, would not)
     scale_z = world if (sharded and args.scaling == "weak" and args.config in ("c2", "c3")) else 1
     cfg = (P.dam_break_scene(method=method) if args.config == "c1" else
            P.c4_scene(method) if args.config == "c4" else P.c2_scene(method, scale_z=scale_z))
@@ -230,7 +230,7 @@ def run_rank(args, rank, world, local_rank):
     device = local_rank % ndev if world > 1 else -1   # several ranks per GPU only happen with SPH_COMM_TRANSPORT=shm
     slab_opt = comm_opt = None
     n_global = None
-    force_slab = world == 1 and os.environ.get("SPH_BENCH_FORCE_SLAB") and method in ("wcsph", "dfsph")
+    force_slab = world == 1 and bool(os.environ.get("SPH_BENCH_FORCE_SLAB"))
     if world > 1 or force_slab:
         uid = exchange_unique_id(lib, rank) if world > 1 else None
         if force_slab:   # tuning aid / RCCL self-test: ONE rank in slab mode (no neighbour to talk to)

@@ -148,6 +148,9 @@ const char *sph_last_error(SphHandle *h);
 int sph_append_particles(SphHandle *h, int object_id, int n, const float *pos, const float *vel,
                          const float *density, const float *pressure, const int32_t *material,
                          const int32_t *is_dynamic, const int32_t *color);
+/* persistent ids (SPH_F_PARTICLE_ID) of the n particles appended last; default = insertion index on this handle.  A rank
+   of a sharded scene passes global insertion indices. */
+int sph_set_appended_ids(SphHandle *h, int n, const int32_t *ids);
 /* object_materials / rigid_body_is_dynamic (base_container.py:150,156; insert_object :237,:317,:332) */
 int sph_set_object(SphHandle *h, int object_id, int material, int is_dynamic);
 /* pose written by the host rigid solver (SPH/rigid_solver/bullet_solver.py:158-167); rot9 row-major */
@@ -214,6 +217,9 @@ int sph_comm_get_slab(SphHandle *h, int *z_lo, int *z_hi, int *n_owned, int *n_g
    all-reduce their per-layer particle histograms and move each interior cut by at most one cell layer towards the
    balanced plan; the layer that changes hands migrates through the ordinary per-step exchange */
 int sph_comm_set_rebalance(SphHandle *h, int every_steps);
+/* late entry (base_container.py:218-221) under sharding: the object holds n particles in the whole scene, n_fluid of them
+   fluid; every rank calls this next to its sph_append_particles of the slab's share (which may be empty) */
+int sph_comm_add_global_count(SphHandle *h, int n, int n_fluid);
 /* host-visible collectives over the communicator (what a launcher otherwise needs MPI / torch.distributed for):
    in-place all-reduce of <= 16 doubles, op 0 sum / 1 max / 2 min (ncclAllReduce); barrier = drain the stream,
    then all-reduce; both synchronous.  The solver residuals of a sharded DFSPH / PCISPH step use the same path. */
@@ -222,6 +228,17 @@ int sph_comm_barrier(SphHandle *h);
 /* transport self-test: ring shift of n floats (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd; a self pair when
    the communicator has one rank), every word checked, plus an all-reduce check */
 int sph_comm_selftest(SphHandle *h, int n);
+
+/* --- mesh -> particles (host code, no GPU involved) ------------------------------------ */
+/* replaces trimesh's mesh.voxelized(pitch).fill().points in BaseContainer.load_rigid_body (base_container.py:641-642):
+   voxel centres (integer multiples of pitch) of the surface voxels plus the region they enclose, f32 xyz, x slowest.
+   out_xyz == NULL: only *n_points is set. */
+int sph_voxelize_mesh(const double *vertices, int n_vertices, const int32_t *faces, int n_faces, double pitch,
+                      float *out_xyz, int64_t capacity_points, int64_t *n_points);
+/* replaces mesh.contains(lattice) in BaseContainer.load_fluid_body (base_container.py:686-694): crossing parity along z;
+   inside[(i * ny + j) * nz + k] for the point (xs[i], ys[j], zs[k]) */
+int sph_points_in_mesh(const double *vertices, int n_vertices, const int32_t *faces, int n_faces, const double *xs, int nx,
+                       const double *ys, int ny, const double *zs, int nz, uint8_t *inside);
 
 #ifdef __cplusplus
 }

@@ -266,9 +266,10 @@ class BaseContainer:
         ids = np.arange(self._next_global_id, self._next_global_id + new_particles_num, dtype=np.int32)
         self._next_global_id += new_particles_num
         if self.slab:  # keep only this rank's z-slab
-            r, cuts = self.slab["rank"], self.slab["cuts"]
+            self.engine.comm_add_global_count(new_particles_num, int((np.asarray(new_particles_material) == self.material_fluid).sum()))   # (counts only after prepare(): late entry)
+            info = self.engine.comm_get_slab(counts=False)   # the current bounds: the cuts follow the fluid (rebalancing)
             cz = self._slab_mod.cell_layer(np.asarray(new_particles_positions)[:, 2], self.dh, int(self.grid_num[2]))
-            m = (cz >= cuts[r]) & (cz < cuts[r + 1])
+            m = (cz >= info["z_lo"]) & (cz < info["z_hi"])
             ids = ids[m]
             sel = lambda a: np.asarray(a)[m]
             new_particles_positions, new_particles_velocity = sel(new_particles_positions), sel(new_particles_velocity)
@@ -282,7 +283,7 @@ class BaseContainer:
                                      new_particle_density, new_particle_pressure, new_particles_material,
                                      new_particles_is_dynamic, new_particles_color)
         if self.slab:  # persistent ids are global insertion indices, identical to a single-rank run
-            self.engine.upload(F.F_PARTICLE_ID, np.concatenate(self._global_ids))
+            self.engine.set_appended_ids(ids)
 
     def _uniform_attributes(self, n, material, is_dynamic, color, density, pressure, velocity, positions):
         vel = (np.zeros_like(positions, dtype=np.float32) if velocity is None

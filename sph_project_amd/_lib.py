@@ -79,6 +79,7 @@ _SIGNATURES = [
     ("sph_destroy", None, [_VP]),
     ("sph_last_error", C.c_char_p, [_VP]),
     ("sph_append_particles", C.c_int, [_VP, C.c_int, C.c_int] + [_VP] * 7),
+    ("sph_set_appended_ids", C.c_int, [_VP, C.c_int, _VP]),
     ("sph_set_object", C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),
     ("sph_set_rigid_pose", C.c_int, [_VP, C.c_int] + [_VP] * 5),
     ("sph_get_rigid_wrench", C.c_int, [_VP, _VP, _VP, C.c_int]),
@@ -104,7 +105,10 @@ _SIGNATURES = [
     ("sph_comm_set_slab", C.c_int, [_VP, C.c_int, C.c_int]),
     ("sph_comm_get_slab", C.c_int, [_VP] + [C.POINTER(C.c_int)] * 4),
     ("sph_comm_set_rebalance", C.c_int, [_VP, C.c_int]),
+    ("sph_comm_add_global_count", C.c_int, [_VP, C.c_int, C.c_int]),
     ("sph_device_count", C.c_int, []),
+    ("sph_voxelize_mesh", C.c_int, [_VP, C.c_int, _VP, C.c_int, C.c_double, _VP, C.c_int64, C.POINTER(C.c_int64)]),
+    ("sph_points_in_mesh", C.c_int, [_VP, C.c_int, _VP, C.c_int] + [_VP, C.c_int] * 3 + [_VP]),
     ("sph_comm_allreduce", C.c_int, [_VP, C.POINTER(C.c_double), C.c_int, C.c_int]),
     ("sph_comm_barrier", C.c_int, [_VP]),
     ("sph_comm_selftest", C.c_int, [_VP, C.c_int]),
@@ -175,6 +179,10 @@ class Engine:
         self._chk(self.lib.sph_append_particles(self.h, int(object_id), n, _ptr(pos), _ptr(vel), _ptr(density),
                                                 _ptr(pressure), _ptr(material), _ptr(is_dynamic), _ptr(color)),
                   "sph_append_particles")
+
+    def set_appended_ids(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(-1)
+        self._chk(self.lib.sph_set_appended_ids(self.h, ids.shape[0], _ptr(ids)), "sph_set_appended_ids")
 
     def set_object(self, object_id, material, is_dynamic):
         self._chk(self.lib.sph_set_object(self.h, int(object_id), int(material), int(bool(is_dynamic))), "sph_set_object")
@@ -265,13 +273,20 @@ class Engine:
     def comm_set_slab(self, z_lo, z_hi):
         self._chk(self.lib.sph_comm_set_slab(self.h, int(z_lo), int(z_hi)), "sph_comm_set_slab")
 
+    def comm_add_global_count(self, n, n_fluid):
+        self._chk(self.lib.sph_comm_add_global_count(self.h, int(n), int(n_fluid)), "sph_comm_add_global_count")
+
     def comm_set_rebalance(self, every_steps):
         self._chk(self.lib.sph_comm_set_rebalance(self.h, int(every_steps)), "sph_comm_set_rebalance")
 
-    def comm_get_slab(self):
+    def comm_get_slab(self, counts=True):
         v = [C.c_int() for _ in range(4)]
-        self._chk(self.lib.sph_comm_get_slab(self.h, *[C.byref(x) for x in v]), "sph_comm_get_slab")
-        return dict(z_lo=v[0].value, z_hi=v[1].value, n_owned=v[2].value, n_ghost=v[3].value)
+        args = [C.byref(v[0]), C.byref(v[1])] + ([C.byref(v[2]), C.byref(v[3])] if counts else [None, None])
+        self._chk(self.lib.sph_comm_get_slab(self.h, *args), "sph_comm_get_slab")
+        out = dict(z_lo=v[0].value, z_hi=v[1].value)
+        if counts:
+            out.update(n_owned=v[2].value, n_ghost=v[3].value)
+        return out
 
     def comm_allreduce(self, values, op="sum"):
         """In-place all-reduce of up to 16 doubles over the communicator; returns the list of reduced values."""

@@ -12,6 +12,8 @@
 #include <vector>
 #include <stdlib.h>
 #include <utility>
+#include <array>
+#include "sph_voxel.hpp"
 
 static thread_local std::string g_create_error;
 
@@ -49,6 +51,7 @@ struct SphHandle {
     DevScalars *scal_h = nullptr;  // pinned
     SlabComm comm;
     long long comm_n_global = 0;   // particle_num of the whole scene (sum of the ranks' owned particles), see sph_prepare
+    long long comm_nfluid_global = 0;   // fluid_particle_num of the whole scene (PCISPH's error mean divides by it)
 };
 
 static int fail(SphHandle *h, int code, const char *fmt, ...) {
@@ -269,7 +272,8 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
         CHK_CREATE(dalloc(h, &s.cg_dinv, cap * 9));
     }
     s.red_blocks = (int)((cap + 255) / 256) + 1;
-    CHK_CREATE(dalloc(h, &s.red_partial, (size_t)s.red_blocks * 4));
+    CHK_CREATE(dalloc(h, &s.red_partial, (size_t)s.red_blocks * 8));   // (also the four partial-sum arrays of the CG kernels)
+    s.cg_parity = 0;
     CHK_CREATE(dalloc(h, &s.scal, 1)); CHK_CREATE(dalloc(h, &s.pose, 1));
     HIP_CREATE(hipHostMalloc((void **)&h->scal_h, sizeof(DevScalars), hipHostMallocDefault));
     memset(h->scal_h, 0, sizeof(DevScalars));
@@ -344,6 +348,17 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
     s.masks_valid = 0;
     s.perm_n = -1; s.list_n = -1;
     refresh_counts(h);
+    return SPH_OK;
+}
+
+// persistent ids of the n particles appended last (a rank of a sharded scene numbers its particles with their global
+// insertion indices, so that ids mean the same thing on every rank and in a single-GPU run)
+extern "C" int sph_set_appended_ids(SphHandle *h, int n, const int32_t *ids) {
+    if (!h || !ids || n < 0 || n > h->n) return fail(h, SPH_ERR_INVALID, "set_appended_ids: bad arguments");
+    if (n == 0) return SPH_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->st.stream));
+    HIPCHK(h, hipMemcpy(h->st.pid.cur() + (size_t)(h->n - n), ids, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
     return SPH_OK;
 }
 
@@ -517,9 +532,10 @@ extern "C" int sph_prepare(SphHandle *h) {
     { ProfScope p(h, SPH_K_MISC); h->L->prepare_emitter(s); h->L->renew_rigid(s); }
     h->pose_dirty = false;
     if (s.slab_active) {
-        double n_own = (double)h->n;   // before any ghost arrives: every particle is owned by exactly one rank
-        rc = sph_comm_allreduce(h, &n_own, 1, 0); if (rc) return rc;
-        h->comm_n_global = (long long)n_own;
+        double n_own[2] = {(double)h->n, (double)h->n_fluid};   // before any ghost arrives: every particle is owned by exactly one rank
+        rc = sph_comm_allreduce(h, n_own, 2, 0); if (rc) return rc;
+        h->comm_n_global = (long long)n_own[0];
+        h->comm_nfluid_global = (long long)n_own[1];
         rc = slab_neighbor_search(h); if (rc) return rc;
     }
     else ph_neighbor_search(h);
@@ -541,7 +557,6 @@ extern "C" int sph_prepare(SphHandle *h) {
 // First half of a step: everything the reference's _step() does before `self.rigid_solver.step()`.
 static int step_first_half(SphHandle *h, bool allow_readback) {
     if (h->in_step) return fail(h, SPH_ERR_INVALID, "sph_step_begin: the previous step was not ended");
-    if (h->st.slab_active && h->prm.method == SPH_METHOD_PCISPH) return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding: wcsph and dfsph (pcisph's per-iteration ghost exchange is not built)");
     step_begin(h);
     int rc;
     switch (h->prm.method) {
@@ -563,10 +578,11 @@ static int step_second_half(SphHandle *h, bool allow_readback) {
     h->in_step = false;
     if (h->pose_dirty) { ProfScope p(h, SPH_K_MISC); h->L->renew_rigid(s); h->pose_dirty = false; }
     if (h->n > h->n_mark) {
-        if (s.slab_active) return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding: objects must be present at prepare() (late entry is single-GPU)");
         ProfScope p(h, SPH_K_MISC);
         h->L->post_insert(s, h->n_mark, h->prm.method != SPH_METHOD_DFSPH);
     }
+    // (late entry under sharding: every rank appended the part of the object that lies in its slab, possibly nothing; the
+    //  host tells the library the object's whole size through sph_comm_add_global_count -- no collective per step)
     if (h->prm.method == SPH_METHOD_DFSPH) {
         int rc = dfsph_step_end(h, allow_readback); if (rc) return rc;
         if (h->fresh_state == 1) { h->fresh_state = 2; ph_rigid_volume(h); }  // base_solver.py:696 on the fresh grid: now it sees them
@@ -810,4 +826,29 @@ extern "C" int sph_upload(SphHandle *h, int field, const void *src, size_t bytes
         return SPH_OK;
     }
     return fail(h, SPH_ERR_UNSUPPORTED, "upload: field %d is read-only", field);
+}
+
+// ---------------------------------------------------------------------------------- mesh -> particles (host code)
+// replaces trimesh's `mesh.voxelized(pitch).fill().points` (base_container.py:641-642).  Call with out == NULL to get the
+// count, then with a buffer of 3 * count floats.
+extern "C" int sph_voxelize_mesh(const double *vertices, int n_vertices, const int32_t *faces, int n_faces, double pitch,
+                                 float *out_xyz, int64_t capacity_points, int64_t *n_points) {
+    if (!vertices || !faces || !n_points) return SPH_ERR_INVALID;
+    for (int k = 0; k < 3 * n_faces; ++k) if (faces[k] < 0 || faces[k] >= n_vertices) return SPH_ERR_INVALID;
+    std::vector<float> pts;
+    if (sphvox::voxelize_fill(vertices, n_vertices, faces, n_faces, pitch, pts) != 0) return SPH_ERR_INVALID;
+    *n_points = (int64_t)(pts.size() / 3);
+    if (!out_xyz) return SPH_OK;
+    if (capacity_points < *n_points) return SPH_ERR_CAPACITY;
+    memcpy(out_xyz, pts.data(), pts.size() * sizeof(float));
+    return SPH_OK;
+}
+
+// replaces `mesh.contains(points)` on the np.arange lattice of base_container.py:686-694: inside[(i*ny + j)*nz + k] = 1 if
+// (xs[i], ys[j], zs[k]) lies inside the closed mesh
+extern "C" int sph_points_in_mesh(const double *vertices, int n_vertices, const int32_t *faces, int n_faces, const double *xs,
+                                  int nx, const double *ys, int ny, const double *zs, int nz, uint8_t *inside) {
+    if (!vertices || !faces || !xs || !ys || !zs || !inside) return SPH_ERR_INVALID;
+    for (int k = 0; k < 3 * n_faces; ++k) if (faces[k] < 0 || faces[k] >= n_vertices) return SPH_ERR_INVALID;
+    return sphvox::contains_lattice(vertices, n_vertices, faces, n_faces, xs, nx, ys, ny, zs, nz, inside) == 0 ? SPH_OK : SPH_ERR_INVALID;
 }

@@ -98,7 +98,8 @@ struct CgApPass {
     static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
-    static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
+    static constexpr bool HAS_B = true, COUNT_PAIRS = true;
+    static constexpr bool HAS_REDUCE = true;   // per-workgroup partial of p . Ap (the denominator of alpha, :394): no separate dot kernel
     static constexpr int PAIR_WEIGHT = 1;
     typedef float4 BT;
     struct Own { float m; float d[9]; float x, y, z; };
@@ -159,8 +160,9 @@ struct CgApPass {
         const float4 p = cg_p[i];
         float x = o.x * c.dt, y = o.y * c.dt, z = o.z * c.dt;
         x = fdiv(x, c.rho0); y = fdiv(y, c.rho0); z = fdiv(z, c.rho0);
-        cg_Ap[i] = make_float4(x + p.x, y + p.y, z + p.z, 0.f);
-        return 0.0f;
+        const float4 a = make_float4(x + p.x, y + p.y, z + p.z, 0.f);
+        cg_Ap[i] = a;
+        return p.x * a.x + p.y * a.y + p.z * a.z;
     }
     __device__ void passive(const Consts &, int, const float4 &) const {}
 };
@@ -196,7 +198,7 @@ k_cg_prepare2(int n, const int *meta, int all_fluid, const float *dinv, const fl
     r[i] = rr; p[i] = rr;
 }
 
-// :394 compute_cg_alpha, partial sums of |r|^2 and p.Ap
+// partial sums of |r|^2 (and p.Ap): run once per solve, for the numerator of the first alpha (:394)
 __global__ void __launch_bounds__(256)
 k_cg_dots(int n, const int *meta, int all_fluid, const float4 *r, const float4 *p, const float4 *Ap, float *part_a, float *part_b,
           const int *stop_flag, const int *blk_list, const int *blk_count) {
@@ -213,45 +215,38 @@ k_cg_dots(int n, const int *meta, int all_fluid, const float4 *r, const float4 *
     block_sum2(num, den, part_a, part_b, blk);
 }
 
-// finishes a two-sum reduction; mode 0: alpha = num/den (:403); mode 1: beta = num/den, err = sqrt(num) (:427-431).
-// Inside a device-controlled loop (looped) mode 1 also counts the iteration and raises the stop flag when the
-// reference's `while tol > 1e-6` (:445) would leave the loop; the update_p that follows in the same iteration is then
-// skipped, which only touches cg_p -- re-initialised by the next solve (:318).
-__global__ void __launch_bounds__(256)
-k_cg_scalars(const float *part_a, const float *part_b, int nb, DevScalars *scal, int mode, int looped, float tol,
-             const int *blk_list, const int *blk_count) {
-    if (looped && scal->flags[0]) return;
-    __shared__ float s_a[4], s_b[4];
-    float a = 0.f, b = 0.f;
-    if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) { a += part_a[blk_list[k]]; b += part_b[blk_list[k]]; } }
-    else for (int k = threadIdx.x; k < nb; k += 256) { a += part_a[k]; b += part_b[k]; }
-    a = wave_sum(a); b = wave_sum(b);
-    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+// ---- one CG iteration in three launches (A p pass, x / r update, p update) instead of six: the kernels that consume a dot
+// product finish the reduction themselves -- every workgroup adds up the per-workgroup partials in the same fixed order, so
+// all of them hold the same alpha / beta -- and workgroup 0 of the p update does the loop's book-keeping (error, iteration
+// count, stop flag).  Partials: rr[2] (|r|^2, ping-pong: the x / r update reads one and writes the other), den (p . Ap, from
+// the A p pass), rold (|r|^2 before the update, the denominator of beta).
+__device__ __forceinline__ float cg_total(const float *part, int nb, const int *blk_list, const int *blk_count, float *s4) {
+    float a = 0.f;
+    if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) a += part[blk_list[k]]; }
+    else for (int k = threadIdx.x; k < nb; k += 256) a += part[k];
+    a = wave_sum(a);
+    __syncthreads();   // s4 may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float num = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
-        const float den = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
-        const float q = den > 1e-18f ? num / den : 0.0f;
-        if (mode == 0) scal->red[4] = q;                       // cg_alpha
-        else {
-            const float err = __builtin_sqrtf(num);
-            scal->red[5] = q; scal->red[3] = err;  // cg_beta, cg_error
-            if (looped) { scal->flags[1] += 1; if (!(err > tol)) scal->flags[0] = 1; }
-        }
-    }
+    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
-// :409 update_cg_x + :415 update_cg_r_and_beta (partials of |new_r|^2 and |r|^2)
+// :394 compute_cg_alpha + :409 update_cg_x + :415 update_cg_r_and_beta (partials)
 __global__ void __launch_bounds__(256)
-k_cg_update_xr(int n, const int *meta, int all_fluid, const DevScalars *scal, float4 *x, float4 *r, const float4 *p,
-               const float4 *Ap, float *part_a, float *part_b, const int *stop_flag, const int *blk_list, const int *blk_count) {
+k_cg_update_xr2(int n, int nb, const int *meta, int all_fluid, float4 *x, float4 *r, const float4 *p, const float4 *Ap,
+                const float *part_rr, const float *part_den, float *part_rr_next, float *part_rold, DevScalars *scal,
+                const int *stop_flag, const int *blk_list, const int *blk_count) {
     if (stop_flag && *stop_flag) return;
     const int blk = cg_block(blk_list, blk_count);
     if (blk < 0) return;
+    __shared__ float s4[4];
+    const float num_a = cg_total(part_rr, nb, blk_list, blk_count, s4);
+    const float den_a = cg_total(part_den, nb, blk_list, blk_count, s4);
+    const float alpha = den_a > 1e-18f ? num_a / den_a : 0.0f;     // :403
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal->red[4] = alpha;
     int i = blk * 256 + threadIdx.x;
     float num = 0.f, den = 0.f;
     if (i < n && is_fluid(meta, i, all_fluid)) {
-        const float alpha = scal->red[4];
         float4 xx = x[i];
         const float4 pp = p[i], rr = r[i], a = Ap[i];
         xx.x += alpha * pp.x; xx.y += alpha * pp.y; xx.z += alpha * pp.z;
@@ -261,23 +256,35 @@ k_cg_update_xr(int n, const int *meta, int all_fluid, const DevScalars *scal, fl
         den = rr.x * rr.x + rr.y * rr.y + rr.z * rr.z;
         r[i] = nr;
     }
-    block_sum2(num, den, part_a, part_b, blk);
+    block_sum2(num, den, part_rr_next, part_rold, blk);
 }
 
-// :434 update_p
+// :427-431 beta, error + :434 update_p; workgroup 0: loop book-keeping (:445 `while tol > 1e-6`)
 __global__ void __launch_bounds__(256)
-k_cg_update_p(int n, const int *meta, int all_fluid, const DevScalars *scal, const float4 *r, float4 *p, const int *stop_flag,
-              const int *blk_list, const int *blk_count) {
+k_cg_update_p2(int n, int nb, const int *meta, int all_fluid, const float4 *r, float4 *p, const float *part_rr_next,
+               const float *part_rold, DevScalars *scal, int looped, float tol, const int *stop_flag, const int *blk_list,
+               const int *blk_count) {
     if (stop_flag && *stop_flag) return;
     const int blk = cg_block(blk_list, blk_count);
     if (blk < 0) return;
+    __shared__ float s4[4];
+    const float num = cg_total(part_rr_next, nb, blk_list, blk_count, s4);
+    const float den = cg_total(part_rold, nb, blk_list, blk_count, s4);
+    const float beta = den > 1e-18f ? num / den : 0.0f;
     int i = blk * 256 + threadIdx.x;
-    if (i >= n || !is_fluid(meta, i, all_fluid)) return;
-    const float beta = scal->red[5];
-    const float4 rr = r[i];
-    float4 pp = p[i];
-    pp.x = rr.x + beta * pp.x; pp.y = rr.y + beta * pp.y; pp.z = rr.z + beta * pp.z;
-    p[i] = pp;
+    if (i < n && is_fluid(meta, i, all_fluid)) {
+        const float4 rr = r[i];
+        float4 pp = p[i];
+        pp.x = rr.x + beta * pp.x; pp.y = rr.y + beta * pp.y; pp.z = rr.z + beta * pp.z;
+        p[i] = pp;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float err = __builtin_sqrtf(num);
+        scal->red[5] = beta; scal->red[3] = err;   // cg_beta, cg_error
+        // raised after this workgroup's own p update; workgroups that see it early skip theirs, which only touches cg_p --
+        // re-initialised by the next solve (:318)
+        if (looped) { scal->flags[1] += 1; if (!(err > tol)) scal->flags[0] = 1; }
+    }
 }
 
 // :440 prepare_guess

@@ -7,7 +7,7 @@ static int implicit_viscosity_non_pressure(SphHandle *h) {
     const int fixed = h->prm.fixed_iterations;
     { ProfScope p(h, SPH_K_CG_PREPARE); h->L->cg_prepare(s); }                     // :510
     { ProfScope p(h, SPH_K_CG_AP); h->L->cg_ap(s); }                               // :511
-    { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_prepare2(s); }                     // :512
+    { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_prepare2(s); h->L->cg_alpha(s); }  // :512 (+ |r0|^2 for the first alpha)
     float tol = 1000.0f;
     int itr = 0;
     const int max_itr = fixed > 0 ? fixed : 1000;
@@ -15,13 +15,13 @@ static int implicit_viscosity_non_pressure(SphHandle *h) {
         int launched = 0;
         int rc = device_loop(h, max_itr, 3, 3, 1.0f, 1e-6, [&]() {
             { ProfScope p(h, SPH_K_CG_AP); h->L->cg_ap(s); }
-            { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_alpha(s); h->L->cg_update_xr(s); h->L->cg_update_p(s); }
+            { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_update_xr(s); h->L->cg_update_p(s); }
         }, &itr, &launched, &tol);
         if (rc) return rc;
     }
     while (fixed > 0 && itr < max_itr) {
         { ProfScope p(h, SPH_K_CG_AP); h->L->cg_ap(s); }
-        { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_alpha(s); h->L->cg_update_xr(s); h->L->cg_update_p(s); }
+        { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_update_xr(s); h->L->cg_update_p(s); }
         itr++;
         if (fixed > 0) continue;
         int rc = read_red(h, 3, &tol); if (rc) return rc;                          // :457 tol = cg_error[None]

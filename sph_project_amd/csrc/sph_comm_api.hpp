@@ -428,6 +428,14 @@ static int slab_rebalance(SphHandle *h) {
     return SPH_OK;
 }
 
+// An object entered late (entryTime > 0): `n` particles in the whole scene, of which this rank appended its slab's share.
+// Keeps particle_num of the scene (the denominator of DFSPH's residual means, DFSPH.py:212 / :293) right on every rank.
+extern "C" int sph_comm_add_global_count(SphHandle *h, int n, int n_fluid) {
+    if (!h || !h->comm.kind || n < 0 || n_fluid < 0 || n_fluid > n) return fail(h, SPH_ERR_INVALID, "comm_add_global_count: bad arguments");
+    if (h->prepared) { h->comm_n_global += n; h->comm_nfluid_global += n_fluid; }   // before prepare() the counts are all-reduced there
+    return SPH_OK;
+}
+
 extern "C" int sph_comm_set_rebalance(SphHandle *h, int every_steps) {
     if (!h || !h->comm.kind || every_steps < 0) return fail(h, SPH_ERR_INVALID, "comm_set_rebalance: bad arguments");
     h->comm.rebalance_every = every_steps;
@@ -535,18 +543,20 @@ static int slab_exchange_scalar(SphHandle *h, float *arr) {
     return SPH_OK;
 }
 
-// velocities of the boundary particles -> ghost copies (16 B records, mass untouched)
-static int slab_exchange_vel(SphHandle *h) {
+// xyz of a float4 per-particle array of the boundary particles -> ghost copies (16 B records, w untouched); default: the
+// velocities
+static int slab_exchange_vel(SphHandle *h, float4 *arr = nullptr) {
     State &s = h->st;
     SlabComm &c = h->comm;
+    if (!arr) arr = s.velm.cur();
     ProfScope p(h, SPH_K_HALO);
-    for (int side = 0; side < 2; ++side) h->L->halo_pack_vel(s, side, c.n_send[side], c.n_recv[side]);
+    for (int side = 0; side < 2; ++side) h->L->halo_pack_vel(s, side, c.n_send[side], c.n_recv[side], arr);
     const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
     void *recv[2] = {s.recvbuf[0], s.recvbuf[1]};
     const size_t bs[2] = {(size_t)(c.n_send[0] + c.n_recv[0]) * 16, (size_t)(c.n_send[1] + c.n_recv[1]) * 16};
     size_t br[2] = {bs[0], bs[1]};
     int rc = comm_exchange(h, send, bs, recv, br, true); if (rc) return rc;
-    for (int side = 0; side < 2; ++side) h->L->halo_unpack_vel(s, side, c.n_recv[side], c.n_send[side]);
+    for (int side = 0; side < 2; ++side) h->L->halo_unpack_vel(s, side, c.n_recv[side], c.n_send[side], arr);
     return SPH_OK;
 }
 

@@ -105,6 +105,7 @@ struct State {
     // CG (implicit viscosity)
     float4 *cg_p, *cg_Ap, *cg_x, *cg_b, *cg_r, *cg_v0;
     float *cg_dinv;      // 9 floats per particle
+    int cg_parity;       // which of the two |r|^2 partial arrays the next x / r update reads
     // reductions
     float *red_partial;  // per-block partial sums
     int red_blocks;
@@ -175,8 +176,8 @@ struct Launch {
     void (*halo_unpack_fields)(State &, int side, int n_recv, int n_send);
     void (*halo_pack_scalar)(State &, int side, int n_send, int n_recv, const float *src);
     void (*halo_unpack_scalar)(State &, int side, int n_recv, int n_send, float *dst);
-    void (*halo_pack_vel)(State &, int side, int n_send, int n_recv);
-    void (*halo_unpack_vel)(State &, int side, int n_recv, int n_send);
+    void (*halo_pack_vel)(State &, int side, int n_send, int n_recv, const float4 *arr);   // xyz of a float4 array
+    void (*halo_unpack_vel)(State &, int side, int n_recv, int n_send, float4 *arr);
     void (*count_ghosts)(State &, int *out);
     void (*layer_hist)(State &, int *hist);      // owned particles per global cell layer
     void (*loop_criterion)(State &, int slot);   // stop test on an all-reduced residual (sharded solver loops)

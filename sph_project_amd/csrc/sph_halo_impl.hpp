@@ -53,15 +53,16 @@ static void l_halo_unpack_scalar(State &s, int side, int n_recv, int n_send, flo
     hipLaunchKernelGGL(k_halo_unpack_scalar, dim3(cdiv(n_send + n_recv, 256)), dim3(256), 0, s.stream, n_recv, n_send,
                        s.halo_tab[HALO_GHOST - 1 + side], s.halo_tab[HALO_ECHO_GHOST - 1 + side], (const float *)s.recvbuf[side], dst);
 }
-static void l_halo_pack_vel(State &s, int side, int n_send, int n_recv) {
+// xyz of a float4 array (velocities: velm, the mass in w stays; PCISPH predicted positions: ppos)
+static void l_halo_pack_vel(State &s, int side, int n_send, int n_recv, const float4 *arr) {
     if (n_send + n_recv <= 0) return;
     hipLaunchKernelGGL(k_halo_pack_vel, dim3(cdiv(n_send + n_recv, 256)), dim3(256), 0, s.stream, n_send, n_recv,
-                       s.halo_tab[HALO_SEND - 1 + side], s.halo_tab[HALO_ECHO_SEND - 1 + side], s.velm.cur(), s.sendbuf[side]);
+                       s.halo_tab[HALO_SEND - 1 + side], s.halo_tab[HALO_ECHO_SEND - 1 + side], arr, s.sendbuf[side]);
 }
-static void l_halo_unpack_vel(State &s, int side, int n_recv, int n_send) {
+static void l_halo_unpack_vel(State &s, int side, int n_recv, int n_send, float4 *arr) {
     if (n_send + n_recv <= 0) return;
     hipLaunchKernelGGL(k_halo_unpack_vel, dim3(cdiv(n_send + n_recv, 256)), dim3(256), 0, s.stream, n_recv, n_send,
-                       s.halo_tab[HALO_GHOST - 1 + side], s.halo_tab[HALO_ECHO_GHOST - 1 + side], s.recvbuf[side], s.velm.cur());
+                       s.halo_tab[HALO_GHOST - 1 + side], s.halo_tab[HALO_ECHO_GHOST - 1 + side], s.recvbuf[side], arr);
 }
 static void l_loop_criterion(State &s, int slot) {
     if (!s.loop_flag || s.loop_slot != slot) return;

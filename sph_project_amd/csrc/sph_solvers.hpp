@@ -207,8 +207,8 @@ struct PcisphRhoStarPass {
         bj.x = q.x; bj.y = q.y; bj.z = q.z;
         return p;
     }
-    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
-        if (!AF && META_MAT(meta[i]) != 1) return false;
+    __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
+        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
         const float4 q = ppos[i];
         o.px = q.x; o.py = q.y; o.pz = q.z; o.sum = 0.0f;
         return true;
@@ -256,8 +256,8 @@ struct PcisphPressureAccelPass {
     __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
-    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
-        if (!AF && META_MAT(meta[i]) != 1) return false;
+    __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
+        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
         o.pt = ptm[i];
         o.ax = o.ay = o.az = 0.0f;
         return true;

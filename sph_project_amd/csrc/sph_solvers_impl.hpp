@@ -123,9 +123,11 @@ static void l_cg_prepare(State &s) {
     if (s.c.all_fluid) { CgPreparePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p, 2); }
     else { CgPreparePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p, 2); }
 }
+// partial-sum arrays of the CG kernels inside red_partial (each red_blocks floats): rr ping-pong, p . Ap, |r_old|^2
+#define CG_PART(k) (s.red_partial + (size_t)(k) * s.red_blocks)
 static void l_cg_ap(State &s) {
-    if (s.c.all_fluid) { CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, s.red_partial}; launch_pass(s, p, 2); }
-    else { CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, s.red_partial}; launch_pass(s, p, 2); }
+    if (s.c.all_fluid) { CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2)}; launch_pass(s, p, 2); }
+    else { CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2)}; launch_pass(s, p, 2); }
 }
 static void l_cg_prepare2(State &s) {
     if (s.c.n == 0) return;
@@ -133,23 +135,26 @@ static void l_cg_prepare2(State &s) {
 }
 // the per-particle CG kernels run the workgroups that hold fluid only (same list as the neighbour passes)
 #define CG_LIST (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_list : nullptr, (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_count : nullptr
+// |r0|^2 partials of a fresh solve (the numerator of the first alpha); later iterations reuse the |new r|^2 partials of
+// the previous x / r update, which are the same numbers
 static void l_cg_alpha(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
-    float *pa = s.red_partial, *pb = s.red_partial + s.red_blocks;
-    hipLaunchKernelGGL(k_cg_dots, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_r, s.cg_p, s.cg_Ap, pa, pb, s.loop_flag, CG_LIST);
-    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 0, s.loop_flag ? 1 : 0, (float)s.loop_thr, CG_LIST);
+    s.cg_parity = 0;
+    hipLaunchKernelGGL(k_cg_dots, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_r, s.cg_p, s.cg_Ap, CG_PART(0), CG_PART(3), (const int *)nullptr, CG_LIST);
 }
 static void l_cg_update_xr(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
-    float *pa = s.red_partial, *pb = s.red_partial + s.red_blocks;
-    hipLaunchKernelGGL(k_cg_update_xr, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap, pa, pb, s.loop_flag, CG_LIST);
-    hipLaunchKernelGGL(k_cg_scalars, dim3(1), dim3(256), 0, s.stream, pa, pb, nb, s.scal, 1, s.loop_flag ? 1 : 0, (float)s.loop_thr, CG_LIST);
+    hipLaunchKernelGGL(k_cg_update_xr2, dim3(nb), dim3(256), 0, s.stream, s.c.n, nb, s.meta.cur(), s.c.all_fluid, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap,
+                       CG_PART(s.cg_parity), CG_PART(2), CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag, CG_LIST);
 }
 static void l_cg_update_p(State &s) {
     if (s.c.n == 0) return;
-    hipLaunchKernelGGL(k_cg_update_p, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.scal, s.cg_r, s.cg_p, s.loop_flag, CG_LIST);
+    const int nb = cdiv(s.c.n, 256);
+    hipLaunchKernelGGL(k_cg_update_p2, dim3(nb), dim3(256), 0, s.stream, s.c.n, nb, s.meta.cur(), s.c.all_fluid, s.cg_r, s.cg_p,
+                       CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag ? 1 : 0, (float)s.loop_thr, s.loop_flag, CG_LIST);
+    s.cg_parity = 1 - s.cg_parity;
 }
 static void l_cg_prepare_guess(State &s) {
     if (s.c.n == 0) return;

@@ -190,31 +190,39 @@ static int dfsph_step_end(SphHandle *h, bool allow_readback) {
     return dfsph_divergence(h, allow_readback);                               // :319
 }
 
-// PCISPH.py:110 refine
+// PCISPH.py:110 refine.  Under slab sharding the ghosts' p / rho^2 goes out between the two passes of an
+// iteration and their predicted positions after it; the density error is summed over the ranks.
 static int pcisph_refine(SphHandle *h, bool allow_readback) {
     State &s = h->st;
     const int fixed = h->prm.fixed_iterations;
     const int max_itr = fixed > 0 ? fixed : 1000;
     int itr = 0;
     float err = 100.0f;
+    const float n_fl = (float)(s.slab_active ? h->comm_nfluid_global : (long long)h->n_fluid);   // PCISPH.py:43-46 divides by fluid_particle_num
+    int comm_rc = SPH_OK;
+    auto iteration = [&]() {
+        { ProfScope p(h, SPH_K_PCISPH_RHO_STAR); h->L->pcisph_rho_star(s); }
+        if (s.slab_active && !comm_rc) comm_rc = slab_exchange_scalar(h, s.ptm);
+        { ProfScope p(h, SPH_K_PCISPH_PRESSURE_ACCEL); h->L->pcisph_pressure_accel(s); }
+        if (s.slab_active && !comm_rc) comm_rc = slab_exchange_vel(h, s.ppos);
+        if (s.slab_active && !comm_rc) comm_rc = slab_finish_reduction(h, 2);
+    };
     if (fixed <= 0 && allow_readback) {
         int launched = 0; float sum = 0.0f;
-        int rc = device_loop(h, max_itr, 2, 2, (float)h->n_fluid, 0.001, [&]() {   // PCISPH.py:43-46, :122
-            { ProfScope p(h, SPH_K_PCISPH_RHO_STAR); h->L->pcisph_rho_star(s); }
-            { ProfScope p(h, SPH_K_PCISPH_PRESSURE_ACCEL); h->L->pcisph_pressure_accel(s); }
-        }, &itr, &launched, &sum);
+        int rc = device_loop(h, max_itr, 2, 2, n_fl, 0.001, iteration, &itr, &launched, &sum);   // PCISPH.py:43-46, :122
         if (rc) return rc;
-        h->last.iter_pcisph = itr; h->last.err_pcisph = h->n_fluid > 0 ? sum / (float)h->n_fluid : 0.0f;
+        if (comm_rc) return comm_rc;
+        h->last.iter_pcisph = itr; h->last.err_pcisph = n_fl > 0 ? sum / n_fl : 0.0f;
         return SPH_OK;
     }
     while (itr < max_itr) {
-        { ProfScope p(h, SPH_K_PCISPH_RHO_STAR); h->L->pcisph_rho_star(s); }
-        { ProfScope p(h, SPH_K_PCISPH_PRESSURE_ACCEL); h->L->pcisph_pressure_accel(s); }
+        iteration();
+        if (comm_rc) return comm_rc;
         itr++;
         if (fixed > 0) continue;
         if (!allow_readback) return fail(h, SPH_ERR_UNSUPPORTED, "pcisph needs host read-back unless fixed_iterations > 0");
         float sum; int rc = read_red(h, 2, &sum); if (rc) return rc;
-        err = h->n_fluid > 0 ? sum / (float)h->n_fluid : 0.0f;       // PCISPH.py:43-46
+        err = n_fl > 0 ? sum / n_fl : 0.0f;                          // PCISPH.py:43-46
         if (err < 0.001f) break;                                    // :122
     }
     h->last.iter_pcisph = itr; h->last.err_pcisph = err;
@@ -223,11 +231,14 @@ static int pcisph_refine(SphHandle *h, bool allow_readback) {
 
 static int pcisph_step(SphHandle *h, bool allow_readback) {
     State &s = h->st;
-    ph_neighbor_search(h);                                                    // PCISPH.py:166
+    if (s.slab_active) { int rc = slab_neighbor_search(h); if (rc) return rc; }   // + migration / ghost exchange
+    else ph_neighbor_search(h);                                               // PCISPH.py:166
     ph_rigid_volume(h);
     { ProfScope p(h, SPH_K_DENSITY); h->L->density(s, 0); }                   // :167
+    if (s.slab_active) { int rc = slab_exchange_scalar(h, s.rho.cur()); if (rc) return rc; }   // ghost densities (viscosity)
     int rc = run_non_pressure(h); if (rc) return rc;                          // :168 (+ :174, v* kept aside)
     { ProfScope p(h, SPH_K_MISC); h->L->pcisph_init(s); }                     // :169
+    if (s.slab_active) { rc = slab_exchange_vel(h, s.ppos); if (rc) return rc; }   // predicted positions of the ghosts
     rc = pcisph_refine(h, allow_readback); if (rc) return rc;                 // :170
     { ProfScope p(h, SPH_K_PRESSURE_INTEGRATE); h->L->pressure_integrate(s); } // :175-177, :185
     return SPH_OK;

@@ -1,6 +1,9 @@
 """Mesh -> particles without trimesh: what base_container.py:611 `load_rigid_body`
-(`mesh.voxelized(pitch).fill().points`) and :676 `load_fluid_body` (lattice points with `mesh.contains`) need,
-restated on numpy + scipy.ndimage.  Host-side preprocessing, not part of the accelerated path.
+(`mesh.voxelized(pitch).fill().points`) and :676 `load_fluid_body` (lattice points with `mesh.contains`) need.
+`voxel_points` / `fluid_points` call the dependency-free C++ behind the C-ABI (`sph_voxelize_mesh`, `sph_points_in_mesh`:
+sph_project_amd/csrc/sph_voxel.hpp); the numpy + scipy.ndimage restatement they replaced stays below as
+`voxel_points_numpy` / `fluid_points_numpy`, the cross-check of tests/test_meshgen.py (same point sets, bit for bit).
+Host-side preprocessing, not part of the accelerated path.
 
 Parity: UNPINNED -- trimesh is not installed here, so these follow its published algorithms (subdivision voxeliser:
 surface samples rounded to the lattice of integer multiples of `pitch`, then `binary_fill_holes`; containment by
@@ -115,9 +118,51 @@ def contains_lattice(mesh, axes):
     return inside
 
 
+def _mesh_arrays(mesh):
+    v = np.ascontiguousarray(mesh.vertices, dtype=np.float64).reshape(-1, 3)
+    f = np.ascontiguousarray(mesh.faces, dtype=np.int32).reshape(-1, 3)
+    return v, f
+
+
 def fluid_points(mesh, pitch):
     """base_container.py:686-694: np.arange lattice over the bounding box, points the mesh contains, (n, 3) f32 in
-    meshgrid 'ij' order."""
+    meshgrid 'ij' order.  Containment through sph_points_in_mesh (C++)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    lo, hi = mesh.bounds
+    axes = [np.ascontiguousarray(np.arange(lo[k], hi[k], pitch), dtype=np.float64) for k in range(3)]
+    v, f = _mesh_arrays(mesh)
+    inside = np.zeros(len(axes[0]) * len(axes[1]) * len(axes[2]), dtype=np.uint8)
+    rc = lib.sph_points_in_mesh(v.ctypes.data_as(C.c_void_p), v.shape[0], f.ctypes.data_as(C.c_void_p), f.shape[0],
+                                axes[0].ctypes.data_as(C.c_void_p), len(axes[0]), axes[1].ctypes.data_as(C.c_void_p), len(axes[1]),
+                                axes[2].ctypes.data_as(C.c_void_p), len(axes[2]), inside.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError(f"sph_points_in_mesh failed ({rc})")
+    pts = np.array(np.meshgrid(*axes, sparse=False, indexing="ij"), dtype=np.float32).reshape(3, -1).T
+    return np.ascontiguousarray(pts[inside.astype(bool)])
+
+
+def voxel_points(mesh, pitch):
+    """base_container.py:641-642 `mesh.voxelized(pitch).fill().points` through sph_voxelize_mesh (C++)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    v, f = _mesh_arrays(mesh)
+    n = C.c_int64(0)
+    args = (v.ctypes.data_as(C.c_void_p), v.shape[0], f.ctypes.data_as(C.c_void_p), f.shape[0], float(pitch))
+    rc = lib.sph_voxelize_mesh(*args, None, 0, C.byref(n))
+    if rc != 0:
+        raise ValueError(f"sph_voxelize_mesh failed ({rc})")
+    out = np.empty((n.value, 3), dtype=np.float32)
+    rc = lib.sph_voxelize_mesh(*args, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+    if rc != 0:
+        raise ValueError(f"sph_voxelize_mesh failed ({rc})")
+    return out
+
+
+def fluid_points_numpy(mesh, pitch):
+    """numpy restatement of fluid_points (cross-check of the C++)."""
     lo, hi = mesh.bounds
     axes = [np.arange(lo[k], hi[k], pitch) for k in range(3)]
     inside = contains_lattice(mesh, axes)
@@ -125,9 +170,9 @@ def fluid_points(mesh, pitch):
     return np.ascontiguousarray(pts[inside.reshape(-1)])
 
 
-def voxel_points(mesh, pitch):
-    """base_container.py:641-642 `mesh.voxelized(pitch).fill().points`: centres (integer multiples of pitch) of the
-    voxels the surface touches plus the region they enclose."""
+def voxel_points_numpy(mesh, pitch):
+    """numpy + scipy.ndimage restatement of voxel_points (cross-check of the C++): centres (integer multiples of pitch)
+    of the voxels the surface touches plus the region they enclose."""
     from scipy import ndimage
     tri = mesh.vertices[mesh.faces]
     step = 0.5 * pitch

@@ -42,15 +42,19 @@ def main():
         ids = np.concatenate(container._global_ids)
         container.engine.upload(L.F_POSITION, pos[ids])
     solver.prepare()
+    hist = []
     for _ in range(steps):
         solver.step()
+        st = solver.stats()
+        hist.append((st["iter_pcisph"], st["err_pcisph"]))
     e = container.engine
     g = e.download(L.F_GHOST) == 1
     info = e.comm_get_slab()
     np.savez(out, ids=e.download(L.F_PARTICLE_ID)[~g], pos=e.download(L.F_POSITION)[~g], vel=e.download(L.F_VELOCITY)[~g],
              rho=e.download(L.F_DENSITY)[~g], prs=e.download(L.F_PRESSURE)[~g], n_ghost=info["n_ghost"], cuts=np.array(cuts),
              pairs=solver.stats()["pair_interactions"], iter_density=solver.stats()["iter_density"],
-             iter_divergence=solver.stats()["iter_divergence"], z_lo=info["z_lo"], z_hi=info["z_hi"])
+             iter_divergence=solver.stats()["iter_divergence"], iter_pcisph=solver.stats()["iter_pcisph"], hist=np.array(hist, np.float64),
+             err_pcisph=solver.stats()["err_pcisph"], z_lo=info["z_lo"], z_hi=info["z_hi"])
     print(f"rank {rank}: slab {info['z_lo']}..{info['z_hi']} owned {info['n_owned']} ghosts {info['n_ghost']}")
 
 

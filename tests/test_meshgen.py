@@ -78,3 +78,30 @@ def test_sphere_counts_match_its_volume():
     # the filled voxel set covers the interior lattice and adds a shell of surface voxels
     assert len(vox) > len(pts) and len(vox) * pitch ** 3 < 1.25 * vol
     assert np.all(np.linalg.norm(vox - 1.0, axis=1) <= 0.3 + pitch)
+
+
+@pytest.mark.parametrize("pitch", [0.02, 0.031])
+def test_cpp_voxeliser_equals_the_numpy_restatement(pitch):
+    """sph_voxelize_mesh / sph_points_in_mesh (dependency-free C++ behind the C-ABI, what the containers use) against the
+    numpy + scipy.ndimage restatement: identical point sets, bit for bit, on a sphere, a rotated brick and a shape with a
+    through-hole (a torus: the hole must stay empty after filling)."""
+    shapes = [M.place(icosphere(3), [0.3, 0.25, 0.2], 0.3, [0, 1, 1], [1.0, 0.7, 1.3])]
+    cube = M.Mesh(CUBE_V, np.array([[q[0], q[1], q[2]] for q in CUBE_Q] + [[q[0], q[2], q[3]] for q in CUBE_Q]) - 1)
+    shapes.append(M.place(cube, [0.4, 0.2, 0.3], 0.7, [1, 0.2, 0.4], [0.5, 0.5, 0.5]))
+    # torus
+    nu, nv, R, r = 40, 20, 0.3, 0.1
+    u, v = np.meshgrid(np.arange(nu) * 2 * np.pi / nu, np.arange(nv) * 2 * np.pi / nv, indexing="ij")
+    tv = np.stack([(R + r * np.cos(v)) * np.cos(u), (R + r * np.cos(v)) * np.sin(u), r * np.sin(v)], -1).reshape(-1, 3) + 0.6
+    idx = lambda i, j: (i % nu) * nv + (j % nv)
+    tf = [[idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)] for i in range(nu) for j in range(nv)] + \
+         [[idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)] for i in range(nu) for j in range(nv)]
+    shapes.append(M.Mesh(tv, tf))
+    for k, mesh in enumerate(shapes):
+        a, b = M.voxel_points(mesh, pitch), M.voxel_points_numpy(mesh, pitch)
+        assert a.dtype == np.float32 and a.shape == b.shape and np.array_equal(a, b), (k, a.shape, b.shape)
+        c, d = M.fluid_points(mesh, pitch), M.fluid_points_numpy(mesh, pitch)
+        assert c.shape == d.shape and np.array_equal(c, d), (k, c.shape, d.shape)
+        assert len(a) > 0 and len(c) > 0
+    # the torus' hole: no voxel on its axis
+    tor = M.voxel_points(shapes[2], pitch)
+    assert np.all(np.hypot(tor[:, 0] - 0.6, tor[:, 1] - 0.6) > 0.1)
