@@ -217,6 +217,11 @@ def c4_sharded(args, rank, world, device, lib):
 
 # ----------------------------------------------------------------------------------------------- one rank
 def run_rank(args, rank, world, local_rank):
+    # stdout carries ONE JSON line and nothing else: librccl prints a version banner through C stdio (flushed at exit,
+    # i.e. after the line), so everything but the line is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     from sph_project_amd import _lib as L, product as P
     lib = L.load()
     method = args.method or ("dfsph" if args.config == "c3" else "wcsph")
@@ -414,8 +419,8 @@ def run_rank(args, rank, world, local_rank):
             except OSError:
                 pass
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 def main():

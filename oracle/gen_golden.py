@@ -85,6 +85,10 @@ SCENES = {
     "dfsph_implicit_emitter": (dam_break_scene(method="dfsph", end=(0.1, 0.2, 0.1), translation=(0.1, 0.2, 0.1), dt=6e-4,
                                                viscosity=50.0, viscosity_method="implicit", velocity=(0.0, -2.5, 0.0),
                                                gravitationUpper=0.31), 0.0, 0, [1, 6, 12]),
+    # implicit viscosity under WCSPH: the solve runs BEFORE compute_pressure clamps particle_densities (WCSPH.py:29-33), i.e. on
+    # the unclamped densities -- a free-surface block, so that rho < rho0 on most particles
+    "wcsph_implicit": (dam_break_scene(end=(0.12, 0.14, 0.12), viscosity=50.0, viscosity_method="implicit",
+                                       velocity=(0.2, -0.5, 0.1)), 0.003, 41, [1, 2, 3]),
     # late entry (base_container.py:218-221): a second block whose entryTime falls into the 4th step; inserted by
     # _step() itself (WCSPH.py:41, DFSPH.py:307, PCISPH.py:181)
     "wcsph_late": (late_scene("wcsph", 4e-4), 0.0, 0, [2, 4, 6]),

@@ -39,8 +39,8 @@ struct CgPreparePass {
     __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
-    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
-        if (!AF && META_MAT(meta[i]) != 1) return false;
+    __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
+        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
         o.m = velm[i].w; o.rho = rho[i];
 #pragma unroll
         for (int k = 0; k < 9; ++k) o.a[k] = 0.0f;
@@ -116,8 +116,8 @@ struct CgApPass {
     __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
-    __device__ bool begin(const Consts &, int i, const float4 &, Own &o) const {
-        if (!AF && META_MAT(meta[i]) != 1) return false;
+    __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
+        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
         o.m = velm[i].w;
 #pragma unroll
         for (int k = 0; k < 9; ++k) o.d[k] = dinv[(size_t)i * 9 + k];
@@ -179,7 +179,8 @@ __device__ __forceinline__ void block_sum2(float a, float b, float *out_a, float
     }
 }
 
-__device__ __forceinline__ bool is_fluid(const int *meta, int i, int all_fluid) { return all_fluid || META_MAT(meta[i]) == 1; }
+// slab sharding: ghosts are somebody else's rows of the system (launchers pass all_fluid = 0 when there are ghosts)
+__device__ __forceinline__ bool is_fluid(const int *meta, int i, int all_fluid) { return all_fluid || META_ACTIVE_FLUID(meta[i]); }
 // workgroup index of a vector kernel: the k-th listed workgroup when only those that hold fluid are launched (-1: none)
 __device__ __forceinline__ int cg_block(const int *blk_list, const int *blk_count) {
     if (!blk_list) return blockIdx.x;
@@ -231,17 +232,29 @@ __device__ __forceinline__ float cg_total(const float *part, int nb, const int *
     return (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
+// Slab sharding: the dot products are sums over all ranks.  One workgroup adds up this rank's partials into out[0..1]; the
+// step orchestration all-reduces the two floats in place (slab_allreduce_dev) and the update kernels take them from there
+// (`glob`) instead of adding up the partials themselves.
+__global__ void __launch_bounds__(256)
+k_cg_fold(int nb, const float *part_a, const float *part_b, float *out_a, float *out_b, const int *stop_flag, const int *blk_list,
+          const int *blk_count) {
+    if (stop_flag && *stop_flag) return;
+    __shared__ float s4[4];
+    if (part_a) { const float a = cg_total(part_a, nb, blk_list, blk_count, s4); if (threadIdx.x == 0) *out_a = a; }
+    if (part_b) { const float b = cg_total(part_b, nb, blk_list, blk_count, s4); if (threadIdx.x == 0) *out_b = b; }
+}
+
 // :394 compute_cg_alpha + :409 update_cg_x + :415 update_cg_r_and_beta (partials)
 __global__ void __launch_bounds__(256)
 k_cg_update_xr2(int n, int nb, const int *meta, int all_fluid, float4 *x, float4 *r, const float4 *p, const float4 *Ap,
                 const float *part_rr, const float *part_den, float *part_rr_next, float *part_rold, DevScalars *scal,
-                const int *stop_flag, const int *blk_list, const int *blk_count) {
+                const int *stop_flag, const int *blk_list, const int *blk_count, const float *glob) {
     if (stop_flag && *stop_flag) return;
     const int blk = cg_block(blk_list, blk_count);
     if (blk < 0) return;
     __shared__ float s4[4];
-    const float num_a = cg_total(part_rr, nb, blk_list, blk_count, s4);
-    const float den_a = cg_total(part_den, nb, blk_list, blk_count, s4);
+    const float num_a = glob ? glob[0] : cg_total(part_rr, nb, blk_list, blk_count, s4);
+    const float den_a = glob ? glob[1] : cg_total(part_den, nb, blk_list, blk_count, s4);
     const float alpha = den_a > 1e-18f ? num_a / den_a : 0.0f;     // :403
     if (blockIdx.x == 0 && threadIdx.x == 0) scal->red[4] = alpha;
     int i = blk * 256 + threadIdx.x;
@@ -263,13 +276,13 @@ k_cg_update_xr2(int n, int nb, const int *meta, int all_fluid, float4 *x, float4
 __global__ void __launch_bounds__(256)
 k_cg_update_p2(int n, int nb, const int *meta, int all_fluid, const float4 *r, float4 *p, const float *part_rr_next,
                const float *part_rold, DevScalars *scal, int looped, float tol, const int *stop_flag, const int *blk_list,
-               const int *blk_count) {
+               const int *blk_count, const float *glob) {
     if (stop_flag && *stop_flag) return;
     const int blk = cg_block(blk_list, blk_count);
     if (blk < 0) return;
     __shared__ float s4[4];
-    const float num = cg_total(part_rr_next, nb, blk_list, blk_count, s4);
-    const float den = cg_total(part_rold, nb, blk_list, blk_count, s4);
+    const float num = glob ? glob[0] : cg_total(part_rr_next, nb, blk_list, blk_count, s4);
+    const float den = glob ? glob[1] : cg_total(part_rold, nb, blk_list, blk_count, s4);
     const float beta = den > 1e-18f ? num / den : 0.0f;
     int i = blk * 256 + threadIdx.x;
     if (i < n && is_fluid(meta, i, all_fluid)) {

@@ -5,27 +5,45 @@
 static int implicit_viscosity_non_pressure(SphHandle *h) {
     State &s = h->st;
     const int fixed = h->prm.fixed_iterations;
+    const bool slab = s.slab_active != 0;
+    int comm_rc = SPH_OK;
+    // Slab sharding: the ghosts are the neighbour ranks' rows of the system.  Their search direction goes out before every
+    // A p pass (12 B per ghost through the slot tables), the three dot products of an iteration are summed over the ranks
+    // (k_cg_fold + one 1-float and one 2-float all-reduce), and the solved velocities of the ghosts after the loop.
+    auto refresh = [&](float4 *arr) { if (slab && !comm_rc) comm_rc = slab_exchange_vel(h, arr); };
+    auto dots = [&](int which) {
+        if (!slab || comm_rc) return;
+        { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_fold(s, which); }
+        comm_rc = which == 1 ? slab_allreduce_dev(h, &s.scal->red[7], 1) : slab_allreduce_dev(h, &s.scal->red[6], which == 0 ? 1 : 2);
+    };
+    auto iteration = [&]() {
+        refresh(s.cg_p);
+        { ProfScope p(h, SPH_K_CG_AP); h->L->cg_ap(s); }
+        dots(1);
+        { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_update_xr(s); }
+        dots(2);
+        { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_update_p(s); }
+    };
     { ProfScope p(h, SPH_K_CG_PREPARE); h->L->cg_prepare(s); }                     // :510
+    refresh(s.cg_p);                                                               // the ghosts' initial guess
     { ProfScope p(h, SPH_K_CG_AP); h->L->cg_ap(s); }                               // :511
     { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_prepare2(s); h->L->cg_alpha(s); }  // :512 (+ |r0|^2 for the first alpha)
+    dots(0);
     float tol = 1000.0f;
     int itr = 0;
     const int max_itr = fixed > 0 ? fixed : 1000;
     if (fixed <= 0) {   // :445 conjugate_gradient_loop, stop test on the device (see device_loop)
         int launched = 0;
-        int rc = device_loop(h, max_itr, 3, 3, 1.0f, 1e-6, [&]() {
-            { ProfScope p(h, SPH_K_CG_AP); h->L->cg_ap(s); }
-            { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_update_xr(s); h->L->cg_update_p(s); }
-        }, &itr, &launched, &tol);
+        int rc = device_loop(h, max_itr, 3, 3, 1.0f, 1e-6, iteration, &itr, &launched, &tol);
         if (rc) return rc;
     }
     while (fixed > 0 && itr < max_itr) {
-        { ProfScope p(h, SPH_K_CG_AP); h->L->cg_ap(s); }
-        { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_update_xr(s); h->L->cg_update_p(s); }
+        iteration();
         itr++;
-        if (fixed > 0) continue;
-        int rc = read_red(h, 3, &tol); if (rc) return rc;                          // :457 tol = cg_error[None]
     }
+    if (comm_rc) return comm_rc;
+    refresh(s.cg_x);                                                               // solved velocities of the ghosts (:514)
+    if (comm_rc) return comm_rc;
     h->last.iter_cg = itr; h->last.err_cg = tol;
     // :514-516: the explicit viscosity formula evaluated with the solved velocities gives the acceleration; the
     // fused pass adds gravity + surface tension and advances the ORIGINAL velocities (:470, :643)

@@ -137,8 +137,6 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
     if (!h || !h->comm.kind) return fail(h, SPH_ERR_INVALID, "comm_set_slab: communicator not initialised");
     Consts &c = h->st.c;
     State &s = h->st;
-    if (h->prm.viscosity_implicit)
-        return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding: implicit viscosity (CG ghost exchange) is not built");
     if (z_lo < 0 || z_hi > c.nz_glob || z_hi - z_lo < 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: a slab needs >= 2 cell layers inside the grid");
     if (h->n > 0) return fail(h, SPH_ERR_INVALID, "comm_set_slab: set the slab before particles are appended");
     HIPCHK(h, hipSetDevice(h->device));
@@ -557,6 +555,28 @@ static int slab_exchange_vel(SphHandle *h, float4 *arr = nullptr) {
     size_t br[2] = {bs[0], bs[1]};
     int rc = comm_exchange(h, send, bs, recv, br, true); if (rc) return rc;
     for (int side = 0; side < 2; ++side) h->L->halo_unpack_vel(s, side, c.n_recv[side], c.n_send[side], arr);
+    return SPH_OK;
+}
+
+// `count` floats in device memory become their sums over all ranks, in place (CG dot products: scal->red[6..7]).
+// RCCL: one ncclAllReduce on the compute stream, no host sync.
+static int slab_allreduce_dev(SphHandle *h, float *dev, int count) {
+    State &s = h->st;
+    SlabComm &c = h->comm;
+    if (c.nranks <= 1) return SPH_OK;
+    ProfScope p(h, SPH_K_HALO);
+    if (c.kind == 1) {
+        NCCLCHK(h, ncclAllReduce(dev, dev, (size_t)count, ncclFloat, ncclSum, (ncclComm_t)c.nccl, s.stream));
+        return SPH_OK;
+    }
+    float v[8]; double d[8];
+    if (count > 8) return fail(h, SPH_ERR_INVALID, "slab_allreduce_dev: count");
+    HIPCHK(h, hipMemcpyAsync(v, dev, sizeof(float) * count, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(h, hipStreamSynchronize(s.stream));
+    for (int k = 0; k < count; ++k) d[k] = (double)v[k];
+    int rc = sph_comm_allreduce(h, d, count, 0); if (rc) return rc;
+    for (int k = 0; k < count; ++k) v[k] = (float)d[k];
+    HIPCHK(h, hipMemcpy(dev, v, sizeof(float) * count, hipMemcpyHostToDevice));
     return SPH_OK;
 }
 

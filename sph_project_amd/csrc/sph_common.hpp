@@ -189,6 +189,7 @@ struct Launch {
     void (*cg_update_xr)(State &);
     void (*cg_update_p)(State &);
     void (*cg_prepare_guess)(State &);
+    void (*cg_fold)(State &, int which);   // slab sharding: local sums of the dot-product partials -> scal->red[6..7]
 };
 
 const Launch *sph_launch_strict();

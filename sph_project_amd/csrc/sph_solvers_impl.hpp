@@ -119,19 +119,25 @@ static void l_pcisph_pressure_accel(State &s) {
 }
 
 // ---- implicit viscosity
+// WCSPH clamps particle_densities only after the non-pressure accelerations (WCSPH.py:29-33): its solve reads the unclamped
+// densities, like the explicit viscosity does (see l_non_pressure)
+#define CG_RHO (s.visc_rho_raw ? s.rho_raw : s.rho.cur())
 static void l_cg_prepare(State &s) {
-    if (s.c.all_fluid) { CgPreparePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p, 2); }
-    else { CgPreparePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p, 2); }
+    if (s.c.all_fluid) { CgPreparePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p, 2); }
+    else { CgPreparePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_x, s.cg_p, s.cg_b, s.cg_r, s.cg_Ap, s.cg_v0, s.cg_dinv, s.c.rho0, s.red_partial}; launch_pass(s, p, 2); }
 }
 // partial-sum arrays of the CG kernels inside red_partial (each red_blocks floats): rr ping-pong, p . Ap, |r_old|^2
 #define CG_PART(k) (s.red_partial + (size_t)(k) * s.red_blocks)
+#define CG_AF (s.c.all_fluid && !s.c.ghosts)   /* "every particle is a row of the system" */
+// slab sharding: all-reduced dot products live in scal->red[6..7] (see k_cg_fold)
+#define CG_GLOB (s.slab_active ? &s.scal->red[6] : (const float *)nullptr)
 static void l_cg_ap(State &s) {
-    if (s.c.all_fluid) { CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2)}; launch_pass(s, p, 2); }
-    else { CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2)}; launch_pass(s, p, 2); }
+    if (s.c.all_fluid) { CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2)}; launch_pass(s, p, 2); }
+    else { CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2)}; launch_pass(s, p, 2); }
 }
 static void l_cg_prepare2(State &s) {
     if (s.c.n == 0) return;
-    hipLaunchKernelGGL(k_cg_prepare2, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_dinv, s.cg_b, s.cg_Ap, s.cg_r, s.cg_p);
+    hipLaunchKernelGGL(k_cg_prepare2, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), CG_AF, s.cg_dinv, s.cg_b, s.cg_Ap, s.cg_r, s.cg_p);
 }
 // the per-particle CG kernels run the workgroups that hold fluid only (same list as the neighbour passes)
 #define CG_LIST (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_list : nullptr, (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_count : nullptr
@@ -141,29 +147,38 @@ static void l_cg_alpha(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
     s.cg_parity = 0;
-    hipLaunchKernelGGL(k_cg_dots, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_r, s.cg_p, s.cg_Ap, CG_PART(0), CG_PART(3), (const int *)nullptr, CG_LIST);
+    hipLaunchKernelGGL(k_cg_dots, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), CG_AF, s.cg_r, s.cg_p, s.cg_Ap, CG_PART(0), CG_PART(3), (const int *)nullptr, CG_LIST);
+}
+// slab sharding: this rank's sums of two partial arrays -> scal->red[6], red[7] (which = 0: |r0|^2 after l_cg_alpha,
+// 1: p . Ap after the A p pass -> red[7] only, 2: |new r|^2 and |old r|^2 after the x / r update)
+static void l_cg_fold(State &s, int which) {
+    const int nb = s.c.n > 0 ? cdiv(s.c.n, 256) : 0;
+    const float *a = which == 0 ? CG_PART(0) : which == 1 ? (const float *)nullptr : CG_PART(1 - s.cg_parity);
+    const float *b = which == 0 ? (const float *)nullptr : which == 1 ? CG_PART(2) : CG_PART(3);
+    hipLaunchKernelGGL(k_cg_fold, dim3(1), dim3(256), 0, s.stream, nb, a, b, &s.scal->red[6], &s.scal->red[7],
+                       which == 0 ? (const int *)nullptr : s.loop_flag, CG_LIST);
 }
 static void l_cg_update_xr(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
-    hipLaunchKernelGGL(k_cg_update_xr2, dim3(nb), dim3(256), 0, s.stream, s.c.n, nb, s.meta.cur(), s.c.all_fluid, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap,
-                       CG_PART(s.cg_parity), CG_PART(2), CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag, CG_LIST);
+    hipLaunchKernelGGL(k_cg_update_xr2, dim3(nb), dim3(256), 0, s.stream, s.c.n, nb, s.meta.cur(), CG_AF, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap,
+                       CG_PART(s.cg_parity), CG_PART(2), CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag, CG_LIST, CG_GLOB);
 }
 static void l_cg_update_p(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
-    hipLaunchKernelGGL(k_cg_update_p2, dim3(nb), dim3(256), 0, s.stream, s.c.n, nb, s.meta.cur(), s.c.all_fluid, s.cg_r, s.cg_p,
-                       CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag ? 1 : 0, (float)s.loop_thr, s.loop_flag, CG_LIST);
+    hipLaunchKernelGGL(k_cg_update_p2, dim3(nb), dim3(256), 0, s.stream, s.c.n, nb, s.meta.cur(), CG_AF, s.cg_r, s.cg_p,
+                       CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag ? 1 : 0, (float)s.loop_thr, s.loop_flag, CG_LIST, CG_GLOB);
     s.cg_parity = 1 - s.cg_parity;
 }
 static void l_cg_prepare_guess(State &s) {
     if (s.c.n == 0) return;
-    hipLaunchKernelGGL(k_cg_prepare_guess, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), s.c.all_fluid, s.cg_x, s.cg_v0);
+    hipLaunchKernelGGL(k_cg_prepare_guess, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), CG_AF, s.cg_x, s.cg_v0);
 }
 
 static void register_solver_launchers(Launch &L) {
     L.cg_prepare = l_cg_prepare; L.cg_ap = l_cg_ap; L.cg_prepare2 = l_cg_prepare2; L.cg_alpha = l_cg_alpha;
-    L.cg_update_xr = l_cg_update_xr; L.cg_update_p = l_cg_update_p; L.cg_prepare_guess = l_cg_prepare_guess;
+    L.cg_update_xr = l_cg_update_xr; L.cg_update_p = l_cg_update_p; L.cg_prepare_guess = l_cg_prepare_guess; L.cg_fold = l_cg_fold;
     L.dfsph_density_alpha = l_dfsph_density_alpha;
     L.dfsph_rho_adv = l_dfsph_rho_adv;
     L.dfsph_correct = l_dfsph_correct;

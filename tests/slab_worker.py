@@ -46,7 +46,7 @@ def main():
     for _ in range(steps):
         solver.step()
         st = solver.stats()
-        hist.append((st["iter_pcisph"], st["err_pcisph"]))
+        hist.append((st["iter_pcisph"], st["err_pcisph"], st["iter_cg"], st["err_cg"]))
     e = container.engine
     g = e.download(L.F_GHOST) == 1
     info = e.comm_get_slab()
