@@ -50,6 +50,58 @@ def late_scene(method, dt):
     })
     return cfg
 
+def rigid_scene(method, dt):
+    """A dynamic rigid body in the fluid's support, for the wrench terms (base_solver.py:240-278 viscosity, :147-186 pressure;
+    DFSPH.py:173-203, :255-283).  The reference builds rigid bodies from meshes (trimesh) and moves them with PyBullet, neither
+    of which exists here, so the generator puts the body's particles in through the reference's own add_particles and
+    rigid_body_* fields (see inject_rigid).  With no RigidBodies in the scene file the reference's PyBulletSolver.step() returns
+    at once (bullet_solver.py:145): the body stays where it is and rigid_body_forces / _torques accumulate over the steps --
+    that running sum is what the fixture records.  Room for the body in particle_max_num comes from a fluid block that never
+    enters (entryTime far in the future) and lends the body its object id."""
+    cfg = dam_break_scene(method=method, end=(0.14, 0.14, 0.14), particleSpacing=0.019, viscosity_b=0.4, dt=dt,
+                          velocity=(0.1, -0.4, 0.05))
+    cfg["FluidBlocks"].append({
+        "objectId": 1, "start": [0.0, 0.0, 0.0], "end": [0.09, 0.09, 0.09], "translation": [0.6, 0.6, 0.6],
+        "scale": [1, 1, 1], "velocity": [0.0, 0.0, 0.0], "density": 1000.0, "color": LATE_COLOR, "entryTime": 1.0e6,
+    })
+    return cfg
+
+
+# body of the rigid scenes: 4 x 4 x 4 particles at the lattice spacing, under the fluid block and inside its support
+RIGID_BODY = {"objectId": 1, "corner": (0.13, 0.035, 0.13), "side": 4, "density": 2200.0}
+
+
+def rigid_points(spec, diameter):
+    k = np.arange(spec["side"], dtype=np.float32) * np.float32(diameter)
+    g = np.stack(np.meshgrid(k, k, k, indexing="ij"), -1).reshape(-1, 3)
+    return (g + np.array(spec["corner"], np.float32)).astype(np.float32)
+
+
+def inject_rigid(container, spec):
+    """What insert_object() does for a dynamic entry of cfg.get_rigid_bodies() (base_container.py:301-340), without the mesh."""
+    obj = spec["objectId"]
+    pts = rigid_points(spec, container.particle_diameter)
+    n = pts.shape[0]
+    zeros3 = np.zeros((n, 3), np.float32)
+    container.object_id_rigid_body.add(obj)
+    container.rigid_body_particle_num[obj] = n
+    container.object_visibility[obj] = 1
+    container.object_materials[obj] = container.material_rigid
+    container.object_collection[obj] = {"particleNum": n}
+    container.add_particles(obj, n, pts, zeros3, spec["density"] * np.ones(n, np.float32), np.zeros(n, np.float32),
+                            np.array([container.material_rigid] * n, dtype=np.int32), np.ones(n, dtype=np.int32),
+                            np.zeros((n, 3), np.int32))
+    container.rigid_body_is_dynamic[obj] = 1
+    container.rigid_body_velocities[obj] = np.zeros(3, np.float32)
+    container.rigid_body_masses[obj] = container.compute_rigid_body_mass(obj)
+    com = pts.astype(np.float64).mean(0).astype(np.float32)   # bullet_solver.py:12: "center of mass = base position"
+    container.rigid_body_original_centers_of_mass[obj] = com
+    container.rigid_body_centers_of_mass[obj] = com
+    container.rigid_body_rotations[obj] = np.eye(3, dtype=np.float32)
+    container.present_object.append(obj)
+    return n, com
+
+
 SCENES = {
     # name: (scene dict, jitter amplitude, seed, checkpoints (steps))
     "wcsph_cube": (dam_break_scene(end=(0.16, 0.16, 0.16)), 0.0, 0, [1, 2, 5, 10]),
@@ -89,6 +141,22 @@ SCENES = {
     # the unclamped densities -- a free-surface block, so that rho < rho0 on most particles
     "wcsph_implicit": (dam_break_scene(end=(0.12, 0.14, 0.12), viscosity=50.0, viscosity_method="implicit",
                                        velocity=(0.2, -0.5, 0.1)), 0.003, 41, [1, 2, 3]),
+    # PCISPH next to boundary particles: rho* uses the CURRENT position of a rigid neighbour and the predicted one of a fluid
+    # neighbour (PCISPH.py:33-63), the pressure acceleration has its own rigid branch (:85-107)
+    "pcisph_box": (dam_break_scene(method="pcisph", domain_end=(0.32, 0.32, 0.32), start=(0.06, 0.06, 0.06),
+                                   end=(0.14, 0.16, 0.14), translation=(0.0, 0.0, 0.0), add_domain_box=True,
+                                   particleSpacing=0.0175, viscosity_b=0.3, velocity=(0.1, -0.4, 0.0)), 0.002, 51, [1, 2, 3]),
+    "pcisph_emitter": (dam_break_scene(method="pcisph", end=(0.1, 0.2, 0.1), translation=(0.1, 0.2, 0.1),
+                                       velocity=(0.0, -2.5, 0.0), gravitationUpper=0.31), 0.0, 0, [1, 6, 12]),
+    "pcisph_implicit": (dam_break_scene(method="pcisph", end=(0.1, 0.12, 0.1), particleSpacing=0.0175, viscosity=50.0,
+                                        viscosity_method="implicit", velocity=(0.2, -0.5, 0.1)), 0.002, 52, [1, 2, 3]),
+    "wcsph_implicit_box": (dam_break_scene(domain_end=(0.32, 0.32, 0.32), start=(0.06, 0.06, 0.06), end=(0.14, 0.14, 0.14),
+                                           translation=(0.0, 0.0, 0.0), add_domain_box=True, viscosity=50.0, viscosity_b=20.0,
+                                           viscosity_method="implicit", velocity=(0.2, -0.5, 0.1)), 0.003, 53, [1, 2]),
+    # dynamic rigid body: force / torque accumulators of every solver (see rigid_scene)
+    "rigid_wcsph": (rigid_scene("wcsph", 4e-4), 0.002, 61, [1, 2, 4]),
+    "rigid_dfsph": (rigid_scene("dfsph", 6e-4), 0.002, 62, [1, 2, 3]),
+    "rigid_pcisph": (rigid_scene("pcisph", 4e-4), 0.002, 63, [1, 2, 3]),
     # late entry (base_container.py:218-221): a second block whose entryTime falls into the 4th step; inserted by
     # _step() itself (WCSPH.py:41, DFSPH.py:307, PCISPH.py:181)
     "wcsph_late": (late_scene("wcsph", 4e-4), 0.0, 0, [2, 4, 6]),
@@ -120,8 +188,11 @@ def snapshot(container, solver, method, log):
                  pcisph_k=np.float32(container.pcisph_k[None]), density_error=np.float32(container.density_error[None]))
     if hasattr(solver, "cg_x"):
         d.update(cg_x=_np(solver.cg_x))
+    wrench = {"rigid_forces": _np(container.rigid_body_forces).copy(), "rigid_torques": _np(container.rigid_body_torques).copy(),
+              "rigid_masses": _np(container.rigid_body_masses).copy()}
     n = container.particle_num[None]
     out = {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] >= n else v) for k, v in d.items()}
+    out.update(wrench)
     # iteration counts printed by the reference's python loops (DFSPH.py:159,:243; PCISPH.py:125; base_solver.py:461)
     text = log.getvalue()
     for key, pat in (("iter_v", r"DFSPH - iteration V: (\d+)"), ("iter_d", r"DFSPH - iterations: (\d+)"),
@@ -150,6 +221,9 @@ def run_scene(name):
         # ---- solver.prepare() (base_solver.py:683-690), spelled out so ids / jitter can be set after insertion
         solver.init_object_id()
         container.insert_object()
+        inject = None
+        if name.startswith("rigid_"):
+            inject = inject_rigid(container, RIGID_BODY)
         n = container.particle_num[None]
         colors = container.particle_colors._data
         colors[:n, 0] = np.arange(n)
@@ -182,6 +256,8 @@ def run_scene(name):
            "geo_dx": np.float64(container.dx), "geo_dh": np.float64(container.dh), "geo_V0": np.float64(container.V0),
            "geo_grid_num": np.array(container.grid_num), "geo_padding": np.float64(container.padding),
            "geo_particle_max_num": np.int64(container.particle_max_num)}
+    if inject:
+        out["inject_count"], out["inject_com"] = np.int64(inject[0]), inject[1]
     for k, v in init.items():
         out["init_" + k] = v
     for k, v in snapshot(container, solver, method, log).items():

@@ -35,6 +35,15 @@ def test_hip_matches_golden(gpu, path, fast_math):
     container.insert_object()
     solver.rigid_solver.insert_rigid_object()
     e = container.engine
+    if "inject_count" in z.files:
+        # the generator's dynamic rigid body (oracle/gen_golden.py inject_rigid): same particles, identity pose about the centroid
+        k = int(z["inject_count"])
+        obj = int(z["init_object_ids"][-1])
+        e.set_object(obj, 2, 1)
+        e.append_particles(obj, z["init_positions"][-k:], z["init_velocities"][-k:], z["init_densities"][-k:], np.zeros(k, np.float32),
+                           z["init_materials"][-k:], z["init_is_dynamic"][-k:], np.zeros((k, 3), np.int32))
+        zero3 = np.zeros(3, np.float32)
+        e.set_rigid_pose(obj, z["inject_com"], np.eye(3, dtype=np.float32), zero3, zero3, com0=z["inject_com"])
     assert e.particle_num == z["init_positions"].shape[0]
     np.testing.assert_array_equal(e.download(L.F_MATERIAL), z["init_materials"])
     e.upload(L.F_POSITION, z["init_positions"])  # jittered scenes: same seeded perturbation as the fixture
@@ -86,7 +95,15 @@ def test_hip_matches_golden(gpu, path, fast_math):
             vs = max(float(np.abs(z[pre + "velocities"]).max()), 1e-30)
             worst["cg_x"] = float(np.abs(cgx.astype(np.float64) - z[pre + "cg_x"].astype(np.float64))[slot_fluid_now(z, pre)].max()) / vs
             assert abs(solver.stats()["iter_cg"] - int(z[pre + "iter_cg"])) <= 2, (solver.stats()["iter_cg"], int(z[pre + "iter_cg"]))
-        lim = {"positions": 1e-5, "velocities": 5e-4, "densities": 2e-5, "rest_volumes": 1e-5, "masses": 1e-5}
+        if "inject_count" in z.files:
+            # running sums of force / torque on the dynamic rigid body (nothing resets them in the fixture run)
+            force, torque = e.get_rigid_wrench(reset=False)
+            for key, mine in (("rigid_forces", force), ("rigid_torques", torque)):
+                ref = z[pre + key].astype(np.float64)
+                assert np.abs(ref).max() > 0
+                worst[key] = float(np.abs(mine[:ref.shape[0]].astype(np.float64) - ref).max() / np.abs(ref).max())
+        lim = {"positions": 1e-5, "velocities": 5e-4, "densities": 2e-5, "rest_volumes": 1e-5, "masses": 1e-5,
+               "rigid_forces": 2e-4, "rigid_torques": 5e-4}
         for k, v in worst.items():
             assert v < lim.get(k, 5e-3), (cp, k, v, worst)
         slot_fluid, slot_fluid_step = z[pre + "materials"] == 1, cp

@@ -60,10 +60,15 @@ def _oracle_from_fixture(z, cfg):
         k = b - a
         color = np.zeros((k, 3), np.int32)
         color[:, 0] = np.arange(a, b)
+        rigid_dyn = int(z["init_materials"][a]) == 2 and int(z["init_is_dynamic"][a]) == 1
         if o >= 0:
-            sim.set_object(o, int(z["init_materials"][a]), 0)
+            sim.set_object(o, int(z["init_materials"][a]), 1 if rigid_dyn else 0)
         sim.add_particles(o, z["init_positions"][a:b], z["init_velocities"][a:b], z["init_densities"][a:b],
                           np.zeros(k, np.float32), z["init_materials"][a:b], z["init_is_dynamic"][a:b], color)
+        if rigid_dyn:   # the generator's injected body (gen_golden.py inject_rigid): identity pose about its centroid
+            f32p = lambda arr: np.ascontiguousarray(arr, np.float32).ctypes.data
+            com, eye, zero3 = z["inject_com"], np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+            sim.lib.sphref_set_rigid_pose(sim.h, o, f32p(com), f32p(eye), f32p(zero3), f32p(zero3), f32p(com))
     return sim, geo
 
 
@@ -80,6 +85,10 @@ def test_host_scene_matches_reference_container(path):
     assert sum(b["pos"].shape[0] for b in batches) == int(z["geo_particle_max_num"])
     batches = [b for b in batches if not b["entry_time"] > 0.0]   # present at prepare()
     pos = np.concatenate([b["pos"] for b in batches])
+    if "inject_count" in z.files:   # a rigid body put in by the generator, not by the scene file: compare the scene's part
+        k = int(z["inject_count"])
+        assert np.all(z["init_materials"][-k:] == 2) and np.all(z["init_is_dynamic"][-k:] == 1)
+        z = {key: (z[key][:-k] if key.startswith("init_") else z[key]) for key in z.files}
     assert pos.shape[0] == z["init_positions"].shape[0]
     if float(z["jitter"]) == 0.0:
         np.testing.assert_array_equal(pos, z["init_positions"])
@@ -118,6 +127,12 @@ def _compare(sim, z, prefix, geo, tol_scale=1.0):
         scale = max(float(np.abs(ref).max()), 1e-30)
         err = float(np.abs(mine.astype(np.float64) - ref.astype(np.float64)).max()) / scale
         worst[key] = err
+    if prefix + "rigid_forces" in z.files and np.abs(z[prefix + "rigid_forces"]).max() > 0:
+        # running sums of the wrench on dynamic rigid bodies (nobody resets them in the fixture runs, see rigid_scene)
+        for key, fname in (("rigid_forces", "rigid_body_forces"), ("rigid_torques", "rigid_body_torques")):
+            ref = z[prefix + key].astype(np.float64)
+            mine = sim.field(fname)[:ref.shape[0]].astype(np.float64)
+            worst[key] = float(np.abs(mine - ref).max() / np.abs(ref).max())
     return worst
 
 
