@@ -153,7 +153,10 @@ int sph_append_particles(SphHandle *h, int object_id, int n, const float *pos, c
 int sph_set_appended_ids(SphHandle *h, int n, const int32_t *ids);
 /* object_materials / rigid_body_is_dynamic (base_container.py:150,156; insert_object :237,:317,:332) */
 int sph_set_object(SphHandle *h, int object_id, int material, int is_dynamic);
-/* pose written by the host rigid solver (SPH/rigid_solver/bullet_solver.py:158-167); rot9 row-major */
+/* pose written by the host rigid solver (SPH/rigid_solver/bullet_solver.py:158-167); rot9 row-major.  Like the reference's
+   rigid_body_* fields it is only READ at the renew_rigid_particle_state point of a step (inside sph_step_end / the second half of
+   sph_step), wherever before that it was written: a pose pushed between two steps moves the particles after the fluid passes of
+   the next step, not before them (base_solver.py:616, WCSPH.py:43). */
 int sph_set_rigid_pose(SphHandle *h, int object_id, const float *com, const float *rot9,
                        const float *vel, const float *angvel, const float *com0);
 /* rigid_body_forces / rigid_body_torques read by bullet_solver.py:150-156; reset != 0 zeroes them */

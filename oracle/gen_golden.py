@@ -77,6 +77,18 @@ def rigid_points(spec, diameter):
     return (g + np.array(spec["corner"], np.float32)).astype(np.float32)
 
 
+def rigid_pose_after_step1(com0):
+    """The pose PyBullet would have written (bullet_solver.py:160-167) -- here a fixed, made-up one, written into the
+    reference's rigid_body_* fields after the first step so that _renew_rigid_particle_state (base_solver.py:616) moves and
+    spins the body's particles in the second."""
+    axis = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+    a = 0.1
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+    return {"com": (com0.astype(np.float64) + np.array([0.004, 0.003, -0.002])).astype(np.float32), "rot": R.astype(np.float32),
+            "vel": np.array([0.3, 0.1, -0.2], np.float32), "angvel": np.array([1.0, -2.0, 0.5], np.float32)}
+
+
 def inject_rigid(container, spec):
     """What insert_object() does for a dynamic entry of cfg.get_rigid_bodies() (base_container.py:301-340), without the mesh."""
     obj = spec["objectId"]
@@ -143,9 +155,9 @@ SCENES = {
                                        velocity=(0.2, -0.5, 0.1)), 0.003, 41, [1, 2, 3]),
     # PCISPH next to boundary particles: rho* uses the CURRENT position of a rigid neighbour and the predicted one of a fluid
     # neighbour (PCISPH.py:33-63), the pressure acceleration has its own rigid branch (:85-107)
-    "pcisph_box": (dam_break_scene(method="pcisph", domain_end=(0.32, 0.32, 0.32), start=(0.06, 0.06, 0.06),
-                                   end=(0.14, 0.16, 0.14), translation=(0.0, 0.0, 0.0), add_domain_box=True,
-                                   particleSpacing=0.0175, viscosity_b=0.3, velocity=(0.1, -0.4, 0.0)), 0.002, 51, [1, 2, 3]),
+    "pcisph_box": (dam_break_scene(method="pcisph", domain_end=(0.32, 0.32, 0.32), start=(0.075, 0.075, 0.075),
+                                   end=(0.17, 0.19, 0.17), translation=(0.0, 0.0, 0.0), add_domain_box=True,
+                                   particleSpacing=0.017, viscosity_b=0.3, velocity=(0.1, -0.4, 0.0)), 0.002, 51, [1, 2, 3]),
     "pcisph_emitter": (dam_break_scene(method="pcisph", end=(0.1, 0.2, 0.1), translation=(0.1, 0.2, 0.1),
                                        velocity=(0.0, -2.5, 0.0), gravitationUpper=0.31), 0.0, 0, [1, 6, 12]),
     "pcisph_implicit": (dam_break_scene(method="pcisph", end=(0.1, 0.12, 0.1), particleSpacing=0.0175, viscosity=50.0,
@@ -268,6 +280,16 @@ def run_scene(name):
             with contextlib.redirect_stdout(log):
                 solver.step()
             step += 1
+            if inject and step == 1:
+                pose = rigid_pose_after_step1(inject[1])
+                obj = RIGID_BODY["objectId"]
+                container.rigid_body_centers_of_mass[obj] = pose["com"]
+                container.rigid_body_rotations[obj] = pose["rot"]
+                container.rigid_body_velocities[obj] = pose["vel"]
+                container.rigid_body_angular_velocities[obj] = pose["angvel"]
+                out["pose_step"] = np.int64(1)
+                for k, v in pose.items():
+                    out["pose_" + k] = v
             # late entrants: still carrying the sentinel colour; their persistent id = insertion index, i.e. the count so
             # far + their rank in lattice order (x slowest, z fastest: base_container.py:769-777), whatever a sort did since
             n_now = container.particle_num[None]

@@ -500,7 +500,9 @@ static void ph_rigid_volume(SphHandle *h) {
 static void step_begin(SphHandle *h) {
     State &s = h->st;
     s.c.stat_bank = (int)(h->steps & 1);   // cleared by the previous step's scan kernel (k_scan_lookback)
-    if (h->pose_dirty) { ProfScope p(h, SPH_K_MISC); h->L->renew_rigid(s); h->pose_dirty = false; }
+    // a pose pushed between two steps is NOT applied here: the reference reads the rigid_body_* fields in the middle of
+    // _step() (renew_rigid_particle_state, WCSPH.py:43 / DFSPH.py:309 / PCISPH.py:183), after the fluid passes of the step --
+    // step_second_half does that (pinned by the rigid_* fixtures, which write a pose between steps 1 and 2)
 }
 
 #include "sph_comm_api.hpp"

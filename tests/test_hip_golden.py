@@ -56,6 +56,9 @@ def test_hip_matches_golden(gpu, path, fast_math):
         while step < cp:
             solver.step()
             step += 1
+            if "pose_step" in z.files and step == int(z["pose_step"]):   # the pose a rigid solver would have written
+                e.set_rigid_pose(int(z["init_object_ids"][-1]), z["pose_com"], z["pose_rot"], z["pose_vel"], z["pose_angvel"],
+                                 com0=z["inject_com"])
         pre = f"s{cp}_"
         ids = e.download(L.F_PARTICLE_ID)
         fluid = H.by_id(z[pre + "ids"], z[pre + "materials"]) == 1

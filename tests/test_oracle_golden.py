@@ -66,9 +66,8 @@ def _oracle_from_fixture(z, cfg):
         sim.add_particles(o, z["init_positions"][a:b], z["init_velocities"][a:b], z["init_densities"][a:b],
                           np.zeros(k, np.float32), z["init_materials"][a:b], z["init_is_dynamic"][a:b], color)
         if rigid_dyn:   # the generator's injected body (gen_golden.py inject_rigid): identity pose about its centroid
-            f32p = lambda arr: np.ascontiguousarray(arr, np.float32).ctypes.data
-            com, eye, zero3 = z["inject_com"], np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
-            sim.lib.sphref_set_rigid_pose(sim.h, o, f32p(com), f32p(eye), f32p(zero3), f32p(zero3), f32p(com))
+            a = [np.ascontiguousarray(v, np.float32) for v in (z["inject_com"], np.eye(3), np.zeros(3), np.zeros(3))]
+            sim.lib.sphref_set_rigid_pose(sim.h, o, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, a[0].ctypes.data)
     return sim, geo
 
 
@@ -153,6 +152,10 @@ def test_oracle_matches_reference_source(path):
         while step < cp:
             H.oracle_step(sim, 1)
             step += 1
+            if "pose_step" in z.files and step == int(z["pose_step"]):   # the pose a rigid solver would have written
+                # (arrays kept alive in `a` while their addresses are in use: z[...] makes a fresh array per access)
+                a = [np.ascontiguousarray(z[k], np.float32) for k in ("pose_com", "pose_rot", "pose_vel", "pose_angvel", "inject_com")]
+                sim.lib.sphref_set_rigid_pose(sim.h, int(z["init_object_ids"][-1]), *[v.ctypes.data for v in a])
         pre = f"s{cp}_"
         assert sim.particle_num == z[pre + "ids"].shape[0], (cp, sim.particle_num, z[pre + "ids"].shape[0])
         np.testing.assert_array_equal(np.sort(H.oracle_ids(sim)), np.sort(z[pre + "ids"]))
