@@ -811,30 +811,46 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         const int e1 = e0 + (z1 - z0) + 1;
         unsigned npairs = 0;
 #pragma unroll 1
-        for (int g = 0; g < (c.force_global == 11 ? 0 : GROUPS); ++g) {
-            // tile plan of the group (uniform): the runs that fit are laid out back to back
+        for (int g = 0, qa = 0; g < (c.force_global == 11 ? 0 : GROUPS); ) {
+            // One group = the three runs of an x offset.  Its runs are staged in ROUNDS (uniform plan): a round takes the longest
+            // prefix of the runs not yet done that fits the tile, laid out back to back -- normally all three in one round; where
+            // the fluid has piled up, two rounds (e.g. {0, 1} then {2}) instead of sending the group down the slow ordered walk.
+            // A run that does not fit the tile on its own is a round of its own and is walked out of L2.  Runs are consumed in
+            // order, so the accumulation order stays the reference's.
             int rs_[RPG], ln_[RPG], lo_[RPG];
-            int total = 0;
+            int total = 0, qb = RPG;
+            unsigned rm = 7u;            // runs of this round (bit q)
             bool overflow = false;
 #pragma unroll
             for (int q = 0; q < RPG; ++q) {
                 rs_[q] = hdr[2 + g * RPG + q];
-                ln_[q] = hdr[11 + g * RPG + q];
-                if (c.force_global != 1 && total + ln_[q] <= CAP) { lo_[q] = total - rs_[q]; total += ln_[q]; }
-                else { lo_[q] = INT_MIN; overflow = true; ln_[q] = ln_[q] > 0 ? ln_[q] : 0; }
+                ln_[q] = hdr[11 + g * RPG + q] > 0 ? hdr[11 + g * RPG + q] : 0;
             }
+            if (qa == 0 && ln_[0] + ln_[1] + ln_[2] <= CAP && c.force_global != 1) {   // the usual case: the whole group fits
+                lo_[0] = -rs_[0]; lo_[1] = ln_[0] - rs_[1]; lo_[2] = ln_[0] + ln_[1] - rs_[2];
+                total = ln_[0] + ln_[1] + ln_[2];
+            } else {   // the round is the longest prefix [qa, qb) of the runs not yet done that fits
+                rm = 0u; qb = qa;
+#pragma unroll
+                for (int q = 0; q < RPG; ++q) {
+                    lo_[q] = INT_MIN;
+                    if (q >= qa && q == qb && !overflow) {
+                        if (c.force_global != 1 && total + ln_[q] <= CAP) { lo_[q] = total - rs_[q]; total += ln_[q]; qb = q + 1; rm |= 1u << q; }
+                        else if (q == qa) { overflow = true; qb = q + 1; rm |= 1u << q; }
+                    }
+                }
+            }
+#define NBR_IN_ROUND(q) ((rm >> (q)) & 1u)
             if (tid < RPG) {
                 s_loff[g * RPG + tid] = tid == 0 ? lo_[0] : (tid == 1 ? lo_[1] : lo_[2]);
-                const int l = tid == 0 ? ln_[0] : (tid == 1 ? ln_[1] : ln_[2]);
-                const int o = tid == 0 ? lo_[0] : (tid == 1 ? lo_[1] : lo_[2]);
-                if (o == INT_MIN && l > 0) atomicAdd(&scal->fallback[c.stat_bank][b & (SPH_STAT_SLOTS - 1)], 1ull);
+                if (overflow && tid == qa && (tid == 0 ? ln_[0] : (tid == 1 ? ln_[1] : ln_[2])) > 0) atomicAdd(&scal->fallback[c.stat_bank][b & (SPH_STAT_SLOTS - 1)], 1ull);
             }
             // first mask word of this group's runs ([run][particle] layout): issued first, nothing below depends on them
             // until the staging barrier has passed
             unsigned mk[RPG] = {0u, 0u, 0u}, mh[RPG] = {0u, 0u, 0u};
             if (MASKMODE == 2 && active && c.force_global != 12) {
 #pragma unroll
-                for (int q = 0; q < RPG; ++q) mk[q] = nbr_mask[(size_t)(g * RPG + q) * mask_stride + i];
+                for (int q = 0; q < RPG; ++q) if (NBR_IN_ROUND(q)) mk[q] = nbr_mask[(size_t)(g * RPG + q) * mask_stride + i];
             }
             // candidate sub-ranges of this lane's particle in the three runs (from the cached cell_start windows)
             bool inr[RPG];
@@ -844,7 +860,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             for (int q = 0; q < RPG; ++q) {
                 const int k = g * RPG + q;
                 const int xx = cx + g - 1, yy = cy + q - 1;
-                inr[q] = active && xx >= 0 && xx < c.nx && yy >= 0 && yy < c.ny;
+                inr[q] = NBR_IN_ROUND(q) && active && xx >= 0 && xx < c.nx && yy >= 0 && yy < c.ny;
                 js_[q] = 0; m_[q] = 0;
                 if (inr[q]) {
                     if (cs_lds) {
@@ -962,8 +978,10 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                 }
             }
             NBR_STAMP(4 + g * 4);
-            __syncthreads();  // LDS is restaged by the next group
+            __syncthreads();  // LDS is restaged by the next round / group
             NBR_STAMP(5 + g * 4);
+            qa = qb;
+            if (qa >= RPG) { qa = 0; ++g; }
         }
         if (P::COUNT_PAIRS) {
             float fp = wave_sum((float)npairs);  // <= 64 * few hundred: exact in f32
