@@ -84,8 +84,24 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SPH_BENCH_RDV=rdv)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
+    # a rank that dies (capacity error, HIP error) leaves its neighbours blocked in a receive: stop them (these exact
+    # children, by pid) as soon as any rank exits non-zero, instead of waiting for ever
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        if any(rc not in (None, 0) for rc in rcs):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
     rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out = b"".join(c for c in chunks if c)
     try:
         os.unlink(rdv)
     except OSError:
@@ -269,6 +285,8 @@ def run_rank(args, rank, world, local_rank):
     if os.environ.get("SPH_BENCH_SELFTEST") and (slab_opt or comm_opt):
         eng.comm_selftest(1 << 16)
     solver.prepare()
+    if os.environ.get("SPH_BENCH_FAIL_RANK") == str(rank):   # test hook: this rank dies while the others wait for its halo
+        raise SystemExit(3)
     n_fluid = container.fluid_particle_num[None]
     names = [lib.sph_kernel_name(k).decode() for k in range(N_KERNEL_IDS)]
     multi = world > 1

@@ -6,6 +6,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -246,6 +247,20 @@ def test_bench_spawns_two_ranks_without_torch(gpu):
     assert out["config"]["pair_interactions_per_step"] == one["config"]["pair_interactions_per_step"]
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "import torch" not in src and "torch.distributed" not in src.replace("torch.distributed.run", "")
+
+
+def test_bench_stops_all_ranks_when_one_dies(gpu):
+    """A rank that dies leaves its neighbour blocked in a halo receive; the launcher stops the survivors (its own children, by
+    pid) and exits non-zero instead of hanging."""
+    env = dict(os.environ, SPH_COMM_TRANSPORT="shm", SPH_BENCH_FAIL_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c1", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--motion-step", "0"], env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert r.returncode != 0 and "rank exit codes" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], "no result line from a run that lost a rank"
+    assert time.time() - t0 < 200
 
 
 def test_bench_rejects_world_size_mismatch(gpu):
