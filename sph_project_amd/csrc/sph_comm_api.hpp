@@ -444,6 +444,10 @@ extern "C" int sph_comm_set_rebalance(SphHandle *h, int every_steps) {
 static int slab_neighbor_search(SphHandle *h) {
     State &s = h->st;
     SlabComm &c = h->comm;
+    // (SURVEY 8e "rigid coupling under sharding": out of scope for C1-C5) a moving body's particles would have to take their
+    // rest positions along when they change owner and the wrench would have to be summed over the ranks: not built -- say so
+    if (s.has_dynamic_rigid && c.nranks > 1)
+        return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding: dynamic rigid bodies are not supported (static bodies and the domain box are)");
     if (c.rebalance_every > 0 && h->prepared && h->steps > 0 && h->steps % c.rebalance_every == 0 && !h->any_rigid_object) {
         int rc = slab_rebalance(h); if (rc) return rc;
     }
