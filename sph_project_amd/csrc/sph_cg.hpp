@@ -101,10 +101,13 @@ struct CgApPass {
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
     static constexpr bool HAS_REDUCE = true;   // per-workgroup partial of p . Ap (the denominator of alpha, :394): no separate dot kernel
     static constexpr int PAIR_WEIGHT = 1;
+    static constexpr bool SPLIT3 = true;       // see PassSplit / k_cg_ap_combine
     typedef float4 BT;
     struct Own { float m; float d[9]; float x, y, z; };
     const float4 *posv, *velm; const int *meta; const float *rho; const float4 *cg_p; const float *dinv;
     float4 *cg_Ap; float *red_out;
+    float4 *part; int part_stride;             // [3][part_stride] partial sums of a split launch
+    __device__ void partial(const Consts &, int i, int g, const Own &o) const { part[(size_t)g * part_stride + i] = make_float4(o.x, o.y, o.z, 0.f); }
 
     __device__ float4 stage_impl(int j, BT &bj) const {
         const float4 p = posv[j], q = cg_p[j];
@@ -230,6 +233,30 @@ __device__ __forceinline__ float cg_total(const float *part, int nb, const int *
     if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = a;
     __syncthreads();
     return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+
+// second half of a split A p pass (CgApPass::SPLIT3): adds the three per-group parts, then CgApPass::finish + its partial of p . Ap
+__global__ void __launch_bounds__(256)
+k_cg_ap_combine(const Consts c, const int *meta, int all_fluid, const float4 *part, int stride, const float4 *p, float4 *Ap,
+                float *part_den, const int *stop_flag, const int *blk_list, const int *blk_count) {
+    if (stop_flag && *stop_flag) return;
+    const int blk = cg_block(blk_list, blk_count);
+    if (blk < 0) return;
+    const int i = blk * 256 + threadIdx.x;
+    float dot = 0.f;
+    if (i < c.n && is_fluid(meta, i, all_fluid)) {
+        const float4 a0 = part[i], a1 = part[(size_t)stride + i], a2 = part[2 * (size_t)stride + i], pp = p[i];
+        float x = ((a0.x + a1.x) + a2.x) * c.dt, y = ((a0.y + a1.y) + a2.y) * c.dt, z = ((a0.z + a1.z) + a2.z) * c.dt;
+        x = fdiv(x, c.rho0); y = fdiv(y, c.rho0); z = fdiv(z, c.rho0);
+        const float4 a = make_float4(x + pp.x, y + pp.y, z + pp.z, 0.f);
+        Ap[i] = a;
+        dot = pp.x * a.x + pp.y * a.y + pp.z * a.z;
+    }
+    __shared__ float s_d[4];
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) s_d[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) part_den[blk] = (s_d[0] + s_d[1]) + (s_d[2] + s_d[3]);
 }
 
 // Slab sharding: the dot products are sums over all ranks.  One workgroup adds up this rank's partials into out[0..1]; the

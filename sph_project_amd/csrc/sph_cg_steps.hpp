@@ -7,6 +7,11 @@ static int implicit_viscosity_non_pressure(SphHandle *h) {
     const int fixed = h->prm.fixed_iterations;
     const bool slab = s.slab_active != 0;
     int comm_rc = SPH_OK;
+    // few fluid particles (the buckling sheet of C5: 106 k of 2.2 M particles = 416 tiles, one wave per SIMD): every A p pass is
+    // pure latency; splitting it by x-offset group triples the waves in flight (PassSplit).  A scene that fills the chip
+    // anyway (> ~1500 tiles) gains nothing from it and keeps the single launch.
+    static const char *no_split = getenv("SPH_NO_CG_SPLIT");
+    s.cg_split = (!no_split && h->n_fluid > 0 && h->n_fluid <= 400000) ? 1 : 0;
     // Slab sharding: the ghosts are the neighbour ranks' rows of the system.  Their search direction goes out before every
     // A p pass (12 B per ghost through the slot tables), the three dot products of an iteration are summed over the ranks
     // (k_cg_fold + one 1-float and one 2-float all-reduce), and the solved velocities of the ghosts after the loop.

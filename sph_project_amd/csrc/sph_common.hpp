@@ -105,6 +105,9 @@ struct State {
     // CG (implicit viscosity)
     float4 *cg_p, *cg_Ap, *cg_x, *cg_b, *cg_r, *cg_v0;
     float *cg_dinv;      // 9 floats per particle
+    float4 *cg_part;     // 3 x cap: per-group parts of A p when the pass is split (CgApPass::SPLIT3)
+    int cg_split;        // this solve splits its A p passes (few fluid particles: see implicit_viscosity_non_pressure)
+    int split_next_pass; // launch_pass: launch the next SPLIT3 functor with gridDim.y = 3
     int cg_parity;       // which of the two |r|^2 partial arrays the next x / r update reads
     // reductions
     float *red_partial;  // per-block partial sums

@@ -401,6 +401,13 @@ template <class P> struct PassFluidOnly<P, decltype((void)P::FLUID_BLOCKS_ONLY)>
 // The passes that run first after a sort (density, DFSPH density + alpha) declare 0 | 1, the rigid volume pass 0 only.
 // Instantiating only what can run keeps dead, register-hungry variants (the unrolled phase 1 inside a force pass) out
 // of the code object; a mask-reusing pass also takes the lean one-candidate-at-a-time phase 1 in its mode-0 fallback.
+// P::SPLIT3: the functor's sum is linear in its pairs and it has partial(): launched with gridDim.y == 3, workgroup (b, g)
+// walks only x-offset group g of tile b and stores its part of the sum; a small kernel of the functor's owner adds the three
+// parts and does what finish() does.  For passes over FEW particles (a 100 k-particle sheet is 416 tiles: less than half of
+// what the chip holds at once, one wave per SIMD, every pass pure latency) this triples the waves in flight.
+template <class P, class = void> struct PassSplit { static constexpr bool value = false; };
+template <class P> struct PassSplit<P, decltype((void)P::SPLIT3)> { static constexpr bool value = P::SPLIT3; };
+
 template <class P, class = void> struct PassModes { static constexpr int value = 0b101; };
 template <class P> struct PassModes<P, decltype((void)P::MODES)> { static constexpr int value = P::MODES; };
 template <class P> constexpr bool pass_builds_masks() { return (PassModes<P>::value & 0b010) != 0; }
@@ -810,8 +817,9 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         const int e0 = (lin - cfirst) + (z0 - cz) + 1;   // s_cs entry of (.., .., z0) in every run
         const int e1 = e0 + (z1 - z0) + 1;
         unsigned npairs = 0;
+        const int gsplit = (PassSplit<P>::value && gridDim.y == GROUPS) ? (int)blockIdx.y : -1;   // uniform: one group only
 #pragma unroll 1
-        for (int g = 0, qa = 0; g < (c.force_global == 11 ? 0 : GROUPS); ) {
+        for (int g = gsplit >= 0 ? gsplit : 0, qa = 0; g < (c.force_global == 11 ? 0 : (gsplit >= 0 ? gsplit + 1 : GROUPS)); ) {
             // One group = the three runs of an x offset.  Its runs are staged in ROUNDS (uniform plan): a round takes the longest
             // prefix of the runs not yet done that fits the tile, laid out back to back -- normally all three in one round; where
             // the fluid has piled up, two rounds (e.g. {0, 1} then {2}) instead of sending the group down the slow ordered walk.
@@ -994,11 +1002,17 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     }
     NBR_STAMP(14);
     float red = 0.0f;
-    if (valid) {
+    bool split_launch = false;
+    if constexpr (PassSplit<P>::value) {
+        split_launch = gridDim.y == GROUPS;
+        if (split_launch && valid && active) p.partial(c, i, (int)blockIdx.y, own);
+    }
+    if (valid && !split_launch) {
         if (active) red = p.finish(c, i, pi, own);
         else p.passive(c, i, pi);
     }
     NBR_STAMP(15);
+    if (split_launch) return;   // uniform; the combining kernel reduces
     if constexpr (P::HAS_REDUCE) {
         // deterministic per-workgroup partial sum: particle order and a fixed tree (whatever the lane permutation),
         // finished by k_reduce_partials

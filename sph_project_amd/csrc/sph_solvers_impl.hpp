@@ -131,16 +131,21 @@ static void l_cg_prepare(State &s) {
 #define CG_AF (s.c.all_fluid && !s.c.ghosts)   /* "every particle is a row of the system" */
 // slab sharding: all-reduced dot products live in scal->red[6..7] (see k_cg_fold)
 #define CG_GLOB (s.slab_active ? &s.scal->red[6] : (const float *)nullptr)
+// the per-particle CG kernels run the workgroups that hold fluid only (same list as the neighbour passes)
+#define CG_LIST (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_list : nullptr, (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_count : nullptr
 static void l_cg_ap(State &s) {
-    if (s.c.all_fluid) { CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2)}; launch_pass(s, p, 2); }
-    else { CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2)}; launch_pass(s, p, 2); }
+    const bool split = s.cg_split && s.cg_part && s.c.n > 0;
+    s.split_next_pass = split ? 1 : 0;
+    if (s.c.all_fluid) { CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2), s.cg_part, s.cap}; launch_pass(s, p, 2); }
+    else { CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2), s.cg_part, s.cap}; launch_pass(s, p, 2); }
+    if (split)   // the three parts -> A p and the partials of p . A p (what finish() and the pass's reduction do otherwise)
+        hipLaunchKernelGGL(k_cg_ap_combine, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.meta.cur(), CG_AF, s.cg_part, s.cap, s.cg_p,
+                           s.cg_Ap, CG_PART(2), s.loop_flag, CG_LIST);
 }
 static void l_cg_prepare2(State &s) {
     if (s.c.n == 0) return;
     hipLaunchKernelGGL(k_cg_prepare2, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), CG_AF, s.cg_dinv, s.cg_b, s.cg_Ap, s.cg_r, s.cg_p);
 }
-// the per-particle CG kernels run the workgroups that hold fluid only (same list as the neighbour passes)
-#define CG_LIST (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_list : nullptr, (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_count : nullptr
 // |r0|^2 partials of a fresh solve (the numerator of the first alpha); later iterations reuse the |new r|^2 partials of
 // the previous x / r update, which are the same numbers
 static void l_cg_alpha(State &s) {
