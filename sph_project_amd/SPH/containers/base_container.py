@@ -16,10 +16,10 @@ import os
 
 import numpy as np
 
-from .. import _engine_fields as F
+from sph_project_amd import _lib as F
 from ..utils import SimConfig
 
-scene = F.scene
+from sph_project_amd import scene  # noqa: E402
 
 
 class _Scalar:
@@ -130,7 +130,7 @@ class BaseContainer:
         self.solver_constants = sol
         pd = scene.params_dict(geo, sol, self.METHOD, self.particle_max_num,
                                fixed_iterations=engine_opts.get("fixed_iterations", 0))
-        p = F.lib.SphParams()
+        p = F.SphParams()
         p.domain_size[:] = pd["domain_size"]; p.particle_radius = pd["particle_radius"]
         p.support_radius = pd["support_radius"]; p.V0 = pd["V0"]; p.padding = pd["padding"]
         p.grid_num[:] = pd["grid_num"]; p.gravity[:] = pd["gravity"]; p.g_upper = pd["g_upper"]
@@ -143,7 +143,7 @@ class BaseContainer:
         p.force_global = int(engine_opts.get("force_global", os.environ.get("SPH_DEBUG_MODE", 0)))  # debug: 1 global path, 4 ordered path
         p.deterministic = int(engine_opts.get("deterministic", 1))
         self.params_dict = pd
-        self.engine = F.lib.Engine(p)
+        self.engine = F.Engine(p)
         # multi-GPU: engine_opts["slab"] = dict(rank=, nranks=, unique_id=<128 bytes>, cuts=[...]) -> this container
         # only inserts the particles of its own z-slab (sph_project_amd/slab.py)
         self.slab = engine_opts.get("slab")

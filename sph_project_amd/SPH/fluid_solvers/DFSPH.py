@@ -1,4 +1,4 @@
-from .. import _engine_fields as F
+from sph_project_amd import _lib as F
 from ..containers import DFSPHContainer
 from .base_solver import BaseSolver
 

@@ -5,7 +5,7 @@ libsph_hip; this class keeps the constants, the prepare()/step() protocol (:683-
 insertion and the host rigid-solver hook."""
 import numpy as np
 
-from .. import _engine_fields as F
+from sph_project_amd import _lib as F
 from ..containers import BaseContainer
 from ..rigid_solver import PyBulletSolver
 
