@@ -81,6 +81,7 @@ __device__ __forceinline__ Geom geom(const Consts &c, float r2) {
 }
 
 // base_solver.py:57 kernel_W.  pow(1-q, 3.0) is evaluated as t*t*t (<= 2 ulp from powf).
+template <bool ACCEPTED = true>
 __device__ __forceinline__ float kernW(const Consts &c, const Geom &g) {
     float res = 0.0f;
     const float q = g.q;
@@ -90,7 +91,9 @@ __device__ __forceinline__ float kernW(const Consts &c, const Geom &g) {
     const float lo = 1.0f - 6.0f * (q * q) * t;   // = 6q^3 - 6q^2 + 1
     const float hi = 2.0f * (t * t * t);
     res = c.kW * (q <= 0.5f ? lo : hi);
-    return q <= 1.0f ? res : 0.0f;
+    // ACCEPTED: g belongs to a pair that passed r2 < h2, so q exceeds 1 by rounding at most, where hi = 2 (1 - q)^3 is ~1e-21:
+    // no test.  (PCISPH's rho* evaluates W at PREDICTED distances, which can exceed h: it keeps the test.)
+    return (ACCEPTED || q <= 1.0f) ? res : 0.0f;
 #endif
     if (q <= 1.0f) {
         if (q <= 0.5f) {
@@ -114,7 +117,7 @@ __device__ __forceinline__ void kernGrad(const Consts &c, float dx, float dy, fl
     {
         const float f = 1.0f - q;
         float s = c.kG * (q <= 0.5f ? q * (3.0f * q - 2.0f) : -f * f);
-        s = (g.rn > 1e-5f && q <= 1.0f) ? s * g.inv_rnh : 0.0f;
+        s = g.rn > 1e-5f ? s * g.inv_rnh : 0.0f;   // (no q <= 1 test, see kernW)
         gx = s * dx; gy = s * dy; gz = s * dz;
         return;
     }

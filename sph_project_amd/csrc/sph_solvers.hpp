@@ -215,7 +215,7 @@ struct PcisphRhoStarPass {
     }
     __device__ void pair(const Consts &c, Own &o, float, float, float, float, const float4 &a, const BT &bj, int) const {
         const float dx = o.px - bj.x, dy = o.py - bj.y, dz = o.pz - bj.z;
-        o.sum += a.w * kernW(c, geom(c, dx * dx + dy * dy + dz * dz));
+        o.sum += a.w * kernW<false>(c, geom(c, dx * dx + dy * dy + dz * dz));   // predicted distance: may exceed h
     }
     __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {
         const float star = o.sum * c.rho0;
