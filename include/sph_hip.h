@@ -159,7 +159,8 @@ int sph_set_object(SphHandle *h, int object_id, int material, int is_dynamic);
    the next step, not before them (base_solver.py:616, WCSPH.py:43). */
 int sph_set_rigid_pose(SphHandle *h, int object_id, const float *com, const float *rot9,
                        const float *vel, const float *angvel, const float *com0);
-/* rigid_body_forces / rigid_body_torques read by bullet_solver.py:150-156; reset != 0 zeroes them */
+/* rigid_body_forces / rigid_body_torques read by bullet_solver.py:150-156; reset != 0 zeroes them.  On a sharded scene
+   (sph_comm_set_slab) this is a collective: every rank calls it at the same point of the step and gets the sum over the ranks. */
 int sph_get_rigid_wrench(SphHandle *h, float *force, float *torque, int reset);
 
 /* --- time stepping --------------------------------------------------------------------- */

@@ -246,9 +246,17 @@ class BaseContainer:
             self.object_materials[obj_id] = self.material_rigid
             self.object_collection[obj_id] = body
             self.engine.set_object(obj_id, self.material_rigid, is_dynamic)
+            where = None
+            if is_dynamic and self.slab:
+                # a dynamic body's particles are inserted in BODY coordinates (the rigid solver's first pose places them, :616);
+                # which slab they belong to is decided by where that pose puts them
+                from ..rigid_solver.host_rigid_solver import _rotation
+                rot = _rotation(body["rotationAngle"] / 360 * (2 * np.pi), body["rotationAxis"])
+                where = (np.asarray(body["translation"], np.float64) + pts.astype(np.float64) @ rot.T).astype(np.float32)
             self.add_particles(obj_id, n, pts, np.tile(velocity, (n, 1)), body["density"] * np.ones(n, np.float32),
                                np.zeros(n, np.float32), np.full(n, self.material_rigid, np.int32),
-                               is_dynamic * np.ones(n, np.int32), np.tile(np.asarray(body["color"], np.int32), (n, 1)))
+                               is_dynamic * np.ones(n, np.int32), np.tile(np.asarray(body["color"], np.int32), (n, 1)),
+                               slab_positions=where)
             self.rigid_body_is_dynamic[obj_id] = is_dynamic
             self.rigid_body_velocities[obj_id] = velocity
             if is_dynamic:  # base_container.py:385 compute_rigid_body_mass
@@ -260,15 +268,17 @@ class BaseContainer:
 
     def add_particles(self, object_id, new_particles_num, new_particles_positions, new_particles_velocity,
                       new_particle_density, new_particle_pressure, new_particles_material,
-                      new_particles_is_dynamic, new_particles_color):
-        """base_container.py:417 / :441 -- append at particle_num."""
+                      new_particles_is_dynamic, new_particles_color, slab_positions=None):
+        """base_container.py:417 / :441 -- append at particle_num.  slab_positions (sharded scenes only): where the particles
+        will be once the rigid solver has placed them, if that is not where they are inserted."""
         assert new_particles_positions.shape[0] == new_particles_num
         ids = np.arange(self._next_global_id, self._next_global_id + new_particles_num, dtype=np.int32)
         self._next_global_id += new_particles_num
         if self.slab:  # keep only this rank's z-slab
             self.engine.comm_add_global_count(new_particles_num, int((np.asarray(new_particles_material) == self.material_fluid).sum()))   # (counts only after prepare(): late entry)
             info = self.engine.comm_get_slab(counts=False)   # the current bounds: the cuts follow the fluid (rebalancing)
-            cz = self._slab_mod.cell_layer(np.asarray(new_particles_positions)[:, 2], self.dh, int(self.grid_num[2]))
+            zpos = np.asarray(new_particles_positions if slab_positions is None else slab_positions)[:, 2]
+            cz = self._slab_mod.cell_layer(zpos, self.dh, int(self.grid_num[2]))
             m = (cz >= info["z_lo"]) & (cz < info["z_hi"])
             ids = ids[m]
             sel = lambda a: np.asarray(a)[m]

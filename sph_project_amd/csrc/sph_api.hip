@@ -292,6 +292,19 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
 }
 
 // ---------------------------------------------------------------------------------- scene upload
+// rigid_particle_original_positions (base_container.py:155): allocated with the first dynamic rigid body
+static int ensure_orig(SphHandle *h) {
+    State &s = h->st;
+    if (!s.orig.b[0]) {
+        int rc = dalloc(h, &s.orig.b[0], (size_t)s.cap); if (rc) return rc;
+        rc = dalloc(h, &s.orig.b[1], (size_t)s.cap); if (rc) return rc;
+        // existing particles: original position = current position
+        HIPCHK(h, hipMemcpyAsync(s.orig.cur(), s.posv.cur(), sizeof(float4) * (size_t)h->n, hipMemcpyDeviceToDevice, s.stream));
+    }
+    s.has_dynamic_rigid = 1;
+    return SPH_OK;
+}
+
 extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const float *pos, const float *vel,
                                     const float *density, const float *pressure, const int32_t *material,
                                     const int32_t *is_dynamic, const int32_t *color) {
@@ -324,13 +337,7 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
         if (material[k] == SPH_MAT_FLUID) nfl++;
         if (material[k] == SPH_MAT_RIGID && is_dynamic[k]) any_dyn_rigid = true;
     }
-    if (any_dyn_rigid && !s.orig.b[0]) {
-        int rc = dalloc(h, &s.orig.b[0], (size_t)s.cap); if (rc) return rc;
-        rc = dalloc(h, &s.orig.b[1], (size_t)s.cap); if (rc) return rc;
-        // existing particles: original position = current position
-        HIPCHK(h, hipMemcpyAsync(s.orig.cur(), s.posv.cur(), sizeof(float4) * (size_t)h->n, hipMemcpyDeviceToDevice, s.stream));
-        s.has_dynamic_rigid = 1;
-    }
+    if (any_dyn_rigid) { int rc = ensure_orig(h); if (rc) return rc; }
     HIPCHK(h, hipStreamSynchronize(s.stream));
     const size_t off = (size_t)h->n;
     HIPCHK(h, hipMemcpy(s.posv.cur() + off, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
@@ -375,6 +382,9 @@ extern "C" int sph_set_object(SphHandle *h, int object_id, int material, int is_
     h->pose_h.material[object_id] = material;
     if (material != 1) h->any_rigid_object = true;
     h->pose_h.is_dynamic[object_id] = is_dynamic ? 1 : 0;
+    // a rank of a sharded scene may hold none of the body's particles now and receive them later as migrants (which carry
+    // their rest positions): every rank that is told about the body keeps the array
+    if (material == SPH_MAT_RIGID && is_dynamic) { int rc = ensure_orig(h); if (rc) return rc; }
     return upload_pose(h);
 }
 
@@ -395,6 +405,18 @@ extern "C" int sph_get_rigid_wrench(SphHandle *h, float *force, float *torque, i
     HIPCHK(h, hipStreamSynchronize(h->st.stream));
     memcpy(force, h->scal_h->wrench, sizeof(float) * SPH_NOBJ * 3);
     memcpy(torque, h->scal_h->wrench + SPH_NOBJ * 3, sizeof(float) * SPH_NOBJ * 3);
+    if (h->st.slab_active && h->comm.nranks > 1) {
+        // sharded scene: every rank holds the contributions of ITS fluid particles (SURVEY 8e "rigid coupling under sharding");
+        // the body's wrench is their sum.  Collective: every rank calls this at the same point of the step (the host
+        // rigid solver does, between sph_step_begin and sph_step_end).
+        double w[2 * SPH_NOBJ * 3];
+        for (int k = 0; k < SPH_NOBJ * 3; ++k) { w[k] = force[k]; w[SPH_NOBJ * 3 + k] = torque[k]; }
+        for (int k0 = 0; k0 < 2 * SPH_NOBJ * 3; k0 += 16) {
+            const int cnt = 2 * SPH_NOBJ * 3 - k0 < 16 ? 2 * SPH_NOBJ * 3 - k0 : 16;
+            int rc = sph_comm_allreduce(h, w + k0, cnt, 0); if (rc) return rc;
+        }
+        for (int k = 0; k < SPH_NOBJ * 3; ++k) { force[k] = (float)w[k]; torque[k] = (float)w[SPH_NOBJ * 3 + k]; }
+    }
     if (reset)
         HIPCHK(h, hipMemsetAsync((char *)h->st.scal + offsetof(DevScalars, wrench), 0, sizeof(float) * 2 * SPH_NOBJ * 3, h->st.stream));
     return SPH_OK;

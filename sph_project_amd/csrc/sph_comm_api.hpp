@@ -102,8 +102,9 @@ extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id1
     c.rank = rank; c.nranks = nranks;
     memcpy(c.id, id128, 128);
     // Message capacity = particle capacity: a face message can never hold more records than this rank has particles, so
-    // no pile-up in the boundary layers can overflow it (192 + 32 bytes per particle of capacity for the four message
-    // buffers and the eight slot tables: ~2 GB at 10 M particles, nothing next to 288 GB of HBM).
+    // no pile-up in the boundary layers can overflow it (256 + 32 bytes per particle of capacity for the four message
+    // buffers -- sized for the 64-byte records of scenes with a dynamic rigid body -- and the eight slot tables: ~3 GB at
+    // 10 M particles, nothing next to 288 GB of HBM).
     size_t cap = (size_t)s.cap < 1024 ? 1024 : (size_t)s.cap;
     s.halo_cap = (int)cap;
     // the shared-memory test transport keeps its mailboxes at a z-face's worth (24 particles per cell, two layers)
@@ -118,7 +119,7 @@ extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id1
     const char *t = getenv("SPH_COMM_TRANSPORT");
     if (t && !strcmp(t, "shm")) {
         if (nranks > SHM_MAX_RANKS) return fail(h, SPH_ERR_INVALID, "shm transport: at most %d ranks", SHM_MAX_RANKS);
-        int rc = shm_attach(h, c, mbox_records * 48);
+        int rc = shm_attach(h, c, mbox_records * 64);
         if (rc) return rc;
         c.kind = 2;
     } else {
@@ -144,8 +145,8 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
         const size_t cap = (size_t)s.halo_cap;
         for (int k = 0; k < 2; ++k) {
             int rc = dalloc(h, &s.xidx[k], (size_t)s.cap); if (rc) return rc;
-            rc = dalloc(h, &s.sendbuf[k], 3 * cap); if (rc) return rc;
-            rc = dalloc(h, &s.recvbuf[k], 3 * cap); if (rc) return rc;
+            rc = dalloc(h, &s.sendbuf[k], 4 * cap); if (rc) return rc;
+            rc = dalloc(h, &s.recvbuf[k], 4 * cap); if (rc) return rc;
         }
         for (int k = 0; k < 8; ++k) { int rc = dalloc(h, &s.halo_tab[k], cap); if (rc) return rc; }
         { int rc = dalloc(h, &s.halo_counts, 4); if (rc) return rc; }
@@ -444,10 +445,9 @@ extern "C" int sph_comm_set_rebalance(SphHandle *h, int every_steps) {
 static int slab_neighbor_search(SphHandle *h) {
     State &s = h->st;
     SlabComm &c = h->comm;
-    // (SURVEY 8e "rigid coupling under sharding": out of scope for C1-C5) a moving body's particles would have to take their
-    // rest positions along when they change owner and the wrench would have to be summed over the ranks: not built -- say so
-    if (s.has_dynamic_rigid && c.nranks > 1)
-        return fail(h, SPH_ERR_UNSUPPORTED, "slab sharding: dynamic rigid bodies are not supported (static bodies and the domain box are)");
+    // records: 48 B, or 64 B with the rest position (rigid_particle_original_positions) once the scene has a dynamic rigid body --
+    // its particles take it along when they change owner (every rank is told about the body: sph_set_object)
+    const size_t rec = s.orig.cur() ? 64 : 48;
     if (c.rebalance_every > 0 && h->prepared && h->steps > 0 && h->steps % c.rebalance_every == 0 && !h->any_rigid_object) {
         int rc = slab_rebalance(h); if (rc) return rc;
     }
@@ -479,8 +479,8 @@ static int slab_neighbor_search(SphHandle *h) {
             if (c.n_send[side] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "halo message of %d particles exceeds capacity %d", c.n_send[side], s.halo_cap);
             if (c.n_recv[side] < 0 || c.n_recv[side] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "received halo exceeds capacity");
         }
-        const size_t bs[2] = {(size_t)c.n_send[0] * 48, (size_t)c.n_send[1] * 48};
-        size_t br[2] = {(size_t)c.n_recv[0] * 48, (size_t)c.n_recv[1] * 48};
+        const size_t bs[2] = {(size_t)c.n_send[0] * rec, (size_t)c.n_send[1] * rec};
+        size_t br[2] = {(size_t)c.n_recv[0] * rec, (size_t)c.n_recv[1] * rec};
         int rc = comm_exchange(h, send, bs, recv, br, true); if (rc) return rc;
     } else {
         HIPCHK(h, hipMemcpyAsync(c.cnt_host, s.halo_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
@@ -490,10 +490,10 @@ static int slab_neighbor_search(SphHandle *h) {
             c.n_send[side] = c.cnt_host[side];
             if (c.n_send[side] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "halo message of %d particles exceeds capacity %d", c.n_send[side], s.halo_cap);
         }
-        const size_t bs[2] = {(size_t)c.n_send[0] * 48, (size_t)c.n_send[1] * 48};
+        const size_t bs[2] = {(size_t)c.n_send[0] * rec, (size_t)c.n_send[1] * rec};
         size_t br[2] = {0, 0};
         { ProfScope p(h, SPH_K_HALO); int rc = comm_exchange(h, send, bs, recv, br, false); if (rc) return rc; }
-        c.n_recv[0] = (int)(br[0] / 48); c.n_recv[1] = (int)(br[1] / 48);
+        c.n_recv[0] = (int)(br[0] / rec); c.n_recv[1] = (int)(br[1] / rec);
         if (c.n_recv[0] > s.halo_cap || c.n_recv[1] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "received halo exceeds capacity");
     }
     // nothing was compacted: the arrivals are appended behind the old particles (dead ones included), the sort files the

@@ -2,7 +2,7 @@
 //
 // Rank r owns the global cell layers cz in [z_lo, z_hi) (>= 2 layers) and keeps one ghost layer per interior
 // side.  Once per step, right before the sort, ONE message per neighbour carries both kinds of
-// records (48 B each: posv, velm, meta|pid|color|rho):
+// records (48 B each: posv, velm, meta|pid|color|rho; 64 B with the rest position when the scene has a dynamic rigid body):
 //   * migrants: particles that left the slab -> ownership moves (ghost flag 0);
 //   * boundary copies: owned particles in cz == z_lo / z_hi-1 -> ghosts of the neighbour (ghost flag 1).
 // A migrant that lands in the neighbour's boundary layer (it moved < 1 layer) is needed back as a ghost; both
@@ -24,13 +24,14 @@
 
 struct HaloArrays {
     const float4 *posv, *velm; int *meta; const int *pid; const unsigned *color; const float *rho; int *xidx;
+    const float4 *orig;   // rigid_particle_original_positions, or null: then records are 3 float4 (rs = 3), else 4
 };
 
-__device__ __forceinline__ void halo_write_record(float4 *buf, int k, const float4 &p, const float4 &v, int meta,
+__device__ __forceinline__ void halo_write_record(float4 *buf, int rs, int k, const float4 &p, const float4 &v, int meta,
                                                   int pid, unsigned color, float rho) {
-    buf[3 * k] = p;
-    buf[3 * k + 1] = v;
-    buf[3 * k + 2] = make_float4(__int_as_float(meta), __int_as_float(pid), __uint_as_float(color), rho);
+    buf[rs * k] = p;
+    buf[rs * k + 1] = v;
+    buf[rs * k + 2] = make_float4(__int_as_float(meta), __int_as_float(pid), __uint_as_float(color), rho);
 }
 
 // one atomic per wave and counter: base index of this lane among the lanes with `want`
@@ -79,7 +80,12 @@ k_halo_classify(const Consts c, int n, int z_lo, int z_hi, int has_down, int has
     if (i >= n) return;
     if (side >= 0) {
         const int k = side == 0 ? k0 : k1;
-        if (k < cap) halo_write_record(side == 0 ? send_down : send_up, k, p, a.velm[i], mrec, a.pid[i], a.color[i], a.rho[i]);
+        if (k < cap) {
+            float4 *buf = side == 0 ? send_down : send_up;
+            const int rs = a.orig ? 4 : 3;
+            halo_write_record(buf, rs, k, p, a.velm[i], mrec, a.pid[i], a.color[i], a.rho[i]);
+            if (a.orig) buf[rs * k + 3] = a.orig[i];
+        }
         const bool migrant = !META_GHOST(mrec);
         xi = HALO_PACK((migrant ? HALO_ECHO_GHOST : HALO_SEND) + side, k);
     }
@@ -91,14 +97,16 @@ k_halo_classify(const Consts c, int n, int z_lo, int z_hi, int has_down, int has
 // appends `count` records received from `side` (0 = lower rank, 1 = upper rank) at [offset, offset + count)
 __global__ void __launch_bounds__(256)
 k_halo_unpack(const Consts c, int count, int offset, int side, int z_lo, int z_hi, const float4 *recv, float4 *posv,
-              float4 *velm, int *meta, int *pid, unsigned *color, float *rho, int *xidx) {
+              float4 *velm, int *meta, int *pid, unsigned *color, float *rho, int *xidx, float4 *orig) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
-    const float4 p = recv[3 * k];
-    const float4 q = recv[3 * k + 2];
+    const int rs = orig ? 4 : 3;
+    const float4 p = recv[rs * k];
+    const float4 q = recv[rs * k + 2];
     const int m = __float_as_int(q.x);
     const int d = offset + k;
-    posv[d] = p; velm[d] = recv[3 * k + 1];
+    posv[d] = p; velm[d] = recv[rs * k + 1];
+    if (orig) orig[d] = recv[rs * k + 3];
     meta[d] = m; pid[d] = __float_as_int(q.y); color[d] = __float_as_uint(q.z); rho[d] = q.w;
     int xi;
     if (META_GHOST(m)) xi = HALO_PACK(HALO_GHOST + side, k);

@@ -5,7 +5,7 @@
 static void l_halo_classify_pack(State &s, int n) {
     hipMemsetAsync(s.halo_counts, 0, 4 * sizeof(int), s.stream);
     if (n > 0) {
-        HaloArrays a{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(), s.xidx[s.xcur]};
+        HaloArrays a{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(), s.xidx[s.xcur], s.orig.cur()};
         hipLaunchKernelGGL(k_halo_classify, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, n, s.z_lo, s.z_hi, s.has_down,
                            s.has_up, a, s.sendbuf[0], s.sendbuf[1], s.halo_cap, s.halo_counts);
     }
@@ -15,7 +15,7 @@ static void l_halo_unpack_append(State &s, int side, int count, int offset) {
     if (count <= 0) return;
     hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv(count, 256)), dim3(256), 0, s.stream, s.c, count, offset, side, s.z_lo, s.z_hi,
                        s.recvbuf[side], s.posv.cur(), s.velm.cur(), s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(),
-                       s.xidx[s.xcur]);
+                       s.xidx[s.xcur], s.orig.cur());
 }
 
 static void l_halo_build_tables(State &s) {
