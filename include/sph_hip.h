@@ -136,7 +136,8 @@ typedef enum {
 } SphKernelId;
 
 /* --- lifetime -------------------------------------------------------------------------- */
-/* replaces XContainer.__init__ allocation (base_container.py:129-185) + XSolver.__init__ */
+/* replaces XContainer.__init__ allocation (base_container.py:129-185) + XSolver.__init__.
+   particle_max_num <= 268,435,455 per handle (SPH_ERR_CAPACITY beyond: shard the scene over GPUs) */
 int sph_create(const SphParams *params, SphHandle **out);
 void sph_destroy(SphHandle *h);
 /* message of the last failure on this handle (h == NULL: last failure of sph_create) */

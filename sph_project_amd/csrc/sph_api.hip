@@ -187,6 +187,10 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
         return fail(nullptr, SPH_ERR_INVALID, "sph_create: invalid parameters");
     if ((double)p.grid_num[0] * p.grid_num[1] * p.grid_num[2] > 2.0e9)
         return fail(nullptr, SPH_ERR_INVALID, "sph_create: grid too large");
+    // particle indices travel as 32-bit BYTE offsets into float4 arrays (ldg_idx) and as 28-bit slot numbers of the slab
+    // sharding: 2^28 - 1 particles per handle (~70 GB of state; a bigger scene is sharded over GPUs)
+    if (p.particle_max_num > 0x0fffffff)
+        return fail(nullptr, SPH_ERR_CAPACITY, "sph_create: particle_max_num %d exceeds 268435455 per GPU; shard the scene (sph_comm_set_slab)", p.particle_max_num);
     if (p.method < 0 || p.method > 2) return fail(nullptr, SPH_ERR_INVALID, "sph_create: unknown method %d", p.method);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
