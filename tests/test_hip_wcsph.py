@@ -153,6 +153,35 @@ def test_all_neighbour_paths_agree(gpu, spacing, label):
     assert d.max() <= 1e-5
 
 
+@pytest.mark.parametrize("spacing,label", [(0.0080, "125 particles per cell: a group's three runs exceed the tile -> staged in rounds"),
+                                           (0.0058, "~330 per cell: single runs exceed the tile -> walked out of L2, 32 candidates at a time")])
+def test_piled_up_cells_density(gpu, spacing, label):
+    """Extreme pile-ups (the domain clamp of the reference parks particles in the boundary cells): the density pass alone -- a
+    full step would blow such a block apart -- through every path: default (rounds / L2 walk as the tile allows), ordered LDS
+    walk (mode 4), everything from L2 (mode 1); bitwise the same densities and pair counts, and the oracle's."""
+    cfg = H.dam_break_scene(end=(0.118, 0.118, 0.118), particleSpacing=spacing)
+    out = []
+    for fg in (0, 4, 1):
+        container, solver = H.build_product(cfg, jitter=0.3 * spacing, seed=4, force_global=fg)
+        solver.prepare()
+        e = container.engine
+        e.run_phase(L.PH_DENSITY)
+        ids = e.download(L.F_PARTICLE_ID)
+        out.append((H.by_id(ids, e.download(L.F_DENSITY)), solver.stats()))
+    for rho, st in out[1:]:
+        np.testing.assert_array_equal(out[0][0], rho)
+        assert st["pair_interactions"] == out[0][1]["pair_interactions"]
+    ref = H.build_oracle(cfg, jitter=0.3 * spacing, seed=4)
+    ref.prepare()
+    ref.call("compute_density")
+    rho_ref = H.by_id(H.oracle_ids(ref), ref.field("particle_densities").copy())
+    n = len(rho_ref)
+    print(label, ": n = %d, max rho / rho0 = %.0f, pairs per particle %.0f, runs walked from L2 %d (default) / %d (forced)" % (
+        n, rho_ref.max() / 1000.0, out[0][1]["pair_interactions"] / n, out[0][1]["lds_fallback_blocks"], out[2][1]["lds_fallback_blocks"]))
+    np.testing.assert_allclose(out[0][0], rho_ref, rtol=3e-6)   # (a density that matches to 3e-6 has the oracle's neighbours)
+    assert rho_ref.max() > 10 * 1000.0
+
+
 def test_static_domain_box(gpu):
     """addDomainBox: static rigid boundary particles (base_container.py:192, base_solver.py:106)."""
     cfg = H.dam_break_scene(domain_end=(0.6, 0.6, 0.6), end=(0.2, 0.2, 0.2), translation=(0.06, 0.06, 0.06),
