@@ -266,6 +266,11 @@ class BaseContainer:
         for _ in self.rigid_blocks:
             raise NotImplementedError
 
+    def objects_pending(self):
+        """True while some object of the scene has not entered yet (entryTime, base_container.py:218-221)."""
+        every = list(self.fluid_blocks) + list(self.fluid_bodies) + list(self.rigid_bodies)
+        return any(o["objectId"] not in self.present_object for o in every)
+
     def add_particles(self, object_id, new_particles_num, new_particles_positions, new_particles_velocity,
                       new_particle_density, new_particle_pressure, new_particles_material,
                       new_particles_is_dynamic, new_particles_color, slab_positions=None):

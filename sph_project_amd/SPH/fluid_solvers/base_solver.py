@@ -83,5 +83,21 @@ class BaseSolver:
         self.container.total_time += self.dt[None]
         self.rigid_solver.total_time += self.dt[None]
 
+    def advance(self, n):
+        """n calls of step().  Where the host has nothing to do inside a step -- no dynamic rigid body to integrate, no object
+        still waiting for its entryTime -- they go to the device as ONE sph_step(h, n): no Python, no host synchronisation
+        between them (not in the reference, whose driver can only call step())."""
+        n = int(n)
+        if n <= 0:
+            return
+        if self.rigid_solver.bodies or self.container.objects_pending():
+            for _ in range(n):
+                self.step()
+            return
+        self.engine.step(n)
+        for _ in range(n):   # the same float additions as n calls of step()
+            self.container.total_time += self.dt[None]
+            self.rigid_solver.total_time += self.dt[None]
+
     def stats(self):
         return self.engine.stats()

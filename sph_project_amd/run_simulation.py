@@ -69,14 +69,25 @@ def main(argv=None):
     solver.prepare()
 
     cnt = 0
+    limit = total_rounds if args.max_steps is None else min(total_rounds, args.max_steps)
+    limit = max(limit, 1)   # the reference's loop steps once before it looks at the round count
     t0 = time.perf_counter()
-    while True:
-        solver.step()
-        if cnt % output_interval == 0 and output_ply:
+    while cnt < limit:
+        # run_simulation.py:126-153 steps once, writes a frame if the count of steps BEFORE this one is a multiple of the
+        # interval, then counts.  Same frames here, but the steps between two frames go to the device in one call.
+        wants_frame = output_ply or output_obj
+        nxt = cnt if cnt % output_interval == 0 else cnt + output_interval - cnt % output_interval   # next count that gets a frame
+        if not wants_frame or nxt >= limit:
+            solver.advance(limit - cnt)
+            cnt = limit
+            break
+        solver.advance(nxt - cnt + 1)
+        cnt = nxt
+        if output_ply:
             os.makedirs(f"{out_dir}/{cnt:06}", exist_ok=True)
             for f_body_id in container.object_id_fluid_body:
                 write_ply_ascii(f"{out_dir}/{cnt:06}/particle_object_{f_body_id}.ply", container.dump(obj_id=f_body_id)["position"])
-        if cnt % output_interval == 0 and output_obj:   # run_simulation.py:146-150
+        if output_obj:   # run_simulation.py:146-150
             os.makedirs(f"{out_dir}/{cnt:06}", exist_ok=True)
             for r_body_id in container.object_id_rigid_body:
                 if "mesh" not in container.object_collection[r_body_id]:   # body given as pre-voxelised points only
@@ -84,8 +95,6 @@ def main(argv=None):
                 with open(f"{out_dir}/{cnt:06}/mesh_object_{r_body_id}.obj", "w") as f:
                     f.write(container.object_collection[r_body_id]["mesh"].export(file_type="obj"))
         cnt += 1
-        if cnt >= total_rounds or (args.max_steps is not None and cnt >= args.max_steps):
-            break
     dt = time.perf_counter() - t0
     print(f"Simulation Finished: {cnt} steps, {container.particle_num[None]} particles, {1e3 * dt / cnt:.3f} ms/step")
     return container, solver

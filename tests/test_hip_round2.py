@@ -299,6 +299,26 @@ def _bench(args, env_extra, timeout=600):
     return json.loads(lines[0])
 
 
+def test_advance_equals_repeated_step(gpu):
+    """solver.advance(n) = n x solver.step(): one sph_step(h, n) where the host has nothing to do inside the steps, the
+    step-by-step loop while an object is still waiting for its entryTime."""
+    for cfg in (P.dam_break_scene(method="dfsph", dt=6e-4), None):
+        if cfg is None:   # a second block enters during the 4th step
+            cfg = P.dam_break_scene(end=(0.12, 0.1, 0.12), velocity=(0.0, -0.5, 0.0))
+            cfg["FluidBlocks"].append({"objectId": 1, "start": [0.0, 0.0, 0.0], "end": [0.07, 0.07, 0.09], "translation": [0.12, 0.2, 0.11],
+                                       "scale": [1, 1, 1], "velocity": [0.0, -1.0, 0.0], "density": 1000.0, "color": [1, 2, 3],
+                                       "entryTime": 2.5 * 4e-4})
+        a_c, a_s = H.build_product(cfg); a_s.prepare()
+        b_c, b_s = H.build_product(cfg); b_s.prepare()
+        a_s.advance(4); a_s.advance(5)
+        for _ in range(9):
+            b_s.step()
+        assert a_c.total_time == b_c.total_time and a_c.engine.particle_num == b_c.engine.particle_num
+        for f in (L.F_PARTICLE_ID, L.F_POSITION, L.F_VELOCITY, L.F_DENSITY):
+            np.testing.assert_array_equal(a_c.engine.download(f), b_c.engine.download(f))
+        del a_c, a_s, b_c, b_s
+
+
 def test_bench_spawns_two_ranks_without_torch(gpu):
     """`python bench.py --gpus 2` with no launcher: two ranks, z-slab sharded, halo exchange through the shared-memory
     transport (two ranks on this box's one GPU), barriers / reductions through sph_comm_*; no torch import."""
