@@ -118,7 +118,7 @@ def test_pcisph_slab_sharding_matches_oracle(gpu, tmp_path, nranks, fixed):
         assert d.max() <= 1e-5
 
 
-@pytest.mark.parametrize("method,nranks", [("wcsph", 2), ("wcsph", 3), ("dfsph", 2)])
+@pytest.mark.parametrize("method,nranks", [("wcsph", 2), ("wcsph", 3), ("dfsph", 2), ("pcisph", 2)])
 def test_implicit_viscosity_slab_sharding_matches_oracle(gpu, tmp_path, method, nranks):
     """Implicit viscosity under z-slab sharding (base_solver.py:445-517): the ghosts' search direction goes out before every
     A p pass, the dot products are all-reduced, the solved velocities of the ghosts follow the loop.  The reference keeps
