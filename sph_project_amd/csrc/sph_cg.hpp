@@ -331,7 +331,14 @@ k_cg_update_p2(int n, int nb, const int *meta, int all_fluid, const float4 *r, f
 __global__ void __launch_bounds__(256)
 k_cg_prepare_guess(int n, const int *meta, int all_fluid, float4 *x, const float4 *v0) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || !is_fluid(meta, i, all_fluid)) return;
+    if (i >= n) return;
+    if (!is_fluid(meta, i, all_fluid)) {
+        // slab sharding: a ghost slot holds the neighbour rank's solved VELOCITY (it fed the viscosity formula), not a guess;
+        // the slot is somebody else's next step (the guess is slot-indexed, base_container.py:506 does not reorder it), and a
+        // velocity there would start that particle's solve an O(|v|) off.  Zero = "start from the current velocity".
+        if (META_GHOST(meta[i])) x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     float4 xx = x[i];
     const float4 v = v0[i];
     xx.x -= v.x; xx.y -= v.y; xx.z -= v.z;

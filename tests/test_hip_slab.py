@@ -123,8 +123,8 @@ def test_implicit_viscosity_slab_sharding_matches_oracle(gpu, tmp_path, method, 
     """Implicit viscosity under z-slab sharding (base_solver.py:445-517): the ghosts' search direction goes out before every
     A p pass, the dot products are all-reduced, the solved velocities of the ghosts follow the loop.  The reference keeps
     last step's solution as the initial guess WITHOUT reordering it with the particles (slot-indexed), so a sharded run starts
-    its solves from a different guess than an undecomposed one: both run the reference's stop test (|r| <= 1e-6) and agree to
-    the solver's tolerance, not to rounding."""
+    its solves from a slightly different guess than an undecomposed one: both run the reference's stop test (|r| <= 1e-6),
+    take the same number of iterations (+-1) and agree to the solver's tolerance, not to rounding."""
     cfg = H.dam_break_scene(method=method, domain_end=(1.0, 1.0, 1.2), start=(0.1, 0.1, 0.08), end=(0.36, 0.36, 1.12),
                             translation=(0, 0, 0), velocity=(0.0, -0.3, 2.0), particleSpacing=0.019, dt=4e-4,
                             viscosity=50.0, viscosity_method="implicit")
@@ -152,8 +152,8 @@ def test_implicit_viscosity_slab_sharding_matches_oracle(gpu, tmp_path, method, 
     print("implicit %s slab x%d: drift max %.3e, |dv|/vmax %.3e, CG iterations per step %s, oracle %s" % (method, nranks, d.max(), dv, it[0], it_ref))
     assert all(i == it[0] for i in it), "every rank runs the same number of iterations"
     assert max(it_ref) >= 5, "the solver has work to do in this scene"
-    # a slot-indexed guess lands on other particles under sharding (ghosts shift the local indices): a few more iterations
-    assert max(it[0]) <= max(it_ref) + 4 and min(it[0]) >= min(it_ref)
+    # (the warm start is slot-indexed; ghost slots are zeroed after a solve so that no neighbour-rank velocity is taken for a guess)
+    assert max(abs(a - b) for a, b in zip(it[0], it_ref)) <= 1
     assert d.max() <= 1e-6 and dv <= 1e-5
 
 
