@@ -93,7 +93,9 @@ def test_pcisph_slab_sharding_matches_oracle(gpu, tmp_path, nranks, fixed):
     print("per step (iterations, error): rank 0", [(int(r[0]), float("%.4e" % r[1])) for r in outs[0]["hist"]])
     if not fixed:
         assert max(h[0] for h in hist_ref) < 1000 and max(h[0] for h in hist_ref) >= 10
-        assert [int(r[0]) for r in outs[0]["hist"]] == [h[0] for h in hist_ref]
+        # (the all-reduced sum is added up in another order than the oracle's: a step whose error passes the threshold by less
+        #  than that rounding may stop one iteration apart -- SURVEY 8c; none does in this scene, +-1 keeps the test from flaking)
+        assert max(abs(int(r[0]) - h[0]) for r, h in zip(outs[0]["hist"], hist_ref)) <= 1
     ids = H.oracle_ids(ref)
     x_ref = H.by_id(ids, ref.field("particle_positions").copy())
     prs_ref = H.by_id(ids, ref.field("particle_pressures").copy())
