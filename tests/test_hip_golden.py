@@ -105,9 +105,12 @@ def test_hip_matches_golden(gpu, path, fast_math):
                 ref = z[pre + key].astype(np.float64)
                 assert np.abs(ref).max() > 0
                 worst[key] = float(np.abs(mine[:ref.shape[0]].astype(np.float64) - ref).max() / np.abs(ref).max())
-        lim = {"positions": 1e-5, "velocities": 5e-4, "densities": 2e-5, "rest_volumes": 1e-5, "masses": 1e-5,
-               "rigid_forces": 2e-4, "rigid_torques": 5e-4}
+        # limits = a few times the worst error any fixture shows in either build (relative to the field's maximum); the loose
+        # ones are quantities that cancel (D rho / Dt, kappa) or integrate a clamped iteration (PCISPH pressure)
+        lim = {"positions": 1e-5, "velocities": 5e-5, "densities": 2e-5, "rest_volumes": 5e-6, "masses": 5e-6, "alphas": 5e-5,
+               "densities_star": 1e-5, "cg_x": 2e-5, "kappa": 1e-3, "kappa_v": 1e-3, "densities_derivatives": 4e-3,
+               "pressures": 2e-3, "accelerations": 2e-3, "rigid_forces": 2e-5, "rigid_torques": 5e-5}
         for k, v in worst.items():
-            assert v < lim.get(k, 5e-3), (cp, k, v, worst)
+            assert v < lim[k], (cp, k, v, worst)
         slot_fluid, slot_fluid_step = z[pre + "materials"] == 1, cp
     print(os.path.basename(path), "fast" if fast_math else "strict", "final drift %.2e" % d, worst)
