@@ -226,7 +226,7 @@ int sph_comm_set_rebalance(SphHandle *h, int every_steps);
    fluid; every rank calls this next to its sph_append_particles of the slab's share (which may be empty) */
 int sph_comm_add_global_count(SphHandle *h, int n, int n_fluid);
 /* host-visible collectives over the communicator (what a launcher otherwise needs MPI / torch.distributed for):
-   in-place all-reduce of <= 16 doubles, op 0 sum / 1 max / 2 min (ncclAllReduce); barrier = drain the stream,
+   in-place all-reduce of <= 128 doubles, op 0 sum / 1 max / 2 min (ncclAllReduce); barrier = drain the stream,
    then all-reduce; both synchronous.  The solver residuals of a sharded DFSPH / PCISPH step use the same path. */
 int sph_comm_allreduce(SphHandle *h, double *inout, int count, int op);
 int sph_comm_barrier(SphHandle *h);

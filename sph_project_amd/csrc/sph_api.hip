@@ -415,10 +415,7 @@ extern "C" int sph_get_rigid_wrench(SphHandle *h, float *force, float *torque, i
         // rigid solver does, between sph_step_begin and sph_step_end).
         double w[2 * SPH_NOBJ * 3];
         for (int k = 0; k < SPH_NOBJ * 3; ++k) { w[k] = force[k]; w[SPH_NOBJ * 3 + k] = torque[k]; }
-        for (int k0 = 0; k0 < 2 * SPH_NOBJ * 3; k0 += 16) {
-            const int cnt = 2 * SPH_NOBJ * 3 - k0 < 16 ? 2 * SPH_NOBJ * 3 - k0 : 16;
-            int rc = sph_comm_allreduce(h, w + k0, cnt, 0); if (rc) return rc;
-        }
+        { int rc = sph_comm_allreduce(h, w, 2 * SPH_NOBJ * 3, 0); if (rc) return rc; }   // one collective
         for (int k = 0; k < SPH_NOBJ * 3; ++k) { force[k] = (float)w[k]; torque[k] = (float)w[SPH_NOBJ * 3 + k]; }
     }
     if (reset)

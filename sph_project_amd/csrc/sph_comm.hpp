@@ -13,7 +13,7 @@ struct ShmMailbox {           // one per (writer rank, direction); written by `r
     uint64_t pad[5];
 };
 #define SHM_MAX_RANKS 64
-#define SHM_RED_MAX 16
+#define SHM_RED_MAX 128   /* doubles per sph_comm_allreduce (the rigid wrench of all objects is 120) */
 struct ShmHeader {
     std::atomic<int> attached; std::atomic<int> detached; int nranks; int pad; uint64_t mbox_cap;
     // sph_comm_barrier / sph_comm_allreduce of the shm transport: arrival counter + generation, one row of doubles per rank
