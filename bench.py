@@ -357,7 +357,8 @@ def run_rank(args, rank, world, local_rank):
     achieved = ALG_BYTES[dom] * n_fluid / avg_s / 1e9 if launches else None
 
     in_motion = None
-    if args.motion_step and not args.presteps and args.config in ("c2", "c4") and method == "wcsph" and steps_done < args.motion_step:
+    fixed_work = method == "wcsph" or not args.measured_iterations   # (measured-iteration loops: ms/step is the iteration count's)
+    if args.motion_step and not args.presteps and args.config in ("c2", "c3", "c4") and fixed_work and steps_done < args.motion_step:
         run(args.motion_step - steps_done); steps_done = args.motion_step
         m_el = median(timed(args.repeats))
         st2 = solver.stats()
@@ -366,8 +367,9 @@ def run_rank(args, rank, world, local_rank):
         in_motion = {"from_step": args.motion_step, "ms_per_step": 1e3 * m_el / args.steps,
                      "value": n_total * args.steps / m_el, "pair_interactions_per_step": p2,
                      "pair_interactions_per_s": p2 * args.steps / m_el, "pair_evaluations_per_s": e2 * args.steps / m_el,
-                     "neighbours_per_particle": e2 / max(n_total, 1) / 2.0,
                      "lds_fallback_blocks_last_step": int(st2["lds_fallback_blocks"])}
+        if method == "wcsph":   # two neighbour walks per step (density, fused forces)
+            in_motion["neighbours_per_particle"] = e2 / max(n_total, 1) / 2.0
 
     traffic = None
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
