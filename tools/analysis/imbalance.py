@@ -37,6 +37,16 @@ def analyse(pos, h, label):
     perm2 = np.argsort(-key2, axis=1, kind="stable")
     cgs2 = np.take_along_axis(cg, perm2[:, :, None], axis=1).reshape(nb, 4, 64, 3)
     static_c = cgs2.max(2).sum(2).mean()
+    # static permutation by TOTAL accepted count (known at the end of the mask-building pass)
+    perm3 = np.argsort(-cg.sum(2), axis=1, kind="stable")
+    cgs3 = np.take_along_axis(cg, perm3[:, :, None], axis=1).reshape(nb, 4, 64, 3)
+    static_t = cgs3.max(2).sum(2).mean()
+    # ... and by (frac-x bucket of 4, total count): x position first, count inside
+    key4 = np.floor(fx * 4).astype(np.int64) * 1000 - cg.sum(2)
+    perm4 = np.argsort(key4, axis=1, kind="stable")
+    cgs4 = np.take_along_axis(cg, perm4[:, :, None], axis=1).reshape(nb, 4, 64, 3)
+    static_xt = cgs4.max(2).sum(2).mean()
+    print(f"   static sort by total count {static_t:.1f}; by (x quarter, count) {static_xt:.1f}; ideal (mean per wave) {cg.reshape(nb, 4, 64, 3).sum(3).mean():.1f}")
     # per-group sort by count (what a per-group hand-over achieves)
     srt = -np.sort(-cg, axis=1)
     pg_sorted = srt.reshape(nb, 4, 64, 3).max(2).sum(2).mean()
