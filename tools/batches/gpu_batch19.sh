@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B of library variants: SPH_HIP_LIB selects the .so
 O=gpurun_out/b19; mkdir -p $O
-for rep in 1 2; do for v in base win; do
+for rep in 1 2; do for v in base relaxocc nopost; do
   SPH_HIP_LIB=$PWD/sph_project_amd/variants/libsph_hip_$v.so python bench.py --no-cpu-baseline > $O/c2_$v$rep.json 2>/dev/null
   SPH_HIP_LIB=$PWD/sph_project_amd/variants/libsph_hip_$v.so python bench.py --no-cpu-baseline --config c3 > $O/c3_$v$rep.json 2>/dev/null
   python - <<PY
