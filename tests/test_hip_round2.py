@@ -319,6 +319,40 @@ def test_advance_equals_repeated_step(gpu):
         del a_c, a_s, b_c, b_s
 
 
+def test_handles_release_their_memory(gpu):
+    """sph_destroy gives back what sph_create / sph_comm_* took: 12 create-run-destroy cycles (every second one in slab mode
+    with a communicator) do not eat device memory."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    cfg = P.dam_break_scene(end=(1.2, 1.2, 1.2), domain_end=(1.6, 1.6, 1.6))   # 216,000 particles, ~130 MB per handle
+    lib = L.load()
+
+    def cycle(k):
+        opts = {}
+        if k % 2:
+            buf = ctypes.create_string_buffer(128)
+            assert lib.sph_comm_unique_id(buf) == 0
+            opts["slab"] = dict(rank=0, nranks=1, unique_id=buf.raw, cuts=[0, 40])
+        c, s = H.build_product(cfg, **opts)
+        s.prepare(); s.step(); s.step()
+        c.engine.close()
+
+    os.environ.setdefault("SPH_COMM_TRANSPORT", "shm")
+    cycle(0); cycle(1)                 # first use: runtime pools, code objects
+    before = free_bytes()
+    for k in range(12):
+        cycle(k)
+    lost = before - free_bytes()
+    print("device memory lost over 12 create/destroy cycles: %.1f MB" % (lost / 1e6))
+    assert lost < 48e6, lost
+
+
 def test_bench_spawns_two_ranks_without_torch(gpu):
     """`python bench.py --gpus 2` with no launcher: two ranks, z-slab sharded, halo exchange through the shared-memory
     transport (two ranks on this box's one GPU), barriers / reductions through sph_comm_*; no torch import."""
