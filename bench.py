@@ -72,6 +72,9 @@ def parse_args(argv=None):
                     help="N>1: weak = every z-slab gets one C2 block (N x 1.23 M particles); strong = the 1.23 M scene is split")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent copies instead of z-slab sharding")
     ap.add_argument("--no-c4", action="store_true", help="N>1: skip the extra C4 (4 M particles, strong scaling) measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra objects of the line: N=1: C3 (DFSPH) and C5 (implicit-viscosity buckling scene); "
+                         "N>1: the 1.23 M scene and C4 under strong scaling")
     return ap.parse_args(argv)
 
 
@@ -187,15 +190,15 @@ def cpu_baseline(cfg, steps):
     return dict(value=table[best], cores=best, secs=best_dt, pairs_per_s=pairs * steps / best_dt, sweep=table, model=model, ncpu=ncpu)
 
 
-# ----------------------------------------------------------------------------------------------- C4 on N GPUs
-def c4_sharded(args, rank, world, device, lib):
-    """BASELINE configs[3]: the 4,000,000-particle WCSPH dam break z-slab sharded over the N ranks of this job (one fixed
-    scene: strong scaling).  Runs after the headline measurement with a communicator of its own; reported as an extra
-    object of the JSON line (`c4_strong_scaling`), never as `value`."""
+# ----------------------------------------------------------------------------------------------- fixed scenes on N GPUs
+def sharded_extra(args, rank, world, device, lib, cfg, workload, suffix):
+    """One FIXED scene z-slab sharded over the N ranks of this job (strong scaling), measured after the headline with a
+    communicator of its own and reported as an extra object of the JSON line, never as `value`:
+      * `c2_strong_scaling`: BASELINE.json's metric as written ("at 1.23M particles, 1/2/4/8 GPU"): the C2 scene itself;
+      * `c4_strong_scaling`: BASELINE configs[3], the 4,000,000-particle WCSPH dam break."""
     import numpy as np
     from sph_project_amd import product as P, slab
-    cfg = P.c4_scene("wcsph")
-    uid = exchange_unique_id(lib, rank, suffix=".c4")
+    uid = exchange_unique_id(lib, rank, suffix=suffix)
     _, geo, batches = P.scene_particles(cfg)
     z = np.concatenate([b["pos"][:, 2] for b in batches])
     nz = int(geo.grid_num[2])
@@ -218,17 +221,122 @@ def c4_sharded(args, rank, world, device, lib):
     pairs = int(eng.comm_allreduce([solver.stats()["pair_interactions"]], "sum")[0])
     info = eng.comm_get_slab()
     owned = [int(v) for v in eng.comm_allreduce([info["n_owned"] if r == rank else 0 for r in range(min(world, 16))], "sum")]
+    transport = eng.comm_transport() if hasattr(eng, "comm_transport") else os.environ.get("SPH_COMM_TRANSPORT", "rccl")
     eng.comm_barrier()
     if rank == 0 and not os.environ.get("SPH_BENCH_RDV"):
         try:
-            os.unlink(rendezvous_path() + ".c4")
+            os.unlink(rendezvous_path() + suffix)
         except OSError:
             pass
     eng.close()
-    return {"workload": "C4 4,000,000-particle dam break, WCSPH", "scaling": "strong", "particles": n_global, "n_gpus": world,
+    return {"workload": workload, "scaling": "strong", "particles": n_global, "n_gpus": world,
             "ms_per_step": 1e3 * el / args.steps, "value": n_global * args.steps / el, "unit": "particle-updates/s",
             "pair_interactions_per_s": pairs * args.steps / el, "slab_cuts": [int(c) for c in cuts], "owned_per_rank": owned,
-            "steps": args.steps, "warmup": args.warmup}
+            "halo_transport": transport, "steps": args.steps, "warmup": args.warmup}
+
+
+# ----------------------------------------------------------------------------------------------- C3 / C5 at N = 1
+def median(v):
+    s_ = sorted(v)
+    return s_[len(s_) // 2]
+
+
+def kernel_table(eng, names):
+    t = {names[k]: eng.profile_read(k) for k in range(N_KERNEL_IDS)}
+    return {k: v for k, v in t.items() if v[0] > 0}
+
+
+def extra_c3(args, names):
+    """BASELINE configs[2]: the C2 scene with DFSPH (divergence + density solver), 2 + 2 fixed iterations per step (SURVEY 8d
+    C3), enqueued without host read-backs; per-pass microseconds from an all-kernel HIP-event pre-pass."""
+    from sph_project_amd import product as P
+    cfg = P.c2_scene("dfsph")
+    container, solver = P.build_product(cfg, fast_math=0 if args.strict_math else 1, fixed_iterations=2,
+                                        deterministic=0 if args.no_deterministic else 1)
+    eng = container.engine
+    solver.prepare()
+    n = int(container.fluid_particle_num[None])
+    eng.step_async(args.warmup); eng.synchronize()
+    eng.profile_enable(-1, True); eng.profile_reset()
+    eng.step_async(5); eng.synchronize()
+    table = kernel_table(eng, names)
+    eng.profile_enable(-1, False)
+    reps = []
+    for _ in range(args.repeats):
+        eng.synchronize(); t0 = time.perf_counter()
+        eng.step_async(args.steps); eng.synchronize()
+        reps.append(time.perf_counter() - t0)
+    el = median(reps)
+    st = solver.stats()
+    it_div, it_den = int(st["iter_divergence"]), int(st["iter_density"])
+    per_pass = {k: {"launches_per_step": v[0] / 5.0, "avg_us": 1e3 * v[1] / v[0]} for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])}
+    dom = max((k for k in table if k in ALG_BYTES), key=lambda k: table[k][1])
+    avg_s = table[dom][1] / table[dom][0] * 1e-3
+    ach = ALG_BYTES[dom] * n / avg_s / 1e9
+    # one solver iteration = one correction pass + one rho* / D rho pass (+ their reduction): 92 B/particle (SURVEY 8d)
+    it_us = sum(1e3 * table[k][1] / table[k][0] for k in ("dfsph_correct", "dfsph_rho_adv") if k in table)
+    step_bytes = (16 + 60 + 20 + 20 + 44 + 36 + 92 * (it_div + it_den)) * n + 12 * int(container.grid_num.prod())
+    out = {"workload": "C3 1,231,200-particle dam break, DFSPH, 2+2 fixed iterations", "particles": n, "dt": cfg["Configuration"]["timeStepSize"],
+           "ms_per_step": 1e3 * el / args.steps, "repeat_ms_per_step": [1e3 * r / args.steps for r in reps],
+           "value": n * args.steps / el, "unit": "particle-updates/s", "steps": args.steps, "warmup": args.warmup,
+           "solver_iterations_per_step": {"divergence": it_div, "density": it_den},
+           "pair_interactions_per_s": st["pair_interactions"] * args.steps / el, "kernels": per_pass,
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "avg_launch_us": 1e6 * avg_s, "alg_bytes_per_launch": ALG_BYTES[dom] * n,
+                        "solver_iteration": {"alg_bytes_per_particle": 92, "us": it_us,
+                                             "achieved": 92 * n / (it_us * 1e-6) / 1e9 if it_us else None,
+                                             "frac": 92 * n / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else None},
+                        "step_achieved": step_bytes / (el / args.steps) / 1e9,
+                        "step_alg_bytes": step_bytes}}
+    eng.close()
+    return out
+
+
+def extra_c5(args, names):
+    """BASELINE configs[4]: the reference's buckling scene (final_scene3.json without its mesh body): DFSPH + implicit
+    viscosity (matrix-free CG over the neighbour graph), 2.17 M particles of which 106,400 fluid, G = 10 M cells; the
+    solvers' own stop tests (DFSPH.py:150/:239, base_solver.py:445-449), so steps are synchronous like the reference's."""
+    from sph_project_amd import product as P
+    cfg = P.c5_scene()
+    container, solver = P.build_product(cfg, fast_math=0 if args.strict_math else 1, deterministic=0 if args.no_deterministic else 1)
+    eng = container.engine
+    solver.prepare()
+    n, nf = int(container.particle_num[None]), int(container.fluid_particle_num[None])
+    for _ in range(3):
+        solver.step()
+    eng.profile_enable(-1, True); eng.profile_reset()
+    it_pre = 0
+    for _ in range(5):
+        solver.step(); it_pre += int(solver.stats()["iter_cg"])
+    eng.synchronize()
+    table = kernel_table(eng, names)
+    eng.profile_enable(-1, False)
+    k_steps = min(args.steps, 20)
+    iters = []
+    eng.synchronize(); t0 = time.perf_counter()
+    for _ in range(k_steps):
+        solver.step()
+        st = solver.stats()
+        iters.append((int(st["iter_cg"]), int(st["iter_density"]), int(st["iter_divergence"])))
+    eng.synchronize()
+    el = time.perf_counter() - t0
+    n_cg = sum(i[0] for i in iters)
+    cg_ms = sum(table[k][1] for k in ("cg_ap", "cg_vector") if k in table)
+    it_us = 1e3 * cg_ms / max(it_pre, 1)          # device time of one CG iteration (A p pass + vector updates), event pre-pass
+    wall_it_us = None
+    per_pass = {k: {"launches_per_step": v[0] / 5.0, "avg_us": 1e3 * v[1] / v[0]} for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])}
+    ach = 224 * nf / (it_us * 1e-6) / 1e9 if it_us else None
+    out = {"workload": "C5 buckling sheet (final_scene3.json without its mesh body): DFSPH + implicit viscosity, solver stop tests",
+           "particles": n, "fluid_particles": nf, "grid_cells": int(container.grid_num.prod()), "dt": cfg["Configuration"]["timeStepSize"],
+           "ms_per_step": 1e3 * el / k_steps, "value": nf * k_steps / el, "unit": "fluid particle-updates/s", "steps": k_steps, "warmup": 8,
+           "cg_iterations_per_step": n_cg / k_steps, "us_per_cg_iteration": it_us,
+           "dfsph_iterations_per_step": {"density": sum(i[1] for i in iters) / k_steps, "divergence": sum(i[2] for i in iters) / k_steps},
+           "kernels": per_pass,
+           "roofline": {"bound": "hbm", "kernel": "cg iteration (cg_ap + cg_vector)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS if ach else None, "alg_bytes_per_launch": 224 * nf, "avg_launch_us": it_us,
+                        "note": "224 B per fluid particle per CG iteration (SURVEY 8d); 106 k rows: launch/dependency latency, not bandwidth"}}
+    eng.close()
+    return out
 
 
 # ----------------------------------------------------------------------------------------------- one rank
@@ -333,10 +441,6 @@ def run_rank(args, rank, world, local_rank):
             out.append(allmax(time.perf_counter() - t0))
         return out
 
-    def median(v):
-        s = sorted(v)
-        return s[len(s) // 2]
-
     eng.profile_enable(names.index(dom), not os.environ.get("SPH_BENCH_NO_EVENTS"))
     eng.profile_reset()
     reps = timed(args.repeats); steps_done += args.repeats * args.steps
@@ -371,16 +475,31 @@ def run_rank(args, rank, world, local_rank):
         if method == "wcsph":   # two neighbour walks per step (density, fused forces)
             in_motion["neighbours_per_particle"] = e2 / max(n_total, 1) / 2.0
 
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    # PMC-derived figures of the dominant kernel: NOT measured in this run -- read from profiles/pmc_derived.json, which
+    # tools/prof_summary.py --json writes from the committed rocprofv3 PMC passes of this same command (source named there)
+    traffic = secondary = pmc_source = None
+    tf = os.path.join(ROOT, "profiles", "pmc_derived.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get(args.config, {}).get(dom)
+            d = json.load(open(tf))
+            e = d.get(args.config, {}).get(dom)
+            if e:
+                traffic = e.get("hbm_bytes_per_launch")
+                secondary = {k: e.get(k) for k in ("valu_issue_frac", "waves_parked_frac", "lds_active_frac", "lds_conflict_frac", "eff_clock_ghz")}
+                pmc_source = d.get("_source")
         except Exception:  # noqa: BLE001
-            traffic = None
+            pass
+    copy_gbs = None
+    if rank == 0:
+        try:
+            copy_gbs = eng.measure_copy_rate(1 << 30, 10)   # measured now, on this GPU: the second denominator
+        except Exception as ex:  # noqa: BLE001
+            print(f"[bench] copy-rate measurement failed: {ex}", file=sys.stderr)
 
+    step_bytes = 204 * n_fluid + 12 * int(container.grid_num.prod()) // (world if sharded else 1)   # SURVEY 8d, per rank
     scaling = ("strong" if args.config == "c4" else args.scaling) if sharded else "weak"
-    transport = os.environ.get("SPH_COMM_TRANSPORT", "rccl")
+    transport = (eng.comm_transport() if hasattr(eng, "comm_transport") and (sharded or force_slab)
+                 else os.environ.get("SPH_COMM_TRANSPORT", "rccl"))
     out = {
         "metric": "particle-updates/sec", "value": value, "unit": "particle-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -394,7 +513,7 @@ def run_rank(args, rank, world, local_rank):
             "dt": cfg["Configuration"]["timeStepSize"], "math": "strict" if args.strict_math else "fast",
             "deterministic_sort": not args.no_deterministic,
             "parallelism": "single-gpu" if world == 1 else
-                           (f"z-slab x{world}, {'RCCL' if transport != 'shm' else 'shared-memory (test rig)'} halo exchange ({scaling} scaling)" if sharded else f"replicas x{world}"),
+                           (f"z-slab x{world}, {transport} halo exchange ({scaling} scaling)" if sharded else f"replicas x{world}"),
             "state": "steps %d..%d from the initial lattice" % (args.presteps + args.warmup + 5, args.presteps + args.warmup + 5 + args.repeats * args.steps),
             "pair_interactions_per_step": int(pairs),
             "pair_interactions_per_s": pairs * args.steps / elapsed,      # every accepted pair once per REFERENCE pass
@@ -409,10 +528,18 @@ def run_rank(args, rank, world, local_rank):
         "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+            "traffic_source": (f"{pmc_source}: 2*FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes; NOT measured in this run"
+                               if traffic else None),
             "launches": int(launches), "avg_launch_us": 1e6 * avg_s,
             "alg_bytes_per_launch": ALG_BYTES[dom] * n_fluid,
-            "step_achieved": (204 * n_fluid + 12 * int(container.grid_num.prod())) / (elapsed / args.steps) / 1e9,
-            "note": "neighbour passes are VALU/LDS-issue-bound under the chip's power-limited clock, not HBM-bound (DESIGN.md 5)",
+            "step_achieved": step_bytes / (elapsed / args.steps) / 1e9, "step_alg_bytes": step_bytes,
+            "measured_copy_gbs": copy_gbs,
+            "frac_of_measured_copy": (achieved / copy_gbs) if (achieved and copy_gbs) else None,
+            "step_frac_of_measured_copy": (step_bytes / (elapsed / args.steps) / 1e9 / copy_gbs) if copy_gbs else None,
+            "secondary": secondary,
+            "note": "the neighbour passes are not HBM-bound: per the PMC passes they run at ~2.4 GHz with about half of the VALU issue "
+                    "slots used and 40-50 % of the wave-cycles parked on waits (latency of staging + dependent LDS gathers); "
+                    "`secondary` (from profiles/, not this run) carries those figures; DESIGN.md 5",
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -426,12 +553,27 @@ def run_rank(args, rank, world, local_rank):
         }
     elif rank == 0:
         out["cpu_baseline"] = None
-    if multi and sharded and args.config == "c2" and method == "wcsph" and not args.no_c4:
+    extras_ok = not args.no_extras and args.config == "c2" and method == "wcsph" and not args.presteps
+    if multi and sharded and extras_ok:
         eng.comm_barrier()
         eng.close()
-        out["c4_strong_scaling"] = c4_sharded(args, rank, world, device, lib)
+        if args.scaling == "weak":   # BASELINE.json's metric as written: the 1.23 M scene itself over the N ranks
+            out["c2_strong_scaling"] = sharded_extra(args, rank, world, device, lib, P.c2_scene("wcsph"),
+                                                     "C2 1,231,200-particle dam break, WCSPH", ".c2s")
+        if not args.no_c4:
+            out["c4_strong_scaling"] = sharded_extra(args, rank, world, device, lib, P.c4_scene("wcsph"),
+                                                     "C4 4,000,000-particle dam break, WCSPH", ".c4")
     elif multi:
         eng.comm_barrier()
+    elif extras_ok and rank == 0:
+        eng.close()
+        ex = {}
+        for key, fn in (("c3", extra_c3), ("c5", extra_c5)):
+            try:
+                ex[key] = fn(args, names)
+            except Exception as e:  # noqa: BLE001  (an extra never takes the headline down)
+                ex[key] = {"error": f"{type(e).__name__}: {e}"}
+        out["extras"] = ex
     if multi:
         if rank == 0 and not os.environ.get("SPH_BENCH_RDV"):
             try:

@@ -206,6 +206,12 @@ const char *sph_kernel_name(int kernel_id);
 /* device properties the bench reports: name (<=255 chars), CU count, HBM bytes */
 int sph_device_info(SphHandle *h, char *name256, int *cu_count, int64_t *hbm_bytes);
 
+/* device-to-device copy rate of this GPU, measured now (the second denominator of the bench's HBM roofline next to the
+   8 TB/s spec): `reps` hipMemcpyAsync D2D copies of `bytes` bytes between two scratch buffers on the handle's
+   stream, bracketed by HIP events; *gb_per_s = (read + written bytes) / time = 2 * bytes * reps / t.  The scratch is freed
+   before returning. */
+int sph_measure_copy_rate(SphHandle *h, size_t bytes, int reps, double *gb_per_s);
+
 /* --- multi-GPU: z-slab sharding, one process per GPU, RCCL over xGMI ------------------- */
 /* number of HIP devices this process sees (launchers map local rank -> device without any other runtime) */
 int sph_device_count(void);

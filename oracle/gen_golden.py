@@ -176,6 +176,23 @@ SCENES = {
     "pcisph_late": (late_scene("pcisph", 4e-4), 0.0, 0, [2, 4, 5]),
 }
 
+# Round 3: fixtures at BASELINE configs[0] size (SURVEY 8c asked for 512-8000 particles x 5-100 steps).  Written to
+# tests/golden/big/ with LEAN snapshots (ids, positions, velocities, densities, pressures, materials) plus the whole
+# iteration history the reference's python loops print, one entry per step.  Hours of interpreter time: run them one
+# per process (`python oracle/gen_golden.py c1_wcsph &` ...).
+BIG_SCENES = {
+    # C1 exactly: domain [1,1,1], block [0,0.4]^3 translated by 0.1 -> 20^3 = 8000, WCSPH, dt 4e-4, mu 10, no jitter
+    "c1_wcsph": (dam_break_scene(), 0.0, 0, [1, 5, 10, 20, 40]),
+    # the same block, perturbed and moving, so that lattice symmetries do not hide errors
+    "c1_wcsph_jitter": (dam_break_scene(velocity=(0.2, -0.5, 0.1)), 0.003, 71, [1, 5, 10, 20]),
+    # 16^3 = 4096 particles, solver loops with the reference's own stop tests
+    "dfsph_4k": (dam_break_scene(method="dfsph", end=(0.31, 0.31, 0.31), dt=6e-4, velocity=(0.1, -0.5, 0.0)), 0.003, 72, [1, 2, 5, 10]),
+    "pcisph_4k": (dam_break_scene(method="pcisph", end=(0.31, 0.31, 0.31), dt=4e-4, velocity=(0.1, -0.5, 0.0)), 0.003, 73, [1, 2, 5, 10]),
+}
+LEAN_KEYS = ("ids", "positions", "velocities", "densities", "pressures", "materials", "iter_v", "iter_d", "iter_pci", "iter_cg")
+ITER_PATTERNS = (("iter_v", r"DFSPH - iteration V: (\d+)"), ("iter_d", r"DFSPH - iterations: (\d+)"),
+                 ("iter_pci", r"PCISPH - iteration: (\d+)"), ("iter_cg", r"CG iteration:\s+(\d+)"))
+
 
 def _np(field):
     return field.to_numpy()
@@ -215,7 +232,8 @@ def snapshot(container, solver, method, log):
 
 
 def run_scene(name):
-    cfg, jitter, seed, checkpoints = SCENES[name]
+    big = name in BIG_SCENES
+    cfg, jitter, seed, checkpoints = (BIG_SCENES if big else SCENES)[name]
     method = cfg["Configuration"]["simulationMethod"]
     tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
     json.dump(cfg, tmp)
@@ -273,7 +291,8 @@ def run_scene(name):
     for k, v in init.items():
         out["init_" + k] = v
     for k, v in snapshot(container, solver, method, log).items():
-        out["prep_" + k] = v
+        if not big or k in LEAN_KEYS:
+            out["prep_" + k] = v
     step = 0
     for cp in checkpoints:
         while step < cp:
@@ -304,15 +323,23 @@ def run_scene(name):
                 out[f"late_step"] = np.int64(step)   # the step during which they were inserted (1-based)
                 out[f"late_first_id"] = np.int64(first)
         for k, v in snapshot(container, solver, method, log).items():
-            out[f"s{cp}_" + k] = v
+            if not big or k in LEAN_KEYS:
+                out[f"s{cp}_" + k] = v
         print(f"  {name}: step {step} done ({time.time() - t0:.0f} s)", flush=True)
-    os.makedirs(OUT, exist_ok=True)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    outdir = os.path.join(OUT, "big") if big else OUT
+    if big:
+        # one entry per step (prepare() prints nothing): the loops' iteration counts over the whole run
+        for key, pat in ITER_PATTERNS:
+            m = re.findall(pat, log.getvalue())
+            if m:
+                out["hist_" + key] = np.array([int(v) for v in m], np.int32)
+    os.makedirs(outdir, exist_ok=True)
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
     os.unlink(tmp.name)
     print(f"{name}: n={n} written ({time.time() - t0:.0f} s)")
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(SCENES)
+    names = sys.argv[1:] or list(SCENES)   # the BIG_SCENES only by name
     for nm in names:
         run_scene(nm)

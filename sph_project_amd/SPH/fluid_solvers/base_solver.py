@@ -77,9 +77,28 @@ class BaseSolver:
             rest = np.asarray(obj["restPosition"], dtype=np.float64) - np.asarray(obj["restCenterOfMass"], dtype=np.float64)
             obj["mesh"].vertices = (b.rot @ rest.T).T + b.com
 
+    def _host_acts_inside_a_step(self):
+        """A dynamic rigid body to integrate or an object still waiting for its entryTime: the host has to act in the middle
+        of _step(), where the reference does (WCSPH.py:39-42)."""
+        return bool(self.rigid_solver.bodies) or self.container.objects_pending()
+
+    def _device_steps(self, n):
+        """n whole steps on the device.  WCSPH (and solvers with a fixed iteration count) need nothing back from the device:
+        the steps are only enqueued -- like a Taichi kernel launch, observable behaviour stays synchronous because every
+        read of a field / of stats() drains the stream first.  Solver loops with their own stop tests read a flag back per
+        batch of iterations anyway."""
+        if self.container.METHOD == "wcsph" or self.container.params_dict.get("fixed_iterations", 0) > 0:
+            self.engine.step_async(n)
+        else:
+            self.engine.step(n)
+
     def step(self):
-        """base_solver.py:692."""
-        self._step()
+        """base_solver.py:692.  Without anything for the host to do inside the step it is one enqueue (no step_begin / step_end
+        pair, no host synchronisation: tools/step_overhead.py)."""
+        if self._host_acts_inside_a_step() or self.cfg.get_cfg("exportObj"):
+            self._step()
+        else:
+            self._device_steps(1)
         self.container.total_time += self.dt[None]
         self.rigid_solver.total_time += self.dt[None]
 
@@ -90,11 +109,11 @@ class BaseSolver:
         n = int(n)
         if n <= 0:
             return
-        if self.rigid_solver.bodies or self.container.objects_pending():
+        if self._host_acts_inside_a_step():
             for _ in range(n):
                 self.step()
             return
-        self.engine.step(n)
+        self._device_steps(n)
         for _ in range(n):   # the same float additions as n calls of step()
             self.container.total_time += self.dt[None]
             self.rigid_solver.total_time += self.dt[None]

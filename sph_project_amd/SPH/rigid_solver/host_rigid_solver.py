@@ -9,8 +9,12 @@ velocity back (sph_set_rigid_pose); the device turns the pose into particle posi
 
 Two backends:
   * "native" (default): free rigid bodies under gravity and the fluid wrench, semi-implicit Euler, inertia tensor of the
-    body's own particle set, inelastic contact of the centre of mass with the reference's boundary walls
-    (bullet_solver.py:53-71).  No body-body contacts: that is Bullet's job.  Unit-tested (tests/test_rigid_host.py).
+    body's own particle set, inelastic contact of the body's particle-set EXTENT (its axis-aligned bounds in the current
+    orientation) with the reference's boundary walls (bullet_solver.py:53-71) -- the reference collides the body's mesh
+    with those wall boxes, so a body comes to rest ON the floor, not with its centre of mass in it.  No body-body
+    contacts, no friction, no contact torque: that is Bullet's job, and a scene that needs it diverges from the
+    reference -- the first dynamic body integrated by this backend therefore prints a one-time warning to stderr
+    (silence it with SPH_RIGID_NATIVE_OK=1).  Unit-tested (tests/test_rigid_host.py).
   * "pybullet": the reference's calls (URDF from the mesh file, applyExternalForce / Torque at the base,
     stepSimulation, base pose read-back) when the package is importable.  It is not installed in this image, so this
     backend has never run here; select it with SPH_RIGID_BACKEND=pybullet.
@@ -18,8 +22,11 @@ Static bodies need no backend at all (bullet_solver.py:31-42 makes the same dist
 """
 import math
 import os
+import sys
 
 import numpy as np
+
+_WARNED = [False]
 
 
 def _rotation(angle, axis):
@@ -51,6 +58,7 @@ class _Body:
         self.rot = np.asarray(rot, dtype=np.float64).copy()
         self.vel = np.asarray(vel, dtype=np.float64).copy()
         self.angvel = np.zeros(3)
+        self.points = None   # body-frame particle positions (wall contact uses their extent)
 
 
 class HostRigidSolver:
@@ -68,8 +76,13 @@ class HostRigidSolver:
         if not self.rigid_bodies and not self.rigid_blocks:
             print("No rigid body in the scene, skip bullet solver initialization.")
         elif self.backend == "pybullet":
-            self._bullet = _BulletBackend(container, self.gravity, self.dt)
-        # walls the centre of mass may not cross (bullet_solver.py:57-61)
+            try:
+                self._bullet = _BulletBackend(container, self.gravity, self.dt)
+            except ImportError as e:   # asked for explicitly: never fall back silently
+                raise NotImplementedError("SPH_RIGID_BACKEND=pybullet, but pybullet is not importable") from e
+        elif self.backend != "native":
+            raise ValueError(f"SPH_RIGID_BACKEND={self.backend!r}: expected 'native' or 'pybullet'")
+        # walls no part of a body may cross (bullet_solver.py:57-61)
         eps = container.padding + container.particle_diameter + container.domain_box_thickness
         self.wall_lo = np.asarray(container.domain_start, dtype=np.float64) + eps
         self.wall_hi = np.asarray(container.domain_end, dtype=np.float64) - eps
@@ -98,6 +111,14 @@ class HostRigidSolver:
                 inertia = inertia + np.eye(3) * m_p * c.particle_diameter ** 2
             mass = float(c.rigid_body_masses[oid]) or m_p * len(pts)
             self.bodies[oid] = _Body(oid, mass, inertia, translation, rot, vel)
+            self.bodies[oid].points = pts
+            if self._bullet is None and not _WARNED[0] and not os.environ.get("SPH_RIGID_NATIVE_OK"):
+                _WARNED[0] = True
+                print("WARNING: dynamic rigid body %d is integrated by the built-in 'native' rigid backend: free-body motion under "
+                      "gravity + the fluid wrench, wall contact by the body's axis-aligned extent, NO body-body contacts, friction or "
+                      "contact torque (the reference uses PyBullet, bullet_solver.py).  Trajectories of bodies in contact diverge "
+                      "from the reference; install pybullet and set SPH_RIGID_BACKEND=pybullet for its behaviour "
+                      "(SPH_RIGID_NATIVE_OK=1 silences this)." % oid, file=sys.stderr, flush=True)
             if self._bullet is not None:
                 self._bullet.add(body, mass, translation, angle, vel)
             self._push(self.bodies[oid], com0=np.zeros(3))
@@ -133,12 +154,19 @@ class HostRigidSolver:
         b.rot = _skew_exp(dt * b.angvel) @ b.rot
         u, _, vt = np.linalg.svd(b.rot)   # keep it a rotation
         b.rot = u @ vt
-        for k in range(3):   # inelastic wall contact of the centre of mass
-            if b.com[k] < self.wall_lo[k]:
-                b.com[k] = self.wall_lo[k]
+        # inelastic wall contact of the body's extent: bounds of its particle set in the current orientation, about the
+        # centre of mass (a body without a particle set -- unit tests -- is a point)
+        if b.points is not None and len(b.points):
+            w = b.points @ b.rot.T
+            ext_lo, ext_hi = w.min(0), w.max(0)
+        else:
+            ext_lo = ext_hi = np.zeros(3)
+        for k in range(3):
+            if b.com[k] + ext_lo[k] < self.wall_lo[k] and self.wall_lo[k] - ext_lo[k] <= self.wall_hi[k] - ext_hi[k]:
+                b.com[k] = self.wall_lo[k] - ext_lo[k]
                 b.vel[k] = max(b.vel[k], 0.0)
-            elif b.com[k] > self.wall_hi[k]:
-                b.com[k] = self.wall_hi[k]
+            elif b.com[k] + ext_hi[k] > self.wall_hi[k]:
+                b.com[k] = max(self.wall_hi[k] - ext_hi[k], self.wall_lo[k] - ext_lo[k])
                 b.vel[k] = min(b.vel[k], 0.0)
 
     def get_rigid_body_states(self, container_idx):

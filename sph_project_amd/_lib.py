@@ -100,6 +100,7 @@ _SIGNATURES = [
     ("sph_profile_read", C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("sph_kernel_name", C.c_char_p, [C.c_int]),
     ("sph_device_info", C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    ("sph_measure_copy_rate", C.c_int, [_VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     ("sph_comm_unique_id", C.c_int, [_VP]),
     ("sph_comm_init", C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     ("sph_comm_set_slab", C.c_int, [_VP, C.c_int, C.c_int]),
@@ -300,6 +301,12 @@ class Engine:
 
     def comm_selftest(self, n=4096):
         self._chk(self.lib.sph_comm_selftest(self.h, int(n)), "sph_comm_selftest")
+
+    def measure_copy_rate(self, nbytes=1 << 30, reps=10):
+        """GB/s (read + written) of device-to-device copies on this GPU, measured now."""
+        v = C.c_double()
+        self._chk(self.lib.sph_measure_copy_rate(self.h, int(nbytes), int(reps), C.byref(v)), "sph_measure_copy_rate")
+        return v.value
 
     def device_info(self):
         name = C.create_string_buffer(256)

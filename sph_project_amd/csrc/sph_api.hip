@@ -488,6 +488,32 @@ extern "C" int sph_device_info(SphHandle *h, char *name256, int *cu_count, int64
     return SPH_OK;
 }
 
+// device copy rate (read + write bytes per second) of `reps` D2D copies of `bytes` bytes, HIP events on the handle's stream
+extern "C" int sph_measure_copy_rate(SphHandle *h, size_t bytes, int reps, double *gb_per_s) {
+    if (!h || !gb_per_s || bytes < 4096 || reps < 1) return fail(h, SPH_ERR_INVALID, "measure_copy_rate: bad arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) {
+        if (a) hipFree(a);
+        return fail(h, SPH_ERR_HIP, "measure_copy_rate: cannot allocate 2 x %zu bytes", bytes);
+    }
+    hipStream_t st = h->st.stream;
+    hipEvent_t e0 = get_event(h), e1 = get_event(h);
+    hipError_t e = hipMemsetAsync(a, 1, bytes, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, st);   // warm-up (page tables, clocks)
+    if (e == hipSuccess) e = hipEventRecord(e0, st);
+    for (int k = 0; k < reps && e == hipSuccess; ++k) e = hipMemcpyAsync((k & 1) ? a : b, (k & 1) ? b : a, bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    h->ev_pool.push_back(e0); h->ev_pool.push_back(e1);
+    hipFree(a); hipFree(b);
+    if (e != hipSuccess || !(ms > 0.0f)) return fail(h, SPH_ERR_HIP, "measure_copy_rate: %s", hipGetErrorString(e));
+    *gb_per_s = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+    return SPH_OK;
+}
+
 // ---------------------------------------------------------------------------------- phases
 static int check_async(SphHandle *h) {
     hipError_t e = hipGetLastError();
@@ -538,7 +564,7 @@ static int read_scalars(SphHandle *h) {
     unsigned long long pairs = 0, evals = 0, fb = 0;
     const int bank = h->steps > 0 ? (int)((h->steps - 1) & 1) : 0;   // bank of the last completed step
     for (int k = 0; k < SPH_STAT_SLOTS; ++k) {
-        pairs += h->scal_h->pairs[bank][k] & 0xffffffffull; evals += h->scal_h->pairs[bank][k] >> 32;
+        pairs += h->scal_h->pairs[bank][k]; evals += h->scal_h->evals[bank][k];
         fb += h->scal_h->fallback[bank][k];
     }
     h->last.pair_interactions = (int64_t)pairs;
@@ -573,6 +599,7 @@ extern "C" int sph_prepare(SphHandle *h) {
     rc = method_prepare(h); if (rc) return rc;
     // the passes above counted into statistics bank 0, which the first step uses as well
     HIPCHK(h, hipMemsetAsync(s.scal, 0, sizeof(unsigned long long) * SPH_STAT_SLOTS, s.stream));
+    HIPCHK(h, hipMemsetAsync((char *)s.scal + offsetof(DevScalars, evals), 0, sizeof(unsigned long long) * SPH_STAT_SLOTS, s.stream));
     HIPCHK(h, hipMemsetAsync((char *)s.scal + offsetof(DevScalars, fallback), 0, sizeof(unsigned long long) * SPH_STAT_SLOTS, s.stream));
     rc = check_async(h); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(s.stream));

@@ -55,7 +55,8 @@ struct Consts {
 #define SPH_STAT_SLOTS 2048  // statistics are striped over many words: ~20k same-address atomics per launch cost >200 us
 struct DevScalars {
     // two banks: step k counts into bank k & 1 while its scan kernel clears the other one for step k + 1
-    unsigned long long pairs[2][SPH_STAT_SLOTS];     // accepted pairs of a step (sum over slots)
+    unsigned long long pairs[2][SPH_STAT_SLOTS];     // accepted pairs of a step weighted by the reference passes a walk stands for (sum over slots)
+    unsigned long long evals[2][SPH_STAT_SLOTS];     // accepted pairs as evaluated (one per neighbour walk); separate 64-bit words: no carry between the two tallies
     unsigned long long fallback[2][SPH_STAT_SLOTS];  // neighbour runs that did not fit the LDS tile
     float wrench[2 * SPH_NOBJ * 3];  // rigid_body_forces, rigid_body_torques
     float red[8];                    // reduction results (errors, CG dots)

@@ -258,6 +258,7 @@ k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *
     __shared__ int s_w[SCAN_TPB / 64];
     if (blockIdx.x * SCAN_TPB + threadIdx.x < SPH_STAT_SLOTS) {   // first SPH_STAT_SLOTS / SCAN_TPB workgroups (the grid is never smaller)
         scal->pairs[clear_bank][blockIdx.x * SCAN_TPB + threadIdx.x] = 0ull;
+        scal->evals[clear_bank][blockIdx.x * SCAN_TPB + threadIdx.x] = 0ull;
         scal->fallback[clear_bank][blockIdx.x * SCAN_TPB + threadIdx.x] = 0ull;
     }
     const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
@@ -996,11 +997,14 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         }
         if (P::COUNT_PAIRS) {
             float fp = wave_sum((float)npairs);  // <= 64 * few hundred: exact in f32
-            if ((tid & 63) == 0 && fp > 0.0f)
-                // one atomic carries both tallies of the slot: low word = pairs weighted by the reference passes this walk
-                // stands for (SURVEY 8d metric), high word = pairs as evaluated (a slot sees < 2^32 of either per step)
-                atomicAdd(&scal->pairs[c.stat_bank][(b * (BLOCK / 64) + (tid >> 6)) & (SPH_STAT_SLOTS - 1)],
-                          (unsigned long long)fp * P::PAIR_WEIGHT + ((unsigned long long)fp << 32));
+            if ((tid & 63) == 0 && fp > 0.0f) {
+                // two 64-bit tallies per slot: pairs weighted by the reference passes this walk stands for (SURVEY 8d
+                // metric) and pairs as evaluated.  (They used to share one word, 32 bits each: hundreds of solver
+                // iterations over ~2^28 particles could carry from one into the other.)
+                const int slot = (b * (BLOCK / 64) + (tid >> 6)) & (SPH_STAT_SLOTS - 1);
+                atomicAdd(&scal->pairs[c.stat_bank][slot], (unsigned long long)fp * P::PAIR_WEIGHT);
+                atomicAdd(&scal->evals[c.stat_bank][slot], (unsigned long long)fp);
+            }
         }
     }
     NBR_STAMP(14);

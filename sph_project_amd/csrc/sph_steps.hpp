@@ -166,10 +166,15 @@ static int dfsph_step_begin(SphHandle *h, bool allow_readback) {
     State &s = h->st;
     if (h->sort_dirty) {
         // particles were appended outside a step (plain C-ABI use): the passes below walk the cell lists, so bring them
-        // (and density / alpha, which the reference refreshes after every sort, DFSPH.py:316-318) up to date first
-        ph_neighbor_search(h);
+        // (and density / alpha, which the reference refreshes after every sort, DFSPH.py:316-318) up to date first.
+        // Sharded: the re-sort invalidates the halo slot tables, so it has to be the full slab search (classify, exchange,
+        // sort, tables) -- a COLLECTIVE: every rank of a sharded DFSPH scene that appends between steps gets here together
+        // (the Python containers append mid-step and re-sort in step_end; this is the plain C-ABI path).
+        if (s.slab_active) { int rc = slab_neighbor_search(h); if (rc) return rc; }
+        else ph_neighbor_search(h);
         ph_rigid_volume(h);
         { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha(s); }
+        if (s.slab_active) { int rc = slab_exchange_scalar(h, s.rho.cur()); if (rc) return rc; }   // ghost densities, as in dfsph_step_end
     }
     int rc = run_non_pressure(h); if (rc) return rc;                          // DFSPH.py:299-300
     if (s.slab_active) { rc = slab_exchange_vel(h); if (rc) return rc; }      // the density solver reads v_j of the ghosts

@@ -287,6 +287,46 @@ def test_c5_scaled_buckling_scene(gpu):
     assert abs(solver.stats()["iter_cg"] - it_ref) <= 2 and it_ref >= 5
 
 
+def test_c5_full_size(gpu):
+    """BASELINE configs[4] at its full size: the reference's buckling scene (data/scenes/final_scene3.json without its mesh
+    body): DFSPH + implicit viscosity, 2,171,495 particles of which 106,400 fluid, G = 10,000,000 cells, the solvers' own stop
+    tests.  3 steps against the oracle (drift, CG iteration count of every step within +-2 of the oracle's AND of the number
+    kept from the MI355X runs of rounds 1-3), plus size-independent properties."""
+    cfg = P.c5_scene()
+    container, solver = H.build_product(cfg, fast_math=1)
+    solver.prepare()
+    ref = H.build_oracle(cfg)
+    ref.prepare()
+    e = container.engine
+    n, nf0 = e.particle_num, container.fluid_particle_num[None]
+    assert n == 2171495 and nf0 == 106400 and int(container.grid_num.prod()) == 10_000_000
+    x0 = H.by_id(e.download(L.F_PARTICLE_ID), e.download(L.F_POSITION))
+    KEPT_CG = 42   # profiles/r0{1,2}*_bench_c5.json: 41.5-41.6 CG iterations per step from rest
+    for step in range(1, 4):
+        solver.step()
+        ref.step(1)
+        st = solver.stats()
+        it_ref = int(ref.scalar("last_iter_cg"))
+        print("C5 full size step %d: cg iterations hip %d oracle %d; dfsph iterations density %d divergence %d" % (
+            step, st["iter_cg"], it_ref, st["iter_density"], st["iter_divergence"]))
+        assert abs(st["iter_cg"] - it_ref) <= 2, (step, st["iter_cg"], it_ref)
+        assert abs(st["iter_cg"] - KEPT_CG) <= 4, (step, st["iter_cg"])   # (the first steps from rest wander a little around it)
+    ids = e.download(L.F_PARTICLE_ID)
+    assert np.array_equal(np.sort(ids), np.arange(n))
+    mat = H.by_id(ids, e.download(L.F_MATERIAL))
+    mat_r = H.by_id(H.oracle_ids(ref), ref.field("particle_materials").copy())
+    assert np.array_equal(mat, mat_r)
+    x = H.by_id(ids, e.download(L.F_POSITION))
+    xr = H.by_id(H.oracle_ids(ref), ref.field("particle_positions").copy())
+    assert np.isfinite(x).all()
+    obj = H.by_id(ids, e.download(L.F_OBJECT_ID))
+    box = obj < 0                                   # the sampled domain box: static boundary particles never move
+    assert box.sum() == n - nf0 and np.array_equal(x[box], x0[box])
+    d = H.drift(x, xr, container.dh)
+    print("C5 full size: n=%d fluid now %d drift max %.3e p99 %.3e" % (n, (mat == 1).sum(), d.max(), np.percentile(d, 99)))
+    assert d.max() <= 1e-4, d.max()
+
+
 # --------------------------------------------------------------------------------------------- multi-rank launcher / RCCL
 def _bench(args, env_extra, timeout=600):
     env = dict(os.environ, **env_extra)

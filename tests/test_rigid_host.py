@@ -4,6 +4,7 @@ writer behind exportObj (run_simulation.py:146-150)."""
 import types
 
 import numpy as np
+import pytest
 
 from sph_project_amd import meshgen
 from sph_project_amd.SPH.rigid_solver import host_rigid_solver as R
@@ -112,9 +113,32 @@ def test_walls_late_entry_and_static_bodies():
         s.insert_rigid_object()
     assert 2 in s.bodies
     eps = 0.04 + 0.02 + 0.03
-    assert abs(s.bodies[1].com[1] - eps) < 1e-12 and s.bodies[1].vel[1] == 0.0   # resting on the floor wall
+    # resting ON the floor wall: the lowest particle of the body touches it (bullet_solver.py:53-71 collides the mesh with
+    # the wall boxes), the centre of mass sits the body's half extent above
+    b = s.bodies[1]
+    low = (b.points @ b.rot.T)[:, 1].min()
+    assert low < 0 and abs(b.com[1] + low - eps) < 1e-12 and b.vel[1] == 0.0
     st = s.get_rigid_body_states(1)
     assert set(st) == {"position", "rotation_matrix", "linear_velocity", "angular_velocity"}
+
+
+def test_native_backend_warns_once_and_pybullet_request_is_never_silently_replaced(capsys, monkeypatch):
+    monkeypatch.delenv("SPH_RIGID_NATIVE_OK", raising=False)
+    R._WARNED[0] = False
+    for _ in range(2):
+        s = R.HostRigidSolver(_container([_body()]), dt=1e-3)
+        s.insert_rigid_object()
+    err = capsys.readouterr().err
+    assert err.count("WARNING: dynamic rigid body") == 1 and "NO body-body contacts" in err
+    monkeypatch.setenv("SPH_RIGID_BACKEND", "pybullet")
+    try:
+        import pybullet  # noqa: F401
+    except ImportError:
+        with pytest.raises(NotImplementedError):
+            R.HostRigidSolver(_container([_body()]), dt=1e-3)
+    monkeypatch.setenv("SPH_RIGID_BACKEND", "bogus")
+    with pytest.raises(ValueError):
+        R.HostRigidSolver(_container([_body()]), dt=1e-3)
 
 
 def test_initial_orientation_matches_bullet_euler_convention():
