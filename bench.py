@@ -362,8 +362,7 @@ def run_rank(args, rank, world, local_rank):
     force_slab = world == 1 and bool(os.environ.get("SPH_BENCH_FORCE_SLAB"))
     if world > 1 or force_slab:
         uid = exchange_unique_id(lib, rank) if world > 1 else None
-        if force_slab:   # tuning aid / RCCL self-test: ONE rank in slab mode (no neighbour to talk to)
-            os.environ.setdefault("SPH_COMM_TRANSPORT", "shm")
+        if force_slab:   # tuning aid: ONE rank in slab mode (no neighbour to talk to): the compute-side cost of sharding
             import ctypes
             buf = ctypes.create_string_buffer(128)
             assert lib.sph_comm_unique_id(buf) == 0

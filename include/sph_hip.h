@@ -152,7 +152,10 @@ int sph_append_particles(SphHandle *h, int object_id, int n, const float *pos, c
 /* persistent ids (SPH_F_PARTICLE_ID) of the n particles appended last; default = insertion index on this handle.  A rank
    of a sharded scene passes global insertion indices. */
 int sph_set_appended_ids(SphHandle *h, int n, const int32_t *ids);
-/* object_materials / rigid_body_is_dynamic (base_container.py:150,156; insert_object :237,:317,:332) */
+/* object_materials / rigid_body_is_dynamic (base_container.py:150,156; insert_object :237,:317,:332).  On a sharded scene
+   (sph_comm_set_slab) EVERY rank registers every object, whether or not it holds any of its particles: the halo records of a
+   scene with a dynamic rigid body carry the rest positions (64 instead of 48 bytes); sph_prepare agrees on that over all ranks,
+   and a later mismatch fails the exchange on both sides (record size in the message header). */
 int sph_set_object(SphHandle *h, int object_id, int material, int is_dynamic);
 /* pose written by the host rigid solver (SPH/rigid_solver/bullet_solver.py:158-167); rot9 row-major.  Like the reference's
    rigid_body_* fields it is only READ at the renew_rigid_particle_state point of a step (inside sph_step_end / the second half of
@@ -220,6 +223,12 @@ int sph_comm_unique_id(void *out128);
 /* attach this handle to a communicator of `nranks` processes (RCCL ncclCommInitRank; SPH_COMM_TRANSPORT=shm:
    POSIX shared memory, several ranks may then share one GPU -- test rig) */
 int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id128);
+/* what carries the halo messages of this handle: "rccl", "shm", "ipc-push+rccl", "ipc-push+shm" ("none" before sph_comm_init).
+   Default (SPH_COMM_TRANSPORT unset / "auto"): RCCL for barriers and all-reduces; halo payload by device stores straight into the
+   neighbour's inbox, mapped through hipIpc ("push"), if that can be set up and passes its self-test on EVERY rank, else RCCL
+   ncclSend / ncclRecv.  "ipc": push or fail; "rccl": RCCL only; "shm" / "shm+ipc": shared-memory control plane (several ranks on
+   one GPU, test rig) with host-staged mailboxes / with the push transport. */
+const char *sph_comm_transport(SphHandle *h);
 /* turn the handle into one z-slab: it owns the cell layers [z_lo, z_hi) of the global grid plus one ghost
    layer on each interior side; before any particle is appended */
 int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi);

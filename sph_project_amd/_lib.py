@@ -103,6 +103,7 @@ _SIGNATURES = [
     ("sph_measure_copy_rate", C.c_int, [_VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     ("sph_comm_unique_id", C.c_int, [_VP]),
     ("sph_comm_init", C.c_int, [_VP, C.c_int, C.c_int, _VP]),
+    ("sph_comm_transport", C.c_char_p, [_VP]),
     ("sph_comm_set_slab", C.c_int, [_VP, C.c_int, C.c_int]),
     ("sph_comm_get_slab", C.c_int, [_VP] + [C.POINTER(C.c_int)] * 4),
     ("sph_comm_set_rebalance", C.c_int, [_VP, C.c_int]),
@@ -307,6 +308,9 @@ class Engine:
         v = C.c_double()
         self._chk(self.lib.sph_measure_copy_rate(self.h, int(nbytes), int(reps), C.byref(v)), "sph_measure_copy_rate")
         return v.value
+
+    def comm_transport(self):
+        return self.lib.sph_comm_transport(self.h).decode()
 
     def device_info(self):
         name = C.create_string_buffer(256)

@@ -30,7 +30,8 @@ struct SphHandle {
     const Launch *L = nullptr;
     std::string err;
     int device = 0;
-    int n = 0;            // particle_num
+    int n = 0;            // particle_num (a launch BOUND while n_exact is false: asynchronous slab steps, see slab_settle)
+    bool n_exact = true;
     int n_fluid = 0;      // fluid_particle_num
     int n_nonfluid = 0;
     bool any_rigid_object = false;   // a non-fluid object was registered (slab sharding: its particles may live on another rank)
@@ -164,6 +165,8 @@ extern "C" const char *sph_kernel_name(int k) {
 }
 
 static void slab_comm_destroy(SlabComm &c);
+static int slab_settle(SphHandle *h);
+static inline int slab_settle_if_needed(SphHandle *h) { return h->n_exact ? SPH_OK : slab_settle(h); }
 
 extern "C" void sph_destroy(SphHandle *h) {
     if (!h) return;
@@ -286,6 +289,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     for (int o = 0; o < SPH_NOBJ; ++o) { h->pose_h.rot[o][0] = h->pose_h.rot[o][4] = h->pose_h.rot[o][8] = 1.0f; }
     memset(&h->last, 0, sizeof(h->last));
     s.has_dynamic_rigid = 0; s.has_rigid = 0;
+    s.dyn = nullptr; s.async_counts = 0; memset(&s.push, 0, sizeof(s.push));
     s.slab_active = 0; s.xcur = 0; s.halo_cap = 0; s.z_lo = 0; s.z_hi = s.c.nz_glob; s.has_down = s.has_up = 0;
     s.xidx[0] = s.xidx[1] = nullptr; s.halo_counts = nullptr;
     s.visc_rho_raw = (p.method == SPH_METHOD_WCSPH);
@@ -316,6 +320,7 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
     if (n < 0 || object_id < -1 || object_id >= SPH_MAX_OBJECTS) return fail(h, SPH_ERR_INVALID, "append: bad object id / count");
     if (n == 0) return SPH_OK;
     if (!pos || !vel || !density || !material || !is_dynamic) return fail(h, SPH_ERR_INVALID, "append: null array");
+    { int rc = slab_settle_if_needed(h); if (rc) return rc; }
     if (h->n + n > h->st.cap) return fail(h, SPH_ERR_CAPACITY, "append: %d + %d exceeds particle_max_num %d", h->n, n, h->st.cap);
     HIPCHK(h, hipSetDevice(h->device));
     State &s = h->st;
@@ -366,6 +371,7 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
 // persistent ids of the n particles appended last (a rank of a sharded scene numbers its particles with their global
 // insertion indices, so that ids mean the same thing on every rank and in a single-GPU run)
 extern "C" int sph_set_appended_ids(SphHandle *h, int n, const int32_t *ids) {
+    if (h) { int rc = slab_settle_if_needed(h); if (rc) return rc; }
     if (!h || !ids || n < 0 || n > h->n) return fail(h, SPH_ERR_INVALID, "set_appended_ids: bad arguments");
     if (n == 0) return SPH_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -559,6 +565,7 @@ static void step_begin(SphHandle *h) {
 #include "sph_steps.hpp"
 
 static int read_scalars(SphHandle *h) {
+    { int rc = slab_settle_if_needed(h); if (rc) return rc; }
     HIPCHK(h, hipMemcpyAsync(h->scal_h, h->st.scal, sizeof(DevScalars), hipMemcpyDeviceToHost, h->st.stream));
     HIPCHK(h, hipStreamSynchronize(h->st.stream));
     unsigned long long pairs = 0, evals = 0, fb = 0;
@@ -588,6 +595,11 @@ extern "C" int sph_prepare(SphHandle *h) {
         rc = sph_comm_allreduce(h, n_own, 2, 0); if (rc) return rc;
         h->comm_n_global = (long long)n_own[0];
         h->comm_nfluid_global = (long long)n_own[1];
+        // halo records carry the rest position (64 instead of 48 B) once the scene has a dynamic rigid body: all ranks agree
+        // on that here, whoever was told about the body (later mismatches are caught by the record size in the message header)
+        double dyn_rigid[1] = {s.orig.cur() ? 1.0 : 0.0};
+        rc = sph_comm_allreduce(h, dyn_rigid, 1, 1); if (rc) return rc;
+        if (dyn_rigid[0] > 0.0 && !s.orig.cur()) { rc = ensure_orig(h); if (rc) return rc; }
         rc = slab_neighbor_search(h); if (rc) return rc;
     }
     else ph_neighbor_search(h);
@@ -629,6 +641,7 @@ static int step_second_half(SphHandle *h, bool allow_readback) {
     if (!h->in_step) return fail(h, SPH_ERR_INVALID, "sph_step_end without sph_step_begin");
     State &s = h->st;
     h->in_step = false;
+    if (h->pose_dirty || h->fresh_state || h->prm.method != SPH_METHOD_WCSPH) { int rc = slab_settle_if_needed(h); if (rc) return rc; }
     if (h->pose_dirty) { ProfScope p(h, SPH_K_MISC); h->L->renew_rigid(s); h->pose_dirty = false; }
     if (h->n > h->n_mark) {
         ProfScope p(h, SPH_K_MISC);
@@ -661,6 +674,8 @@ extern "C" int sph_step_begin(SphHandle *h) {
     HIPCHK(h, hipSetDevice(h->device));
     refresh_counts(h);
     int rc = step_first_half(h, true); if (rc) return rc;
+    rc = slab_settle_if_needed(h); if (rc) return rc;   // the host may append next: it needs the count
+    h->n_mark = h->n;
     return check_async(h);
 }
 
@@ -687,6 +702,7 @@ extern "C" int sph_step_async(SphHandle *h, int nsteps) {
 extern "C" int sph_synchronize(SphHandle *h) {
     if (!h) return SPH_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->n_exact) return slab_settle(h);   // drains the stream (bounded) and brings the counts of the asynchronous steps back
     HIPCHK(h, hipStreamSynchronize(h->st.stream));
     return SPH_OK;
 }
@@ -704,6 +720,7 @@ extern "C" int sph_step(SphHandle *h, int nsteps) {
 extern "C" int sph_run_phase(SphHandle *h, int phase) {
     if (!h) return SPH_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc = slab_settle_if_needed(h); if (rc) return rc; }
     refresh_counts(h);
     State &s = h->st;
     switch (phase) {
@@ -720,7 +737,11 @@ extern "C" int sph_run_phase(SphHandle *h, int phase) {
 }
 
 // ---------------------------------------------------------------------------------- state access
-extern "C" int sph_particle_num(SphHandle *h) { return h ? h->n : SPH_ERR_INVALID; }
+extern "C" int sph_particle_num(SphHandle *h) {
+    if (!h) return SPH_ERR_INVALID;
+    if (!h->n_exact) { hipSetDevice(h->device); const int rc = slab_settle(h); if (rc) return rc; }
+    return h->n;
+}
 extern "C" int sph_fluid_particle_num(SphHandle *h) { return h ? h->n_fluid : SPH_ERR_INVALID; }
 
 extern "C" int sph_get_stats(SphHandle *h, SphStats *out) {
@@ -766,6 +787,7 @@ static const float *scalar_field(SphHandle *h, int field) {
 extern "C" int sph_download(SphHandle *h, int field, void *dst, size_t bytes) {
     if (!h || !dst) return SPH_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc = slab_settle_if_needed(h); if (rc) return rc; }
     State &s = h->st;
     const size_t n = (size_t)h->n;
     HIPCHK(h, hipStreamSynchronize(s.stream));
@@ -835,6 +857,7 @@ extern "C" int sph_download(SphHandle *h, int field, void *dst, size_t bytes) {
 extern "C" int sph_upload(SphHandle *h, int field, const void *src, size_t bytes) {
     if (!h || !src) return SPH_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    { int rc = slab_settle_if_needed(h); if (rc) return rc; }
     State &s = h->st;
     const size_t n = (size_t)h->n;
     HIPCHK(h, hipStreamSynchronize(s.stream));

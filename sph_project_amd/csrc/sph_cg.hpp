@@ -244,7 +244,7 @@ k_cg_ap_combine(const Consts c, const int *meta, int all_fluid, const float4 *pa
     if (blk < 0) return;
     const int i = blk * 256 + threadIdx.x;
     float dot = 0.f;
-    if (i < c.n && is_fluid(meta, i, all_fluid)) {
+    if (i < live_n(c) && is_fluid(meta, i, all_fluid)) {
         const float4 a0 = part[i], a1 = part[(size_t)stride + i], a2 = part[2 * (size_t)stride + i], pp = p[i];
         float x = ((a0.x + a1.x) + a2.x) * c.dt, y = ((a0.y + a1.y) + a2.y) * c.dt, z = ((a0.z + a1.z) + a2.z) * c.dt;
         x = fdiv(x, c.rho0); y = fdiv(y, c.rho0); z = fdiv(z, c.rho0);

@@ -13,6 +13,9 @@
         if (r_ != ncclSuccess) return fail((h), SPH_ERR_COMM, "%s failed: %s", #call, ncclGetErrorString(r_)); \
     } while (0)
 
+static int push_setup(SphHandle *h);
+static int slab_settle(SphHandle *h);
+
 static inline ShmMailbox *shm_mbox(SlabComm &c, int writer, int dir) {
     char *base = (char *)c.shm_base + sizeof(ShmHeader);
     const size_t stride = sizeof(ShmMailbox) + c.mbox_cap;
@@ -20,6 +23,10 @@ static inline ShmMailbox *shm_mbox(SlabComm &c, int writer, int dir) {
 }
 
 static void slab_comm_destroy(SlabComm &c) {
+    for (int side = 0; side < 2; ++side) if (c.ipc_mapped[side]) hipIpcCloseMemHandle(c.ipc_mapped[side]);
+    if (c.inbox_alloc) hipFree(c.inbox_alloc);
+    if (c.bad_dev) hipFree(c.bad_dev);
+    if (c.n_stage) hipHostFree(c.n_stage);
     if (c.kind == 1 && c.nccl) ncclCommDestroy((ncclComm_t)c.nccl);
     if (c.kind == 2 && c.shm_base) {
         ShmHeader *hd = (ShmHeader *)c.shm_base;
@@ -41,7 +48,7 @@ extern "C" int sph_comm_unique_id(void *out128) {
     if (!out128) return SPH_ERR_INVALID;
     memset(out128, 0, 128);
     const char *t = getenv("SPH_COMM_TRANSPORT");
-    if (!(t && !strcmp(t, "shm"))) {
+    if (!(t && !strncmp(t, "shm", 3))) {
         ncclUniqueId id;
         if (ncclGetUniqueId(&id) == ncclSuccess) { memcpy(out128, &id, sizeof(id) < 128 ? sizeof(id) : 128); return SPH_OK; }
     }
@@ -112,16 +119,25 @@ extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id1
     size_t mbox_records = face * 24 * 2;
     if (mbox_records > cap) mbox_records = cap;
     if (mbox_records < 1024) mbox_records = 1024;
-    HIPCHK(h, hipMalloc((void **)&c.cnt_dev, 4 * sizeof(int)));
-    HIPCHK(h, hipHostMalloc((void **)&c.cnt_host, 8 * sizeof(int), hipHostMallocDefault));
+    HIPCHK(h, hipMalloc((void **)&c.cnt_dev, 8 * sizeof(int)));
+    HIPCHK(h, hipHostMalloc((void **)&c.cnt_host, 12 * sizeof(int), hipHostMallocDefault));
     HIPCHK(h, hipMalloc((void **)&c.red_dev, SHM_RED_MAX * sizeof(double)));
     HIPCHK(h, hipHostMalloc((void **)&c.red_host, SHM_RED_MAX * sizeof(double), hipHostMallocDefault));
+    // SPH_COMM_TRANSPORT: unset / "auto" = RCCL control plane, push data plane if it can be set up on every rank, else RCCL
+    // send/recv; "ipc" = the same, but a push transport that cannot be set up is an error; "rccl" = RCCL only; "shm" = shared-
+    // memory control plane + host-staged mailboxes; "shm+ipc" = shared-memory control plane + push data plane (several ranks
+    // on one GPU: the test rig of the push transport)
     const char *t = getenv("SPH_COMM_TRANSPORT");
-    if (t && !strcmp(t, "shm")) {
+    if (t && strcmp(t, "auto") && strcmp(t, "ipc") && strcmp(t, "rccl") && strcmp(t, "shm") && strcmp(t, "shm+ipc"))
+        return fail(h, SPH_ERR_INVALID, "SPH_COMM_TRANSPORT=%s: expected auto, ipc, rccl, shm or shm+ipc", t);
+    c.push_wanted = (!t || !strcmp(t, "auto")) ? 1 : ((!strcmp(t, "ipc") || !strcmp(t, "shm+ipc")) ? 2 : 0);
+    if (const char *to = getenv("SPH_COMM_TIMEOUT_S")) { const double v = atof(to); if (v > 0.0) c.timeout_s = v; }
+    if (t && !strncmp(t, "shm", 3)) {
         if (nranks > SHM_MAX_RANKS) return fail(h, SPH_ERR_INVALID, "shm transport: at most %d ranks", SHM_MAX_RANKS);
         int rc = shm_attach(h, c, mbox_records * 64);
         if (rc) return rc;
         c.kind = 2;
+        snprintf(c.transport, sizeof(c.transport), "shm");
     } else {
         ncclUniqueId id;
         memset(&id, 0, sizeof(id));
@@ -130,8 +146,43 @@ extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id1
         NCCLCHK(h, ncclCommInitRank(&comm, nranks, id, rank));
         c.nccl = comm;
         c.kind = 1;
+        snprintf(c.transport, sizeof(c.transport), "rccl");
     }
     return SPH_OK;
+}
+
+extern "C" const char *sph_comm_transport(SphHandle *h) { return (h && h->comm.kind) ? h->comm.transport : "none"; }
+
+// Host waits with an end: a neighbour that died (or never sent) must not hang this process for ever.  Polls the stream;
+// on time-out the RCCL communicator is aborted (its kernels may be what blocks the stream) and the call fails.
+static int stream_sync_bounded(SphHandle *h, const char *what) {
+    State &s = h->st;
+    struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(s.stream);
+        if (e == hipSuccess) return SPH_OK;
+        if (e != hipErrorNotReady) return fail(h, SPH_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+        if (spins > 2000) usleep(spins > 20000 ? 200 : 20);   // the first ~2000 polls spin: a step is a fraction of a millisecond
+        if ((spins & 255) == 255) {
+            struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > h->comm.timeout_s) {
+                if (h->comm.kind == 1 && h->comm.nccl) ncclCommAbort((ncclComm_t)h->comm.nccl), h->comm.nccl = nullptr, h->comm.kind = 0;
+                return fail(h, SPH_ERR_COMM, "%s: no answer within %.0f s (a neighbour rank is gone or stuck)", what, h->comm.timeout_s);
+            }
+        }
+    }
+}
+
+static const char *slab_status_text(int st) {
+    static thread_local char buf[256];
+    snprintf(buf, sizeof(buf), "%s%s%s%s%s%s",
+             (st & SLAB_ST_SEND_OVERFLOW) ? "a halo message of this rank exceeds the message capacity; " : "",
+             (st & SLAB_ST_PEER) ? "a neighbour rank reported a failure; " : "",
+             (st & SLAB_ST_STRIDE) ? "halo record sizes differ between neighbours (a dynamic rigid body must be registered with sph_set_object on EVERY rank); " : "",
+             (st & SLAB_ST_CAPACITY) ? "own + received particles exceed particle_max_num; " : "",
+             (st & SLAB_ST_TIMEOUT) ? "a neighbour's halo message did not arrive in time; " : "",
+             (st & SLAB_ST_BOUND) ? "the particle count outran the launch bound of an asynchronous step (SPH_SLAB_ASYNC=0 runs exact launches); " : "");
+    return buf;
 }
 
 extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
@@ -141,7 +192,10 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
     if (z_lo < 0 || z_hi > c.nz_glob || z_hi - z_lo < 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: a slab needs >= 2 cell layers inside the grid");
     if (h->n > 0) return fail(h, SPH_ERR_INVALID, "comm_set_slab: set the slab before particles are appended");
     HIPCHK(h, hipSetDevice(h->device));
+    s.has_down = h->comm.rank > 0; s.has_up = h->comm.rank < h->comm.nranks - 1;
+    bool first = false;
     if (!h->comm.slab_ready) {
+        first = true;
         const size_t cap = (size_t)s.halo_cap;
         for (int k = 0; k < 2; ++k) {
             int rc = dalloc(h, &s.xidx[k], (size_t)s.cap); if (rc) return rc;
@@ -150,6 +204,9 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
         }
         for (int k = 0; k < 8; ++k) { int rc = dalloc(h, &s.halo_tab[k], cap); if (rc) return rc; }
         { int rc = dalloc(h, &s.halo_counts, 4); if (rc) return rc; }
+        { int rc = dalloc(h, &s.dyn, 1); if (rc) return rc; }
+        HIPCHK(h, hipMalloc((void **)&h->comm.bad_dev, sizeof(int)));
+        HIPCHK(h, hipHostMalloc((void **)&h->comm.n_stage, 16 * sizeof(int), hipHostMallocDefault));
         s.xcur = 0;
         HIPCHK(h, hipMalloc((void **)&h->comm.hist_dev, sizeof(int) * (size_t)(c.nz_glob + h->comm.nranks)));
         HIPCHK(h, hipHostMalloc((void **)&h->comm.hist_host, sizeof(int) * (size_t)(c.nz_glob + h->comm.nranks), hipHostMallocDefault));
@@ -158,7 +215,6 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
         h->comm.slab_ready = 1;
     }
     s.slab_active = 1;
-    s.has_down = h->comm.rank > 0; s.has_up = h->comm.rank < h->comm.nranks - 1;
     s.z_lo = z_lo; s.z_hi = z_hi;
     // the cell lists cover the own layers plus one ghost layer per interior side only: G, and with it the histogram, the
     // scan and the cell windows, shrink from the global grid to the slab (weak scaling would otherwise scan N times as
@@ -167,6 +223,7 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
     const int top = z_hi < c.nz_glob ? z_hi + 1 : c.nz_glob;
     c.nz = top - c.cz_off;
     c.G = c.nx * c.ny * c.nz;
+    if (first && h->comm.push_wanted) { int rc = push_setup(h); if (rc) return rc; }
     return SPH_OK;
 }
 
@@ -176,6 +233,7 @@ extern "C" int sph_comm_get_slab(SphHandle *h, int *z_lo, int *z_hi, int *n_owne
     if (z_lo) *z_lo = h->st.z_lo;
     if (z_hi) *z_hi = h->st.z_hi;
     if (n_owned || n_ghost) {
+        { int rc = slab_settle(h); if (rc) return rc; }
         refresh_counts(h);
         h->L->count_ghosts(h->st, h->comm.cnt_dev + 3);   // 4 bytes come back, not the whole meta array
         int g = 0;
@@ -193,7 +251,7 @@ static int shm_wait(std::atomic<uint64_t> &a, uint64_t want, SphHandle *h, const
     for (unsigned spins = 0; a.load(std::memory_order_acquire) < want; ++spins) {
         if ((spins & 1023) == 1023) {
             struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
-            if (t1.tv_sec - t0.tv_sec > 60) return fail(h, SPH_ERR_COMM, "shm transport: timed out waiting for %s", what);
+            if ((double)(t1.tv_sec - t0.tv_sec) > h->comm.timeout_s) return fail(h, SPH_ERR_COMM, "shm transport: timed out waiting for %s", what);
             usleep(50);
         }
     }
@@ -213,7 +271,7 @@ static int shm_barrier(SphHandle *h, SlabComm &c) {
     for (unsigned spins = 0; hd->bar_gen.load(std::memory_order_acquire) == gen; ++spins) {
         if ((spins & 255) == 255) {
             struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
-            if (t1.tv_sec - t0.tv_sec > 120) return fail(h, SPH_ERR_COMM, "shm transport: barrier timed out");
+            if ((double)(t1.tv_sec - t0.tv_sec) > 2.0 * c.timeout_s) return fail(h, SPH_ERR_COMM, "shm transport: barrier timed out");
             usleep(20);
         }
     }
@@ -294,6 +352,16 @@ extern "C" int sph_comm_selftest(SphHandle *h, int n) {
     }
     for (int k = 0; k < n; ++k)
         if (dst[k] != (float)(from * 1000 + (k % 997))) return fail(h, SPH_ERR_COMM, "comm_selftest: word %d from rank %d is %g", k, from, (double)dst[k]);
+    if (s.push.on && c.nranks > 1) {   // the push transport through its own kernels: pattern into both neighbours' inboxes, wait, check
+        const int m = std::min(n, (int)(s.push.fld_bytes / sizeof(float)));
+        HIPCHK(h, hipMemsetAsync(c.bad_dev, 0, sizeof(int), s.stream));
+        h->L->halo_selftest(s, m, c.rank, c.rank - 1, c.rank + 1, c.bad_dev);
+        int bad = -1, st = 0;
+        HIPCHK(h, hipMemcpyAsync(&bad, c.bad_dev, sizeof(int), hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(h, hipMemcpyAsync(&st, &s.dyn->status, sizeof(int), hipMemcpyDeviceToHost, s.stream));
+        int rc = stream_sync_bounded(h, "comm_selftest (push transport)"); if (rc) return rc;
+        if (bad || st) return fail(h, SPH_ERR_COMM, "comm_selftest: push transport delivered %d wrong words (status %d)", bad, st);
+    }
     double v[2] = {(double)(c.rank + 1), 1.0};
     int rc = sph_comm_allreduce(h, v, 2, 0); if (rc) return rc;
     if (v[0] != 0.5 * c.nranks * (c.nranks + 1) || v[1] != (double)c.nranks) return fail(h, SPH_ERR_COMM, "comm_selftest: all-reduce gave %g, %g", v[0], v[1]);
@@ -353,6 +421,125 @@ static int comm_exchange(SphHandle *h, const void *send[2], const size_t bytes_s
         if (bytes_recv[side]) NCCLCHK(h, ncclRecv(recv[side], bytes_recv[side], ncclChar, peer[side], comm, s.stream));
     }
     NCCLCHK(h, ncclGroupEnd());
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- push transport set-up
+// Every rank allocates its inbox, hands an IPC handle of it to both neighbours (one small message each through the control
+// plane's neighbour transport), maps theirs, and the ranks then run a self-test through the very kernels the halo exchange
+// uses (payload stores into the neighbour's inbox, system-scope fence, message number, bounded wait, check).  Whether the
+// push transport is used is agreed by all ranks (all-reduce of the per-rank verdicts): all or none.
+static int push_teardown(SphHandle *h) {
+    State &s = h->st; SlabComm &c = h->comm;
+    for (int side = 0; side < 2; ++side) { if (c.ipc_mapped[side]) hipIpcCloseMemHandle(c.ipc_mapped[side]); c.ipc_mapped[side] = nullptr; s.push.peer[side] = nullptr; }
+    if (c.inbox_alloc) { hipFree(c.inbox_alloc); c.inbox_alloc = nullptr; }
+    if (s.push.mirror) { hipHostFree(s.push.mirror); s.push.mirror = nullptr; }
+    if (s.push.ticket) { hipFree(s.push.ticket); s.push.ticket = nullptr; }
+    s.push.on = 0; s.push.inbox = nullptr;
+    (void)hipGetLastError();
+    return SPH_OK;
+}
+
+static int push_setup(SphHandle *h) {
+    State &s = h->st; SlabComm &c = h->comm;
+    memset(&s.push, 0, sizeof(s.push));
+    s.push.rec_bytes = (size_t)s.halo_cap * 64;        // records of 64 B (with the rest position of a dynamic rigid body)
+    s.push.fld_bytes = (size_t)s.halo_cap * 2 * 16;    // n_send + n_recv <= 2 halo_cap records of <= 16 B
+    s.push.timeout_ticks = (long long)(0.5 * c.timeout_s * 1.0e8);   // 100 MHz wall clock; the device gives up before the host does
+    const size_t bytes = 2 * sizeof(HaloCtl) + 4 * s.push.rec_bytes + 4 * s.push.fld_bytes;
+    int ok = 1;
+    char why[160] = "";
+    void *inbox = nullptr;
+    // memory the other device writes and this one polls: uncached / fine-grained where the runtime offers it (what RCCL uses
+    // for its own flags), plain device memory otherwise (enough between two ranks of ONE device)
+    hipError_t e = hipExtMallocWithFlags(&inbox, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&inbox, bytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&inbox, bytes); }
+    if (e != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "inbox allocation of %zu bytes: %s", bytes, hipGetErrorString(e)); (void)hipGetLastError(); }
+    hipIpcMemHandle_t mine;
+    memset(&mine, 0, sizeof(mine));
+    if (ok) {
+        c.inbox_alloc = inbox; s.push.inbox = (char *)inbox;
+        e = hipMemset(inbox, 0, 2 * sizeof(HaloCtl));
+        if (e == hipSuccess && c.nranks > 1) e = hipIpcGetMemHandle(&mine, inbox);
+        if (e != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "hipIpcGetMemHandle: %s", hipGetErrorString(e)); (void)hipGetLastError(); }
+    }
+    if (hipHostMalloc((void **)&s.push.mirror, sizeof(SlabDyn), hipHostMallocDefault) != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "pinned mirror"); (void)hipGetLastError(); }
+    else memset(s.push.mirror, 0, sizeof(SlabDyn));
+    if (hipMalloc((void **)&s.push.ticket, sizeof(int)) != hipSuccess || hipMemset(s.push.ticket, 0, sizeof(int)) != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "ticket"); (void)hipGetLastError(); }
+    // handles to the neighbours (even a rank that failed so far takes part: the exchange is collective)
+    struct Hello { unsigned magic; int ok; int rank; int pad; hipIpcMemHandle_t handle; } hello_out, hello_in[2];
+    static_assert(sizeof(Hello) <= 256, "hello message");
+    hello_out.magic = 0x53504831u; hello_out.ok = ok; hello_out.rank = c.rank; hello_out.pad = 0; hello_out.handle = mine;
+    memset(hello_in, 0, sizeof(hello_in));
+    if (c.nranks > 1) {
+        for (int side = 0; side < 2; ++side) HIPCHK(h, hipMemcpy(s.sendbuf[side], &hello_out, sizeof(Hello), hipMemcpyHostToDevice));
+        const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
+        void *recv[2] = {s.recvbuf[0], s.recvbuf[1]};
+        const size_t bs[2] = {sizeof(Hello), sizeof(Hello)};
+        size_t br[2] = {sizeof(Hello), sizeof(Hello)};
+        int rc = comm_exchange(h, send, bs, recv, br, true); if (rc) return rc;
+        HIPCHK(h, hipStreamSynchronize(s.stream));
+        const int peer[2] = {c.rank - 1, c.rank + 1};
+        for (int side = 0; side < 2; ++side) {
+            if (!(side == 0 ? s.has_down : s.has_up)) continue;
+            HIPCHK(h, hipMemcpy(&hello_in[side], s.recvbuf[side], sizeof(Hello), hipMemcpyDeviceToHost));
+            if (hello_in[side].magic != 0x53504831u || hello_in[side].rank != peer[side]) { ok = 0; snprintf(why, sizeof(why), "bad hello from rank %d", peer[side]); continue; }
+            if (!hello_in[side].ok || !ok) { ok = 0; continue; }
+            void *mapped = nullptr;
+            e = hipIpcOpenMemHandle(&mapped, hello_in[side].handle, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "hipIpcOpenMemHandle(rank %d): %s", peer[side], hipGetErrorString(e)); (void)hipGetLastError(); continue; }
+            c.ipc_mapped[side] = mapped; s.push.peer[side] = (char *)mapped;
+        }
+    }
+    // self-test through the real kernels; a rank that is not ok so far still answers its neighbours' waits as far as it can
+    double verdict[1] = {(double)ok};
+    { int rc = sph_comm_allreduce(h, verdict, 1, 2); if (rc) return rc; }   // min over ranks
+    if (verdict[0] >= 1.0 && c.nranks > 1) {
+        s.push.on = 1;
+        const int n = 1 << 16;
+        HIPCHK(h, hipMemsetAsync(c.bad_dev, 0, sizeof(int), s.stream));
+        h->L->halo_selftest(s, n, c.rank, c.rank - 1, c.rank + 1, c.bad_dev);
+        int bad = -1, st = 0;
+        hipError_t e2 = hipMemcpyAsync(&bad, c.bad_dev, sizeof(int), hipMemcpyDeviceToHost, s.stream);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&st, &s.dyn->status, sizeof(int), hipMemcpyDeviceToHost, s.stream);
+        int rc = e2 == hipSuccess ? stream_sync_bounded(h, "push transport self-test") : SPH_ERR_HIP;
+        if (rc || bad != 0 || st != 0) { ok = 0; snprintf(why, sizeof(why), "self-test: %d wrong words, status %d", bad, st); }
+        HIPCHK(h, hipMemsetAsync(&s.dyn->status, 0, sizeof(int), s.stream));
+        verdict[0] = (double)ok;
+        rc = sph_comm_allreduce(h, verdict, 1, 2); if (rc) return rc;
+    }
+    if (verdict[0] < 1.0) {
+        push_teardown(h);
+        if (c.push_wanted == 2) return fail(h, SPH_ERR_COMM, "push transport (SPH_COMM_TRANSPORT=ipc) cannot be set up%s%s", why[0] ? ": " : " (another rank failed)", why);
+        fprintf(stderr, "[libsph_hip] rank %d: push transport not available%s%s -- halo exchange through %s\n", c.rank, why[0] ? ": " : " on another rank", why, c.transport);
+        return SPH_OK;
+    }
+    s.push.on = 1;
+    const char *as = getenv("SPH_SLAB_ASYNC");
+    c.async_enabled = !(as && atoi(as) == 0);
+    char base[24];
+    snprintf(base, sizeof(base), "%s", c.transport);
+    snprintf(c.transport, sizeof(c.transport), "ipc-push+%s", base);
+    return SPH_OK;
+}
+
+// Asynchronous steps leave the host with launch bounds instead of counts.  Before anything on the host needs the exact
+// particle count (download, append, statistics, a solver that launches exact grids) the stream is drained -- bounded -- and
+// the counts of the last step come back from the pinned mirror, together with the sticky status word.
+static int slab_settle(SphHandle *h) {
+    State &s = h->st; SlabComm &c = h->comm;
+    if (h->n_exact) return SPH_OK;
+    int rc = stream_sync_bounded(h, "waiting for the asynchronous slab steps"); if (rc) return rc;
+    const SlabDyn m = *(const SlabDyn *)s.push.mirror;
+    h->n = m.n_live; h->n_exact = true;
+    for (int side = 0; side < 2; ++side) { c.n_send[side] = m.n_send[side]; c.n_recv[side] = m.n_recv[side]; }
+    c.est_recv = m.n_recv[0] + m.n_recv[1];
+    s.halo_longest = m.longest;
+    s.async_counts = 0; s.c.n_dev = nullptr;
+    s.perm_n = s.list_n = -1;   // headers / lists were built for the launch bound
+    refresh_counts(h);
+    if (m.status) return fail(h, SPH_ERR_COMM, "sharded step failed (status %d): %s", m.status, slab_status_text(m.status));
     return SPH_OK;
 }
 
@@ -441,44 +628,136 @@ extern "C" int sph_comm_set_rebalance(SphHandle *h, int every_steps) {
     return SPH_OK;
 }
 
+// ---- step message over the push transport (sph_halo.hpp).  Two flavours:
+//   exact : the counts come back to the host once per step (one bounded wait on the stream), every launch is sized exactly --
+//           what the iterative solvers use (their loops read flags back anyway);
+//   async : WCSPH.  Nothing comes back.  The halo kernels keep the counts in device memory (SlabDyn), every kernel of the step
+//           reads the particle count from there, and the host sizes its launches from BOUNDS: the last counts it has seen in
+//           the pinned mirror (written by the wait kernel, a step or a few behind) plus a margin.  The wait kernel checks the
+//           bounds against the real counts (SLAB_ST_BOUND, sticky, reported at the next settle); the host never runs more than
+//           SLAB_MAX_LAG steps ahead of the mirror (back-pressure, not a drain).
+#define SLAB_MAX_LAG 3
+static int slab_neighbor_search_push(SphHandle *h, bool async) {
+    State &s = h->st;
+    SlabComm &c = h->comm;
+    if (!async) {
+        int rc = slab_settle(h); if (rc) return rc;
+        s.async_counts = 0; s.c.n_dev = nullptr;
+        { ProfScope p(h, SPH_K_HALO);
+          h->L->halo_classify_pack(s, h->n);
+          h->L->halo_wait_rec(s, h->n, 0, 0); }
+        rc = stream_sync_bounded(h, "halo exchange (step message)"); if (rc) return rc;
+        const SlabDyn m = *(const SlabDyn *)s.push.mirror;
+        if (m.status) return fail(h, SPH_ERR_COMM, "halo exchange failed (status %d): %s", m.status, slab_status_text(m.status));
+        for (int side = 0; side < 2; ++side) { c.n_send[side] = m.n_send[side]; c.n_recv[side] = m.n_recv[side]; }
+        c.est_recv = m.n_recv[0] + m.n_recv[1];
+        { ProfScope p(h, SPH_K_HALO); h->L->halo_unpack2(s, std::max(c.est_recv, m.longest)); }
+        h->n = m.n_app;
+        refresh_counts(h);
+        ph_neighbor_search(h);
+        h->n = m.n_live;
+        refresh_counts(h);
+        s.halo_longest = m.longest;
+        { ProfScope p(h, SPH_K_HALO); h->L->halo_build_tables(s); }
+        return SPH_OK;
+    }
+    long long live_known, app_known;
+    int lag = 0, grid_n;
+    if (h->n_exact) {   // first asynchronous step after an exact count: hand it to the device
+        c.n_stage[0] = h->n;
+        HIPCHK(h, hipMemcpyAsync(&s.dyn->n_live, c.n_stage, sizeof(int), hipMemcpyHostToDevice, s.stream));
+        live_known = h->n; app_known = (long long)h->n + c.est_recv; grid_n = h->n;
+        s.push.mirror->seq = s.push.rec_seq; s.push.mirror->n_live = h->n; s.push.mirror->n_app = (int)app_known; s.push.mirror->status = 0;
+    } else {
+        volatile SlabDyn *mv = s.push.mirror;
+        struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned spins = 0;; ++spins) {
+            const unsigned q0 = mv->seq;
+            live_known = mv->n_live; app_known = mv->n_app;
+            const int st = mv->status;
+            __sync_synchronize();
+            if (mv->seq != q0) continue;   // torn read: the wait kernel was writing
+            if (st) return slab_settle(h);  // drains the stream and reports
+            lag = (int)(s.push.rec_seq - q0);
+            if (lag <= SLAB_MAX_LAG) break;
+            if ((spins & 1023) == 1023) {
+                struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((double)(t1.tv_sec - t0.tv_sec) > c.timeout_s) return fail(h, SPH_ERR_COMM, "asynchronous slab steps: the device fell %d steps behind for %.0f s", lag, c.timeout_s);
+            }
+        }
+        grid_n = c.bound_live;
+    }
+    const long long margin = std::max<long long>(16384, live_known / 16) + (long long)lag * std::max<long long>(4096, live_known / 64);
+    const int bound_app = (int)std::min<long long>(s.cap, app_known + margin);
+    const int bound_live = (int)std::min<long long>(s.cap, live_known + margin);
+    h->n_exact = false;
+    s.async_counts = 1;
+    s.c.n = grid_n; s.c.n_dev = &s.dyn->n_live;
+    { ProfScope p(h, SPH_K_HALO);
+      h->L->halo_classify_pack(s, grid_n);
+      h->L->halo_wait_rec(s, -1, bound_app, bound_live);
+      h->L->halo_unpack2(s, c.est_recv + c.est_recv / 4 + 4096); }
+    h->n = bound_app; refresh_counts(h); s.c.n_dev = &s.dyn->n_app;
+    ph_neighbor_search(h);
+    h->n = bound_live; refresh_counts(h); s.c.n_dev = &s.dyn->n_live;
+    c.bound_live = bound_live;
+    { ProfScope p(h, SPH_K_HALO); h->L->halo_build_tables(s); }
+    return SPH_OK;
+}
+
 // replaces ph_neighbor_search in slab mode: migrate + ghost exchange, then the usual sort, then the slot tables
-static int slab_neighbor_search(SphHandle *h) {
+static int slab_neighbor_search(SphHandle *h, bool allow_async = false) {
     State &s = h->st;
     SlabComm &c = h->comm;
     // records: 48 B, or 64 B with the rest position (rigid_particle_original_positions) once the scene has a dynamic rigid body --
-    // its particles take it along when they change owner (every rank is told about the body: sph_set_object)
+    // its particles take it along when they change owner.  EVERY rank must have been told about the body (sph_set_object):
+    // the record size travels in the message header and a mismatch fails on both sides instead of mis-parsing the payload.
     const size_t rec = s.orig.cur() ? 64 : 48;
     if (c.rebalance_every > 0 && h->prepared && h->steps > 0 && h->steps % c.rebalance_every == 0 && !h->any_rigid_object) {
-        int rc = slab_rebalance(h); if (rc) return rc;
+        int rc = slab_settle(h); if (rc) return rc;
+        rc = slab_rebalance(h); if (rc) return rc;
     }
+    if (s.push.on) return slab_neighbor_search_push(h, allow_async && c.async_enabled != 0);
     { ProfScope p(h, SPH_K_HALO); h->L->halo_classify_pack(s, h->n); }
     const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
     void *recv[2] = {s.recvbuf[0], s.recvbuf[1]};
     int dropped = 0;
     if (c.kind == 1) {
-        // RCCL: the record counts go to the neighbours straight from device memory, then ONE read-back brings my own
-        // counts and theirs to the host (the payload calls need both), then the payload
+        // RCCL: the record counts go to the neighbours straight from device memory, each followed by an info word (record
+        // size | this rank's sticky status << 8); ONE read-back brings my own counts and theirs to the host (the payload calls
+        // need both).  A failure either side knows about at this point (message over capacity, record sizes that differ, a
+        // failure carried over) is seen by BOTH before any payload call is posted: both return, nobody is left in a receive.
         ProfScope p(h, SPH_K_HALO);
         ncclComm_t comm = (ncclComm_t)c.nccl;
         const int peer[2] = {c.rank - 1, c.rank + 1};
         const bool has[2] = {s.has_down != 0, s.has_up != 0};
+        c.n_stage[4] = c.n_stage[5] = (int)rec | (c.sticky_status << 8);
+        HIPCHK(h, hipMemcpyAsync(c.cnt_dev + 4, c.n_stage + 4, 2 * sizeof(int), hipMemcpyHostToDevice, s.stream));
         NCCLCHK(h, ncclGroupStart());
         for (int side = 0; side < 2; ++side) {
             if (!has[side]) continue;
             NCCLCHK(h, ncclSend(s.halo_counts + side, 1, ncclInt32, peer[side], comm, s.stream));
+            NCCLCHK(h, ncclSend(c.cnt_dev + 4 + side, 1, ncclInt32, peer[side], comm, s.stream));
             NCCLCHK(h, ncclRecv(c.cnt_dev + 2 + side, 1, ncclInt32, peer[side], comm, s.stream));
+            NCCLCHK(h, ncclRecv(c.cnt_dev + 6 + side, 1, ncclInt32, peer[side], comm, s.stream));
         }
         NCCLCHK(h, ncclGroupEnd());
         HIPCHK(h, hipMemcpyAsync(c.cnt_host, s.halo_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
-        HIPCHK(h, hipMemcpyAsync(c.cnt_host + 4, c.cnt_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
-        HIPCHK(h, hipStreamSynchronize(s.stream));
+        HIPCHK(h, hipMemcpyAsync(c.cnt_host + 4, c.cnt_dev, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+        { int rc = stream_sync_bounded(h, "halo exchange (message sizes)"); if (rc) return rc; }
         dropped = c.cnt_host[2];
+        int st = c.sticky_status;
         for (int side = 0; side < 2; ++side) {
             c.n_send[side] = c.cnt_host[side];
-            c.n_recv[side] = has[side] ? c.cnt_host[6 + side] : 0;
-            if (c.n_send[side] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "halo message of %d particles exceeds capacity %d", c.n_send[side], s.halo_cap);
-            if (c.n_recv[side] < 0 || c.n_recv[side] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "received halo exceeds capacity");
+            c.n_recv[side] = has[side] ? c.cnt_host[4 + 2 + side] : 0;
+            if (c.n_send[side] > s.halo_cap) st |= SLAB_ST_SEND_OVERFLOW;
+            if (!has[side]) continue;
+            const int info = c.cnt_host[4 + 6 + side];
+            if ((info & 0xff) != (int)rec) st |= SLAB_ST_STRIDE;
+            if (info >> 8) st |= SLAB_ST_PEER;
+            if (c.n_recv[side] < 0 || c.n_recv[side] > s.halo_cap) st |= SLAB_ST_PEER;   // the neighbour saw its own overflow too
         }
+        if (st) { c.sticky_status |= st; return fail(h, SPH_ERR_CAPACITY, "halo exchange refused by both sides (status %d): %s", st, slab_status_text(st)); }
         const size_t bs[2] = {(size_t)c.n_send[0] * rec, (size_t)c.n_send[1] * rec};
         size_t br[2] = {(size_t)c.n_recv[0] * rec, (size_t)c.n_recv[1] * rec};
         int rc = comm_exchange(h, send, bs, recv, br, true); if (rc) return rc;
@@ -493,14 +772,18 @@ static int slab_neighbor_search(SphHandle *h) {
         const size_t bs[2] = {(size_t)c.n_send[0] * rec, (size_t)c.n_send[1] * rec};
         size_t br[2] = {0, 0};
         { ProfScope p(h, SPH_K_HALO); int rc = comm_exchange(h, send, bs, recv, br, false); if (rc) return rc; }
+        if (br[0] % rec || br[1] % rec) return fail(h, SPH_ERR_COMM, "halo record sizes differ between neighbours (a dynamic rigid body must be registered with sph_set_object on EVERY rank)");
         c.n_recv[0] = (int)(br[0] / rec); c.n_recv[1] = (int)(br[1] / rec);
         if (c.n_recv[0] > s.halo_cap || c.n_recv[1] > s.halo_cap) return fail(h, SPH_ERR_CAPACITY, "received halo exceeds capacity");
     }
     // nothing was compacted: the arrivals are appended behind the old particles (dead ones included), the sort files the
     // dead ones into the graveyard cell behind all live particles, and only then does the particle count shrink
     const int n_old = h->n;
-    if ((long long)n_old + c.n_recv[0] + c.n_recv[1] > s.cap)
+    if ((long long)n_old + c.n_recv[0] + c.n_recv[1] > s.cap) {
+        // the payload has been exchanged, so no neighbour is stuck in this step; the status travels in the next header
+        c.sticky_status |= SLAB_ST_CAPACITY;
         return fail(h, SPH_ERR_CAPACITY, "slab holds %d + %d + %d particles, particle_max_num is %d", n_old, c.n_recv[0], c.n_recv[1], s.cap);
+    }
     { ProfScope p(h, SPH_K_HALO);
       h->L->halo_unpack_append(s, 0, c.n_recv[0], n_old);
       h->L->halo_unpack_append(s, 1, c.n_recv[1], n_old + c.n_recv[0]); }
@@ -514,10 +797,23 @@ static int slab_neighbor_search(SphHandle *h) {
     return SPH_OK;
 }
 
+// field messages over the push transport: pack straight into the neighbours' inboxes (+ message number), wait, scatter
+static int slab_exchange_push(SphHandle *h, int kind, float *f0, float4 *v) {
+    State &s = h->st;
+    SlabComm &c = h->comm;
+    ProfScope p(h, SPH_K_HALO);
+    const int hint = h->n_exact ? c.n_send[0] + c.n_recv[0] + c.n_send[1] + c.n_recv[1] : 2 * c.est_recv + c.est_recv / 2 + 4096;
+    h->L->halo_push_fields(s, kind, f0, v, hint);
+    h->L->halo_wait_fld(s);
+    h->L->halo_pull_fields(s, kind, f0, v, hint);
+    return SPH_OK;
+}
+
 // density / pressure of the ghosts after the density pass (SURVEY 8e message (3))
 static int slab_exchange_fields(SphHandle *h) {
     State &s = h->st;
     SlabComm &c = h->comm;
+    if (s.push.on) return slab_exchange_push(h, 2, nullptr, nullptr);
     ProfScope p(h, SPH_K_HALO);
     for (int side = 0; side < 2; ++side) h->L->halo_pack_fields(s, side, c.n_send[side], c.n_recv[side]);
     const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
@@ -534,6 +830,7 @@ static int slab_exchange_fields(SphHandle *h) {
 static int slab_exchange_scalar(SphHandle *h, float *arr) {
     State &s = h->st;
     SlabComm &c = h->comm;
+    if (s.push.on) return slab_exchange_push(h, 0, arr, nullptr);
     ProfScope p(h, SPH_K_HALO);
     for (int side = 0; side < 2; ++side) h->L->halo_pack_scalar(s, side, c.n_send[side], c.n_recv[side], arr);
     const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
@@ -551,6 +848,7 @@ static int slab_exchange_vel(SphHandle *h, float4 *arr = nullptr) {
     State &s = h->st;
     SlabComm &c = h->comm;
     if (!arr) arr = s.velm.cur();
+    if (s.push.on) return slab_exchange_push(h, 1, nullptr, arr);
     ProfScope p(h, SPH_K_HALO);
     for (int side = 0; side < 2; ++side) h->L->halo_pack_vel(s, side, c.n_send[side], c.n_recv[side], arr);
     const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};

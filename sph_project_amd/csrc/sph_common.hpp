@@ -49,7 +49,38 @@ struct Consts {
     int   force_global;
     int   ghosts;           // slab sharding: ghost particles present (meta bit 11) even when all_fluid
     int   stat_bank;        // DevScalars bank the running step counts into (step parity)
+    // slab sharding, device-resident counts (sph_halo.hpp SlabDyn): when set, the particle count lives in device memory
+    // (the halo exchange changes it without the host looking) and `n` above is only the launch bound the grid was sized for
+    const int *n_dev;
 };
+
+// particle_num as the kernels see it
+__device__ __forceinline__ int live_n(const Consts &c) { return c.n_dev ? *c.n_dev : c.n; }
+
+// z-slab sharding: per-step counts, kept on the device by the halo kernels (sph_halo.hpp) and mirrored into pinned host memory.
+// status bits: see SLAB_ST_* below.
+struct SlabDyn {
+    int n_app;       // particles while the step's sort runs: last step's + arrivals (dead ones still in)
+    int n_live;      // after the sort: the dead ones (last step's ghosts, migrants that left) dropped
+    int n_send[2];   // records sent to the lower / upper rank this step (migrants + boundary copies)
+    int n_recv[2];   // records received from them
+    int dropped;
+    int longest;     // longest of the four messages (slot tables are reset up to here)
+    int status;      // sticky: SLAB_ST_*
+    unsigned seq;    // number of the step message these counts belong to
+};
+struct HaloCtl {            // push transport: header block of one side of a rank's inbox, 256 bytes, written by that neighbour
+    unsigned rec_seq;       // number of the last complete step message (stored last, system-scope release)
+    int rec_count, rec_status, rec_stride;   // its header: records, the sender's status bits, float4 per record
+    unsigned fld_seq;       // number of the last complete field message
+    int pad[59];
+};
+#define SLAB_ST_SEND_OVERFLOW 1   /* a face message of mine exceeds the message capacity */
+#define SLAB_ST_PEER 2            /* a neighbour reported a failure in its message header */
+#define SLAB_ST_STRIDE 4          /* the neighbour's record size differs from mine (dynamic rigid body not registered on every rank) */
+#define SLAB_ST_CAPACITY 8        /* own + received particles exceed particle_max_num */
+#define SLAB_ST_TIMEOUT 16        /* a neighbour's message did not arrive in time */
+#define SLAB_ST_BOUND 32          /* particle count outran the launch bound of an asynchronous step */
 
 // Device-side scalar block (zeroed / read back by the host)
 #define SPH_STAT_SLOTS 2048  // statistics are striped over many words: ~20k same-address atomics per launch cost >200 us
@@ -122,7 +153,20 @@ struct State {
     int xcur;
     int *halo_tab[8];    // slot tables, index = kind - 1 (sph_halo.hpp HALO_*): send, ghost, echo-send, echo-ghost x {down, up}
     float4 *sendbuf[2], *recvbuf[2];     // 3 float4 per particle record
-    int *halo_counts;    // device: [0..1] send counts, [2] kept count
+    int *halo_counts;    // device: [0..1] send counts, [2] dropped, [3] workgroups done (publish ticket of k_halo_classify)
+    SlabDyn *dyn;        // device-resident counts of the running step (push transport)
+    int async_counts;    // the running step takes its counts from `dyn` (c.n_dev set, c.n = launch bound)
+    // push transport (sph_halo.hpp): my inbox, the neighbours' inboxes mapped through hipIpc, message numbers
+    struct PushState {
+        int on;                        // halo payload travels by device stores into the neighbour's inbox
+        char *inbox;                   // mine (device memory the neighbours write)
+        char *peer[2];                 // lower / upper neighbour's inbox in my address space (null: no neighbour)
+        size_t rec_bytes, fld_bytes;   // size of one step-message / field-message region
+        unsigned rec_seq, fld_seq;     // messages sent (= received) so far
+        long long timeout_ticks;       // bounded waits of the device (100 MHz wall clock)
+        SlabDyn *mirror;               // pinned host copy of `dyn`, written by the wait kernel
+        int *ticket;                   // last-workgroup ticket of the publishing kernels
+    } push;
     int halo_cap;        // particles per message buffer
     int halo_longest;    // longest halo message of the running step, in particles (sent or received)
     int slab_active, z_lo, z_hi, has_down, has_up;
@@ -185,6 +229,13 @@ struct Launch {
     void (*count_ghosts)(State &, int *out);
     void (*layer_hist)(State &, int *hist);      // owned particles per global cell layer
     void (*loop_criterion)(State &, int slot);   // stop test on an all-reduced residual (sharded solver loops)
+    // push transport: the step message is written by halo_classify_pack itself; then
+    void (*halo_wait_rec)(State &, int n_old, int bound_app, int bound_live);   // wait for both neighbours' messages, settle SlabDyn
+    void (*halo_unpack2)(State &, int count_hint);                             // append both messages, reset the slot tables
+    void (*halo_push_fields)(State &, int kind, float *f0, float4 *v, int count_hint);   // pack + publish a field message per neighbour
+    void (*halo_wait_fld)(State &);
+    void (*halo_pull_fields)(State &, int kind, float *f0, float4 *v, int count_hint);   // scatter the neighbours' field messages
+    void (*halo_selftest)(State &, int n, int tag, int tag_down, int tag_up, int *bad_dev);
     // implicit viscosity (CG)
     void (*cg_prepare)(State &);
     void (*cg_ap)(State &);

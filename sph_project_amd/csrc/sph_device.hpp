@@ -177,7 +177,7 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
              int *__restrict__ rank, int *__restrict__ cell_count, const int *__restrict__ meta_dead) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool valid = i < c.n;
+    const bool valid = i < live_n(c);
     int lin = -1 - lane;  // distinct dummy key for lanes past the end
     if (valid) {
         const float4 p = posv[i];
@@ -252,7 +252,7 @@ k_scan_reduce(const int *__restrict__ in, int n, int *__restrict__ partial) {
 
 __global__ void __launch_bounds__(SCAN_TPB)
 k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *__restrict__ out,
-             int total_particles, DevScalars *__restrict__ scal, int clear_bank) {
+             int total_particles, DevScalars *__restrict__ scal, int clear_bank, const int *__restrict__ total_dev) {
     // side jobs of the kernel that runs every step: clears cell_count behind itself (the next histogram starts from
     // zero without a memset) and clears the statistics bank of the next step
     __shared__ int s_w[SCAN_TPB / 64];
@@ -286,15 +286,16 @@ k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *
             if (idx + 2 < n) { out[idx + 2] = o.z; in[idx + 2] = 0; }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total_particles;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total_dev ? *total_dev : total_particles;
 }
 
 // deterministic mode: list the source indices of every cell, so that the scatter can compute a
 // stable rank (= serial execution of base_container.py:510-515).
 __global__ void __launch_bounds__(256)
 k_scatter_index(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
-                const int *__restrict__ cell_start, int *__restrict__ tmp_idx) {
+                const int *__restrict__ cell_start, int *__restrict__ tmp_idx, const int *__restrict__ n_dev) {
     int i = blockIdx.x * 256 + threadIdx.x;
+    if (n_dev) n = *n_dev;
     if (i >= n) return;
     tmp_idx[cell_start[cellid[i]] + rank[i]] = i;
 }
@@ -317,8 +318,9 @@ struct SortArrays {
 template <bool STABLE>
 __global__ void __launch_bounds__(256)
 k_scatter(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
-          const int *__restrict__ cell_start, const int *__restrict__ tmp_idx, SortArrays a) {
+          const int *__restrict__ cell_start, const int *__restrict__ tmp_idx, SortArrays a, const int *__restrict__ n_dev) {
     int i = blockIdx.x * 256 + threadIdx.x;
+    if (n_dev) n = *n_dev;
     if (i >= n) return;
     int cell = cellid[i];
     int s = cell_start[cell];
@@ -643,9 +645,14 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i0 = blockIdx.x * 256;
     const int i = i0 + tid;
-    const int nvalid = (c.n - i0) < 256 ? (c.n - i0) : 256;
+    const int n = live_n(c);
+    if (i0 >= n) {   // launch bound of an asynchronous slab step: no such tile
+        if (blk_flag && tid == 0) blk_flag[blockIdx.x] = 0;
+        return;
+    }
+    const int nvalid = (n - i0) < 256 ? (n - i0) : 256;
     int key = 63;  // slots past the end go last
-    if (i < c.n) {
+    if (i < n) {
         const float4 p = posv[i];
         const int cx = cell_coord(p.x, c.grid_size, c.nx);
         const int k = (int)((p.x / c.grid_size - (float)cx) * 62.0f);
@@ -660,7 +667,7 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
     }
     (&s_cnt[0][0])[tid] = 0;
     if (blk_flag) {   // does this workgroup hold any fluid particle? (k_compact_blocks lists those that do)
-        const int anyf = __syncthreads_or((i < c.n && META_ACTIVE_FLUID(meta[i])) ? 1 : 0);
+        const int anyf = __syncthreads_or((i < n && META_ACTIVE_FLUID(meta[i])) ? 1 : 0);
         if (tid == 0) blk_flag[blockIdx.x] = anyf ? 1 : 0;
     }
     unsigned long long peers = ~0ull;   // lanes of this wave holding the same key
@@ -780,10 +787,15 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     NBR_STAMP(0);
     const int b = blk_list ? blk_list[blockIdx.x] : xcd_remap(blockIdx.x, nblocks);
     const int i0 = b * BLOCK;
+    const int n_live = live_n(c);
+    if (i0 >= n_live) {   // launch bound of an asynchronous slab step: no such tile (its header was never written)
+        if constexpr (P::HAS_REDUCE) { if (tid == 0 && !(PassSplit<P>::value && gridDim.y == 3)) p.red_out[b] = 0.0f; }
+        return;
+    }
     // which particle of the workgroup this lane owns for the whole pass
     const int who = lane_perm ? (int)lane_perm[i0 + tid] : tid;
     const int i = i0 + who;
-    const bool valid = i < c.n;
+    const bool valid = i < n_live;
 
     // workgroup header (uniform)
     const int *hdr = blk_hdr + (size_t)b * BLK_HDR_INTS;

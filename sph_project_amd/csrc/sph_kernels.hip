@@ -37,7 +37,7 @@ void l_scan(State &s) {
     if (nb < SPH_STAT_SLOTS / SCAN_TPB) nb = SPH_STAT_SLOTS / SCAN_TPB;   // k_scan_final also clears the statistics slots
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial,
-                       s.cell_start, s.c.n, s.scal, 1 - s.c.stat_bank);
+                       s.cell_start, s.c.n, s.scal, 1 - s.c.stat_bank, s.c.n_dev);
     s.cell_count_clean = 1;
 }
 
@@ -48,7 +48,7 @@ void l_block_prep(State &s) {
     const bool lst = !s.c.all_fluid && s.blk_list;
     hipLaunchKernelGGL(k_block_prep, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.meta.cur(), s.cell_start,
                        s.blk_hdr, s.lane_perm, lst ? s.blk_flag : nullptr);
-    if (lst) hipLaunchKernelGGL(k_compact_blocks, dim3(1), dim3(256), 0, s.stream, s.blk_flag, cdiv(n, 256), s.blk_list, s.blk_count);
+    if (lst) hipLaunchKernelGGL(k_compact_blocks, dim3(1), dim3(256), 0, s.stream, s.blk_flag, cdiv(n, 256), s.blk_list, s.blk_count);   // (tiles past the live count carry flag 0)
     s.list_n = lst ? n : -1;
     s.perm_n = n;
 }
@@ -69,12 +69,12 @@ void l_scatter_impl(State &s, bool stable) {
     int *tmp_idx = (int *)s.red_partial;  // reused scratch (sized >= n ints by the allocator)
     if (stable) {
         hipLaunchKernelGGL(k_scatter_index, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
-                           s.cell_start, s.tmp_idx);
+                           s.cell_start, s.tmp_idx, s.c.n_dev);
         hipLaunchKernelGGL(k_scatter<true>, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
-                           s.cell_start, s.tmp_idx, a);
+                           s.cell_start, s.tmp_idx, a, s.c.n_dev);
     } else {
         hipLaunchKernelGGL(k_scatter<false>, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
-                           s.cell_start, s.tmp_idx, a);
+                           s.cell_start, s.tmp_idx, a, s.c.n_dev);
     }
     (void)tmp_idx;
     s.posv.flip(); s.velm.flip(); s.meta.flip(); s.pid.flip(); s.color.flip(); s.rho.flip();
@@ -171,7 +171,7 @@ void l_non_pressure(State &s) {
 __global__ void __launch_bounds__(256)
 k_emitter_advance(const Consts c, float4 *posv, const float4 *velm, int *meta, const RigidPose *pose) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= c.n) return;
+    if (i >= live_n(c)) return;
     const int m = meta[i];
     if (META_MAT(m) == 1) return;
     float4 p = posv[i];
@@ -227,7 +227,7 @@ void l_rigid_volume(State &s) {
 __global__ void __launch_bounds__(256)
 k_renew_rigid(const Consts c, float4 *posv, float4 *velm, const float4 *orig, const int *meta, const RigidPose *pose) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= c.n) return;
+    if (i >= live_n(c)) return;
     const int m = meta[i];
     if (META_MAT(m) != 2 || !META_DYN(m)) return;
     const int o = META_OBJ(m);
@@ -257,7 +257,7 @@ void l_renew_rigid(State &s) {
 // base_solver.py:670 prepare_emitter
 __global__ void __launch_bounds__(256) k_prepare_emitter(const Consts c, const float4 *posv, int *meta) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= c.n) return;
+    if (i >= live_n(c)) return;
     const int m = meta[i];
     if (META_MAT(m) == 1 && posv[i].y > c.g_upper) meta[i] = META_SET_MAT(m, 2);
 }
@@ -275,7 +275,7 @@ void l_prepare_emitter(State &s) {
 __global__ void __launch_bounds__(256)
 k_post_insert(const Consts c, int first, float4 *posv, float4 *velm, const int *meta, int stale_volume) {
     const int i = first + blockIdx.x * 256 + threadIdx.x;
-    if (i >= c.n) return;
+    if (i >= live_n(c)) return;
     const int m = meta[i];
     float4 p = posv[i], v = velm[i];
     if (META_MAT(m) == 1) {
@@ -329,6 +329,8 @@ const Launch *SPH_LAUNCH_FN() {
         L.halo_pack_scalar = l_halo_pack_scalar; L.halo_unpack_scalar = l_halo_unpack_scalar;
         L.halo_pack_vel = l_halo_pack_vel; L.halo_unpack_vel = l_halo_unpack_vel;
         L.loop_criterion = l_loop_criterion;
+        L.halo_wait_rec = l_halo_wait_rec; L.halo_unpack2 = l_halo_unpack2; L.halo_push_fields = l_halo_push_fields;
+        L.halo_wait_fld = l_halo_wait_fld; L.halo_pull_fields = l_halo_pull_fields; L.halo_selftest = l_halo_selftest;
         L.layer_hist = l_layer_hist;
         L.count_ghosts = l_count_ghosts;
         init = true;

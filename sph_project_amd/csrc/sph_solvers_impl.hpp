@@ -6,7 +6,7 @@
 __global__ void __launch_bounds__(256)
 k_advect_boundary(const Consts c, float4 *posv, float4 *velm, int *meta, const RigidPose *pose, int all_fluid) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= c.n) return;
+    if (i >= live_n(c)) return;
     float4 p = posv[i], v = velm[i];
     const int m = all_fluid ? META_PACK(0, 1, 1) : meta[i];
     if (META_MAT(m) == 1) {
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256)
 k_pcisph_init(const Consts c, const float4 *posv, const float4 *vel0, const float4 *acc_np, const int *meta,
               float *prs, float *ptm, float4 *pacc, float4 *pvel, float4 *ppos, int all_fluid) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= c.n) return;
+    if (i >= live_n(c)) return;
     prs[i] = 0.0f; ptm[i] = 0.0f;
     pacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!all_fluid && META_MAT(meta[i]) != 1) return;

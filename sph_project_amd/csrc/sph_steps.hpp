@@ -61,7 +61,10 @@ static int run_non_pressure(SphHandle *h) {
 
 static int wcsph_step(SphHandle *h) {
     State &s = h->st;
-    if (s.slab_active) { int rc = slab_neighbor_search(h); if (rc) return rc; }   // + migration / ghost exchange
+    // sharded: + migration / ghost exchange; over the push transport a plain WCSPH step needs nothing back from the device
+    // (slab_neighbor_search_push, "async"): implicit viscosity and the unfused force passes launch exact grids instead
+    const bool fused = !h->prm.viscosity_implicit && !getenv("SPH_NO_FUSED_FORCES");
+    if (s.slab_active) { int rc = slab_neighbor_search(h, fused); if (rc) return rc; }
     else ph_neighbor_search(h);                                               // WCSPH.py:28
     ph_rigid_volume(h);                                                       // base_solver.py:696 (see ph_rigid_volume)
     { ProfScope p(h, SPH_K_DENSITY); h->L->density(s, 1); }                   // :29 + :33 (EOS fused)

@@ -1,6 +1,9 @@
-"""GPU: z-slab sharding.  Several ranks (one process each) share this box's single GPU and talk through the
-shared-memory transport (SPH_COMM_TRANSPORT=shm); the device-side protocol (migration, ghost layers, echo
-ghosts, field exchange) is exactly the one the RCCL transport drives on a multi-GPU node."""
+"""GPU: z-slab sharding.  Several ranks (one process each) share this box's single GPU.  Control plane: the shared-memory
+segment (RCCL refuses two ranks on one device).  Data plane, both tested against the undecomposed CPU oracle:
+  * "shm+ipc": the PUSH transport -- the production data plane: halo records and field messages are written by the sending
+    rank's kernels straight into the neighbour's inbox (hipIpc mapping), headers / message numbers / waits on the device,
+    WCSPH steps fully asynchronous (device-resident counts, launches from bounds);
+  * "shm": host-staged mailboxes (the older test rig; same classify / unpack / table kernels as the RCCL send/recv fallback)."""
 import json
 import os
 import subprocess
@@ -16,11 +19,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.0, seed=0, fixed_iterations=0, rebalance=0):
+TRANSPORT = ["shm+ipc"]   # set by the fixture below for the running test
+
+
+@pytest.fixture(autouse=True, params=["shm+ipc", "shm"])
+def transport(request):
+    TRANSPORT[0] = request.param
+    return request.param
+
+
+def _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.0, seed=0, fixed_iterations=0, rebalance=0, advance=False, extra_env=None):
     scene_path = tmp_path / "scene.json"
     scene_path.write_text(json.dumps(cfg))
     uid = os.urandom(128).hex()
-    env = dict(os.environ, SPH_COMM_TRANSPORT="shm", SPH_FIXED_ITERATIONS=str(fixed_iterations), SPH_SLAB_REBALANCE=str(rebalance))
+    env = dict(os.environ, SPH_COMM_TRANSPORT=TRANSPORT[0], SPH_FIXED_ITERATIONS=str(fixed_iterations), SPH_SLAB_REBALANCE=str(rebalance),
+               SPH_WORKER_ADVANCE="1" if advance else "0", SPH_COMM_TIMEOUT_S="40", **(extra_env or {}))
     procs = []
     for r in range(nranks):
         out = tmp_path / f"rank{r}.npz"
@@ -33,16 +46,22 @@ def _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.0, seed=0, fixed_iteration
         logs.append(o.decode())
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
-    return [np.load(tmp_path / f"rank{r}.npz") for r in range(nranks)], logs
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(nranks)]
+    want = "ipc-push+shm" if TRANSPORT[0] == "shm+ipc" else "shm"
+    assert all(str(o["transport"]) == want for o in outs), [str(o["transport"]) for o in outs]   # no silent fall-back in the tests
+    return outs, logs
 
 
+@pytest.mark.parametrize("advance", [False, True], ids=["step", "advance"])
 @pytest.mark.parametrize("nranks", [2, 3])
-def test_slab_sharding_matches_oracle(gpu, tmp_path, nranks):
+def test_slab_sharding_matches_oracle(gpu, tmp_path, nranks, advance):
+    """advance: all 40 steps handed to the device in ONE call -- over the push transport they run without a single host
+    read-back (device-resident counts, launch bounds from the pinned mirror); step: one call and one settle per step."""
     # a block that spans the domain in z and falls / spreads for 40 steps: particles migrate across slab faces
     cfg = H.dam_break_scene(domain_end=(1.0, 1.0, 1.2), start=(0.1, 0.1, 0.08), end=(0.4, 0.4, 1.12), translation=(0, 0, 0),
                             velocity=(0.0, -0.3, 2.5), particleSpacing=0.019)
     steps = 40
-    outs, logs = _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.002, seed=3)
+    outs, logs = _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.002, seed=3, advance=advance)
     # the undecomposed CPU oracle on the same seeded scene is the reference (not a single-rank run of the same library)
     ref = H.build_oracle(cfg, jitter=0.002, seed=3)
     ref.prepare()
@@ -329,3 +348,23 @@ def test_dynamic_rigid_body_under_slab_sharding(gpu, tmp_path):
     assert np.bincount(owner[rigid], minlength=2).min() > 0, "the body straddles the face"
     assert body.com[1] < 0.27 - 0.03, "it fell"
     assert d[rigid].max() <= 1e-5 and d[~rigid].max() <= 1e-4
+
+
+def test_dead_neighbour_is_an_error_not_a_hang(gpu, tmp_path):
+    """A rank that disappears must not leave its neighbour waiting for ever -- neither in a kernel (the device-side waits of
+    the push transport are bounded and raise SLAB_ST_TIMEOUT) nor on the host (bounded stream waits / mailbox waits): the
+    survivor's call returns an error within the time-out.  Plain library use, no launcher that could kill it."""
+    import time
+    cfg = H.dam_break_scene(domain_end=(1.0, 1.0, 1.2), start=(0.1, 0.1, 0.08), end=(0.3, 0.3, 1.12), translation=(0, 0, 0))
+    scene_path = tmp_path / "scene.json"
+    scene_path.write_text(json.dumps(cfg))
+    uid = os.urandom(128).hex()
+    env = dict(os.environ, SPH_COMM_TRANSPORT=TRANSPORT[0], SPH_COMM_TIMEOUT_S="6", SPH_WORKER_DIE_RANK="1", SPH_WORKER_ADVANCE="1")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "slab_worker.py"), str(r), "2", uid, str(scene_path), "5",
+                               str(tmp_path / f"rank{r}.npz")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=200)[0].decode() for p in procs]
+    assert procs[1].returncode == 3
+    assert procs[0].returncode not in (0, None), logs[0][-2000:]
+    assert "SphError" in logs[0] and ("did not arrive in time" in logs[0] or "timed out" in logs[0] or "no answer" in logs[0]), logs[0][-2000:]
+    assert time.time() - t0 < 150
