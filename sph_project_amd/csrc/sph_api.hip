@@ -289,7 +289,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     for (int o = 0; o < SPH_NOBJ; ++o) { h->pose_h.rot[o][0] = h->pose_h.rot[o][4] = h->pose_h.rot[o][8] = 1.0f; }
     memset(&h->last, 0, sizeof(h->last));
     s.has_dynamic_rigid = 0; s.has_rigid = 0;
-    s.dyn = nullptr; s.async_counts = 0; memset(&s.push, 0, sizeof(s.push));
+    s.dyn = s.dyn_cur = nullptr; s.async_counts = 0; s.tables_pending = 0; memset(&s.push, 0, sizeof(s.push));
     s.slab_active = 0; s.xcur = 0; s.halo_cap = 0; s.z_lo = 0; s.z_hi = s.c.nz_glob; s.has_down = s.has_up = 0;
     s.xidx[0] = s.xidx[1] = nullptr; s.halo_counts = nullptr;
     s.visc_rho_raw = (p.method == SPH_METHOD_WCSPH);

@@ -203,8 +203,9 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
             rc = dalloc(h, &s.recvbuf[k], 4 * cap); if (rc) return rc;
         }
         for (int k = 0; k < 8; ++k) { int rc = dalloc(h, &s.halo_tab[k], cap); if (rc) return rc; }
-        { int rc = dalloc(h, &s.halo_counts, 4); if (rc) return rc; }
-        { int rc = dalloc(h, &s.dyn, 1); if (rc) return rc; }
+        { int rc = dalloc(h, &s.halo_counts, 8); if (rc) return rc; }
+        { int rc = dalloc(h, &s.dyn, 2); if (rc) return rc; }
+        s.dyn_cur = s.dyn;
         HIPCHK(h, hipMalloc((void **)&h->comm.bad_dev, sizeof(int)));
         HIPCHK(h, hipHostMalloc((void **)&h->comm.n_stage, 16 * sizeof(int), hipHostMallocDefault));
         s.xcur = 0;
@@ -358,7 +359,7 @@ extern "C" int sph_comm_selftest(SphHandle *h, int n) {
         h->L->halo_selftest(s, m, c.rank, c.rank - 1, c.rank + 1, c.bad_dev);
         int bad = -1, st = 0;
         HIPCHK(h, hipMemcpyAsync(&bad, c.bad_dev, sizeof(int), hipMemcpyDeviceToHost, s.stream));
-        HIPCHK(h, hipMemcpyAsync(&st, &s.dyn->status, sizeof(int), hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(h, hipMemcpyAsync(&st, &s.dyn_cur->status, sizeof(int), hipMemcpyDeviceToHost, s.stream));
         int rc = stream_sync_bounded(h, "comm_selftest (push transport)"); if (rc) return rc;
         if (bad || st) return fail(h, SPH_ERR_COMM, "comm_selftest: push transport delivered %d wrong words (status %d)", bad, st);
     }
@@ -434,7 +435,6 @@ static int push_teardown(SphHandle *h) {
     for (int side = 0; side < 2; ++side) { if (c.ipc_mapped[side]) hipIpcCloseMemHandle(c.ipc_mapped[side]); c.ipc_mapped[side] = nullptr; s.push.peer[side] = nullptr; }
     if (c.inbox_alloc) { hipFree(c.inbox_alloc); c.inbox_alloc = nullptr; }
     if (s.push.mirror) { hipHostFree(s.push.mirror); s.push.mirror = nullptr; }
-    if (s.push.ticket) { hipFree(s.push.ticket); s.push.ticket = nullptr; }
     s.push.on = 0; s.push.inbox = nullptr;
     (void)hipGetLastError();
     return SPH_OK;
@@ -466,7 +466,6 @@ static int push_setup(SphHandle *h) {
     }
     if (hipHostMalloc((void **)&s.push.mirror, sizeof(SlabDyn), hipHostMallocDefault) != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "pinned mirror"); (void)hipGetLastError(); }
     else memset(s.push.mirror, 0, sizeof(SlabDyn));
-    if (hipMalloc((void **)&s.push.ticket, sizeof(int)) != hipSuccess || hipMemset(s.push.ticket, 0, sizeof(int)) != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "ticket"); (void)hipGetLastError(); }
     // handles to the neighbours (even a rank that failed so far takes part: the exchange is collective)
     struct Hello { unsigned magic; int ok; int rank; int pad; hipIpcMemHandle_t handle; } hello_out, hello_in[2];
     static_assert(sizeof(Hello) <= 256, "hello message");
@@ -502,10 +501,10 @@ static int push_setup(SphHandle *h) {
         h->L->halo_selftest(s, n, c.rank, c.rank - 1, c.rank + 1, c.bad_dev);
         int bad = -1, st = 0;
         hipError_t e2 = hipMemcpyAsync(&bad, c.bad_dev, sizeof(int), hipMemcpyDeviceToHost, s.stream);
-        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&st, &s.dyn->status, sizeof(int), hipMemcpyDeviceToHost, s.stream);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&st, &s.dyn_cur->status, sizeof(int), hipMemcpyDeviceToHost, s.stream);
         int rc = e2 == hipSuccess ? stream_sync_bounded(h, "push transport self-test") : SPH_ERR_HIP;
         if (rc || bad != 0 || st != 0) { ok = 0; snprintf(why, sizeof(why), "self-test: %d wrong words, status %d", bad, st); }
-        HIPCHK(h, hipMemsetAsync(&s.dyn->status, 0, sizeof(int), s.stream));
+        HIPCHK(h, hipMemsetAsync(s.dyn, 0, 2 * sizeof(SlabDyn), s.stream));   // (the status word is sticky: a failed self-test must not outlive the fall-back)
         verdict[0] = (double)ok;
         rc = sph_comm_allreduce(h, verdict, 1, 2); if (rc) return rc;
     }
@@ -645,13 +644,12 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
         s.async_counts = 0; s.c.n_dev = nullptr;
         { ProfScope p(h, SPH_K_HALO);
           h->L->halo_classify_pack(s, h->n);
-          h->L->halo_wait_rec(s, h->n, 0, 0); }
+          h->L->halo_unpack2(s, h->n, 0, 0, c.est_recv + c.est_recv / 4 + 4096); }
         rc = stream_sync_bounded(h, "halo exchange (step message)"); if (rc) return rc;
         const SlabDyn m = *(const SlabDyn *)s.push.mirror;
         if (m.status) return fail(h, SPH_ERR_COMM, "halo exchange failed (status %d): %s", m.status, slab_status_text(m.status));
         for (int side = 0; side < 2; ++side) { c.n_send[side] = m.n_send[side]; c.n_recv[side] = m.n_recv[side]; }
         c.est_recv = m.n_recv[0] + m.n_recv[1];
-        { ProfScope p(h, SPH_K_HALO); h->L->halo_unpack2(s, std::max(c.est_recv, m.longest)); }
         h->n = m.n_app;
         refresh_counts(h);
         ph_neighbor_search(h);
@@ -665,7 +663,7 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
     int lag = 0, grid_n;
     if (h->n_exact) {   // first asynchronous step after an exact count: hand it to the device
         c.n_stage[0] = h->n;
-        HIPCHK(h, hipMemcpyAsync(&s.dyn->n_live, c.n_stage, sizeof(int), hipMemcpyHostToDevice, s.stream));
+        HIPCHK(h, hipMemcpyAsync(&s.dyn_cur->n_live, c.n_stage, sizeof(int), hipMemcpyHostToDevice, s.stream));   // (the bank the next message reads as "last step's")
         live_known = h->n; app_known = (long long)h->n + c.est_recv; grid_n = h->n;
         s.push.mirror->seq = s.push.rec_seq; s.push.mirror->n_live = h->n; s.push.mirror->n_app = (int)app_known; s.push.mirror->status = 0;
     } else {
@@ -692,14 +690,13 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
     const int bound_live = (int)std::min<long long>(s.cap, live_known + margin);
     h->n_exact = false;
     s.async_counts = 1;
-    s.c.n = grid_n; s.c.n_dev = &s.dyn->n_live;
+    s.c.n = grid_n; s.c.n_dev = &s.dyn_cur->n_live;
     { ProfScope p(h, SPH_K_HALO);
       h->L->halo_classify_pack(s, grid_n);
-      h->L->halo_wait_rec(s, -1, bound_app, bound_live);
-      h->L->halo_unpack2(s, c.est_recv + c.est_recv / 4 + 4096); }
-    h->n = bound_app; refresh_counts(h); s.c.n_dev = &s.dyn->n_app;
+      h->L->halo_unpack2(s, -1, bound_app, bound_live, c.est_recv + c.est_recv / 4 + 4096); }   // (moves dyn_cur to this message's bank)
+    h->n = bound_app; refresh_counts(h); s.c.n_dev = &s.dyn_cur->n_app;
     ph_neighbor_search(h);
-    h->n = bound_live; refresh_counts(h); s.c.n_dev = &s.dyn->n_live;
+    h->n = bound_live; refresh_counts(h); s.c.n_dev = &s.dyn_cur->n_live;
     c.bound_live = bound_live;
     { ProfScope p(h, SPH_K_HALO); h->L->halo_build_tables(s); }
     return SPH_OK;
@@ -804,7 +801,6 @@ static int slab_exchange_push(SphHandle *h, int kind, float *f0, float4 *v) {
     ProfScope p(h, SPH_K_HALO);
     const int hint = h->n_exact ? c.n_send[0] + c.n_recv[0] + c.n_send[1] + c.n_recv[1] : 2 * c.est_recv + c.est_recv / 2 + 4096;
     h->L->halo_push_fields(s, kind, f0, v, hint);
-    h->L->halo_wait_fld(s);
     h->L->halo_pull_fields(s, kind, f0, v, hint);
     return SPH_OK;
 }

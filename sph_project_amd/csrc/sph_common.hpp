@@ -153,8 +153,10 @@ struct State {
     int xcur;
     int *halo_tab[8];    // slot tables, index = kind - 1 (sph_halo.hpp HALO_*): send, ghost, echo-send, echo-ghost x {down, up}
     float4 *sendbuf[2], *recvbuf[2];     // 3 float4 per particle record
-    int *halo_counts;    // device: [0..1] send counts, [2] dropped, [3] workgroups done (publish ticket of k_halo_classify)
-    SlabDyn *dyn;        // device-resident counts of the running step (push transport)
+    int *halo_counts;    // device, two banks of 4 (push transport: bank = message parity): [0..1] send counts, [2] dropped
+    SlabDyn *dyn;        // device-resident counts of a step, two banks (message parity): a kernel reads the last step's, writes this step's
+    SlabDyn *dyn_cur;    // the bank of the last step message (what c.n_dev and the field kernels look at)
+    int tables_pending;  // push transport: the next k_block_prep also fills the halo slot tables from xidx
     int async_counts;    // the running step takes its counts from `dyn` (c.n_dev set, c.n = launch bound)
     // push transport (sph_halo.hpp): my inbox, the neighbours' inboxes mapped through hipIpc, message numbers
     struct PushState {
@@ -165,7 +167,6 @@ struct State {
         unsigned rec_seq, fld_seq;     // messages sent (= received) so far
         long long timeout_ticks;       // bounded waits of the device (100 MHz wall clock)
         SlabDyn *mirror;               // pinned host copy of `dyn`, written by the wait kernel
-        int *ticket;                   // last-workgroup ticket of the publishing kernels
     } push;
     int halo_cap;        // particles per message buffer
     int halo_longest;    // longest halo message of the running step, in particles (sent or received)
@@ -230,11 +231,10 @@ struct Launch {
     void (*layer_hist)(State &, int *hist);      // owned particles per global cell layer
     void (*loop_criterion)(State &, int slot);   // stop test on an all-reduced residual (sharded solver loops)
     // push transport: the step message is written by halo_classify_pack itself; then
-    void (*halo_wait_rec)(State &, int n_old, int bound_app, int bound_live);   // wait for both neighbours' messages, settle SlabDyn
-    void (*halo_unpack2)(State &, int count_hint);                             // append both messages, reset the slot tables
-    void (*halo_push_fields)(State &, int kind, float *f0, float4 *v, int count_hint);   // pack + publish a field message per neighbour
-    void (*halo_wait_fld)(State &);
-    void (*halo_pull_fields)(State &, int kind, float *f0, float4 *v, int count_hint);   // scatter the neighbours' field messages
+    // announce my message, wait for both neighbours', settle SlabDyn, append their records, reset the slot tables
+    void (*halo_unpack2)(State &, int n_old, int bound_app, int bound_live, int count_hint);
+    void (*halo_push_fields)(State &, int kind, float *f0, float4 *v, int count_hint);   // pack a field message per neighbour
+    void (*halo_pull_fields)(State &, int kind, float *f0, float4 *v, int count_hint);   // announce, wait, scatter the neighbours' field messages
     void (*halo_selftest)(State &, int n, int tag, int tag_down, int tag_up, int *bad_dev);
     // implicit viscosity (CG)
     void (*cg_prepare)(State &);

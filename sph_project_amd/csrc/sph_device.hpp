@@ -631,6 +631,7 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
 #define NBR_CS_PITCH (NBR_CS_SPAN + 4)
 #define NBR_BLOCK 256
 
+struct BlockPrepTables { int *tab[8]; };
 // Lane permutation of a workgroup (256 consecutive sorted particles): particles stably sorted by their x position
 // inside the cell.  The x-offset groups (-1, 0, +1) of the neighbour pass hold very different numbers of accepted
 // neighbours for particles in the low-x and the high-x part of a cell; putting like with like makes the 64 lanes
@@ -639,7 +640,7 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
 __global__ void __launch_bounds__(256)
 k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restrict__ meta,
              const int *__restrict__ cell_start, int *__restrict__ blk_hdr, unsigned char *__restrict__ perm,
-             int *__restrict__ blk_flag) {
+             int *__restrict__ blk_flag, const int *__restrict__ xidx, BlockPrepTables tabs) {
     __shared__ int s_cnt[4][64];
     __shared__ int s_c[2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -653,6 +654,11 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
     const int nvalid = (n - i0) < 256 ? (n - i0) : 256;
     int key = 63;  // slots past the end go last
     if (i < n) {
+        if (xidx) {   // slab sharding, push transport: the halo slot tables of this sort (sph_halo.hpp k_halo_tables) ride along
+            const int x = xidx[i];
+            const int kind = (int)(((unsigned)x) >> 28);
+            if (kind >= 1 && kind <= 8) tabs.tab[kind - 1][x & 0x0fffffff] = i;
+        }
         const float4 p = posv[i];
         const int cx = cell_coord(p.x, c.grid_size, c.nx);
         const int k = (int)((p.x / c.grid_size - (float)cx) * 62.0f);

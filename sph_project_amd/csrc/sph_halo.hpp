@@ -46,48 +46,43 @@ __device__ __forceinline__ int halo_wave_slot(bool want, int *counter) {
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
-// ---- push transport (sph_comm.hpp kind "ipc"): a rank's INBOX is one device allocation that its two neighbours map
-// through hipIpc and write into directly -- no send buffer, no copy engine, no host.  Per side (= which neighbour writes):
-// a control block, two step-message regions (parity of the message number) and two field-message regions.  The writer
-// stores the payload, makes it visible system-wide (__threadfence_system in every workgroup that wrote), and the LAST
-// workgroup of the kernel stores the header and then the message number (system-scope release); the reader's wait kernel
-// polls the number (relaxed, s_sleep), then acquires.  Both sides run the same sequence of exchanges, so message numbers
-// stay in lockstep; a message m + 2 can only be written after the writer received the reader's message m + 1, which the
-// reader sent after it had consumed message m: two regions per direction suffice.
-// (HaloCtl, the control block of one inbox side: sph_common.hpp)
-struct HaloPush {           // how k_halo_classify announces its two messages (ticket == null: records go to local send buffers)
-    HaloCtl *ctl[2];        // the neighbours' control blocks for messages from me (null: no neighbour on that side)
-    unsigned seq;
-    int stride;
-    int *ticket;            // workgroups done so far
-    const SlabDyn *dyn;     // my sticky status travels in the header
-};
-
-// The last workgroup of a kernel to get here returns true (for all its threads).  Every workgroup calls it once, after
-// its own stores; the system-scope fence in front makes them visible to the other device before the ticket is drawn.
-__device__ __forceinline__ bool halo_last_workgroup(int *ticket) {
-    __shared__ int s_last;
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nb = (int)(gridDim.x * gridDim.y);
-        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == nb - 1;
-        if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next kernel
-    }
-    __syncthreads();
-    return s_last != 0;
-}
+// ---- push transport (sph_comm.hpp): a rank's INBOX is one device allocation that its two neighbours map through hipIpc and
+// write into directly -- no send buffer, no copy engine, no host.  Per side (= which neighbour writes): a control block, two
+// step-message regions (parity of the message number) and two field-message regions.
+//   writer:  kernel K stores the payload (k_halo_classify: the records; k_halo_pack2: the field values) with plain stores;
+//            the NEXT kernel on the stream (k_halo_unpack2 / k_halo_unpack2f, which also consume the neighbours' messages)
+//            begins -- workgroup 0, one lane per neighbour -- by storing the header, a system-scope fence, and the message
+//            number (release).  The kernel boundary in between has completed all payload stores; stores from one device to
+//            one destination are delivered in order, so whoever sees the number sees the payload.
+//   reader:  every workgroup of the consuming kernel polls the number in ITS OWN inbox (relaxed load + s_sleep, bounded by
+//            the wall clock: a neighbour that never answers raises SLAB_ST_TIMEOUT instead of hanging the GPU), acquires,
+//            reads the header, and consumes the payload in the same launch.  No separate wait kernel, no per-workgroup
+//            fences, no tickets: the step message costs one extra launch (classify) on top of the unpack, a field message two.
+// Both sides run the same sequence of exchanges, so message numbers stay in lockstep; message m + 2 can only be written after
+// the writer has received the reader's message m + 1, which was sent after message m had been consumed: two regions per
+// direction suffice.  The per-step counts live in device memory, double-buffered by message parity (SlabDyn[2]: a kernel
+// reads last step's bank and writes this step's; halo_counts[2][4] likewise), and are mirrored into pinned host memory.
+// (HaloCtl, the control block of one inbox side, and SlabDyn: sph_common.hpp)
 __device__ __forceinline__ void halo_store_sys(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ int halo_load_sys(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ bool halo_poll(const unsigned *word, unsigned seq, long long timeout_ticks) {
+    const long long t0 = (long long)wall_clock64();
+    for (;;) {
+        const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int)(v - seq) >= 0) return true;
+        if ((long long)wall_clock64() - t0 > timeout_ticks) return false;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
 
 // In place: nothing is compacted or copied.  Particles that are no longer this rank's business (last step's ghosts,
 // migrants beyond the neighbour's boundary layer) get the DEAD bit; the sort that follows files them into the
 // graveyard cell G behind every live particle, and the live count shrinks by counts[2].
 // counts[0] = records for the lower rank, counts[1] = upper rank, counts[2] = particles that died.
+// send_down / send_up: the local send buffers, or (push transport) the step-message regions of the neighbours' inboxes.
 __global__ void __launch_bounds__(256)
 k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z_lo, int z_hi, int has_down, int has_up, HaloArrays a,
-                float4 *send_down, float4 *send_up, int cap, int *counts, HaloPush push) {
+                float4 *send_down, float4 *send_up, int cap, int *counts) {
     const int n = n_dev ? *n_dev : n_host;
     const int i = blockIdx.x * 256 + threadIdx.x;
     int side = -1, dead = 0, xi = 0, mnew = 0, mrec = 0;
@@ -113,129 +108,116 @@ k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z
     const int k0 = halo_wave_slot(side == 0, &counts[0]);
     const int k1 = halo_wave_slot(side == 1, &counts[1]);
     halo_wave_slot(dead != 0, &counts[2]);
-    if (i < n) {
-        if (side >= 0) {
-            const int k = side == 0 ? k0 : k1;
-            if (k < cap) {
-                float4 *buf = side == 0 ? send_down : send_up;
-                const int rs = a.orig ? 4 : 3;
-                halo_write_record(buf, rs, k, p, a.velm[i], mrec, a.pid[i], a.color[i], a.rho[i]);
-                if (a.orig) buf[rs * k + 3] = a.orig[i];
-            }
-            const bool migrant = !META_GHOST(mrec);
-            xi = HALO_PACK((migrant ? HALO_ECHO_GHOST : HALO_SEND) + side, k);
+    if (i >= n) return;
+    if (side >= 0) {
+        const int k = side == 0 ? k0 : k1;
+        if (k < cap) {
+            float4 *buf = side == 0 ? send_down : send_up;
+            const int rs = a.orig ? 4 : 3;
+            halo_write_record(buf, rs, k, p, a.velm[i], mrec, a.pid[i], a.color[i], a.rho[i]);
+            if (a.orig) buf[rs * k + 3] = a.orig[i];
         }
-        if (dead) { mnew |= 1 << 12; xi = 0; }
-        a.meta[i] = mnew;
-        a.xidx[i] = xi;
+        const bool migrant = !META_GHOST(mrec);
+        xi = HALO_PACK((migrant ? HALO_ECHO_GHOST : HALO_SEND) + side, k);
     }
-    if (push.ticket && halo_last_workgroup(push.ticket) && threadIdx.x < 2 && push.ctl[threadIdx.x]) {
-        // every workgroup's records are visible system-wide (fence before its ticket): announce the message
-        HaloCtl *ctl = push.ctl[threadIdx.x];
-        const int cnt = __hip_atomic_load(&counts[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int st = push.dyn->status | (cnt > cap ? SLAB_ST_SEND_OVERFLOW : 0);
-        halo_store_sys(&ctl->rec_count, cnt);
-        halo_store_sys(&ctl->rec_status, st);
-        halo_store_sys(&ctl->rec_stride, push.stride);
-        __threadfence_system();
-        __hip_atomic_store(&ctl->rec_seq, push.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (dead) { mnew |= 1 << 12; xi = 0; }
+    a.meta[i] = mnew;
+    a.xidx[i] = xi;
 }
 
-// Receiver side of the step message: one wave; lane `side` waits for the neighbour's header (bounded: a neighbour that
-// never answers raises SLAB_ST_TIMEOUT instead of hanging the GPU), then lane 0 settles this step's counts in device
-// memory (SlabDyn) and mirrors them into pinned host memory -- the host may look at them, nothing waits for it.
-struct HaloWait {
-    const HaloCtl *ctl[2];   // my inbox control blocks (null: no neighbour on that side)
+// Step message, receiving side and settlement of the step's counts (see the protocol above).
+struct HaloStep {
+    HaloCtl *out_ctl[2];          // the neighbours' control blocks for messages from me (null: no neighbour on that side)
+    const HaloCtl *in_ctl[2];     // my inbox control blocks
+    const float4 *recv[2];        // my step-message regions for this message
     unsigned seq;
     int stride, cap, halo_cap;
-    int n_old;               // particle count before the exchange when the host knows it exactly, else -1: dyn->n_live
-    int bound_app, bound_live;   // launch bounds of an asynchronous step (0: the host launches exact grids afterwards)
-    long long timeout_ticks;     // of the 100 MHz wall clock
+    int n_old;                    // particle count before the exchange when the host knows it exactly, else -1: last step's n_live
+    int bound_app, bound_live;    // launch bounds of an asynchronous step (0: the host launches exact grids afterwards)
+    long long timeout_ticks;      // of the 100 MHz wall clock
+    const int *counts;            // what k_halo_classify just counted (bank seq & 1)
+    int *counts_next;             // the other bank: zeroed here for the next step's classify
+    const SlabDyn *dyn_old;       // last step's counts (bank (seq - 1) & 1)
+    SlabDyn *dyn_new;             // this step's (bank seq & 1); the status word only ever accumulates (sticky)
+    volatile SlabDyn *mirror;     // pinned host copy
 };
-__device__ __forceinline__ bool halo_poll(const unsigned *word, unsigned seq, long long timeout_ticks) {
-    const long long t0 = (long long)wall_clock64();
-    for (;;) {
-        const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((int)(v - seq) >= 0) return true;
-        if ((long long)wall_clock64() - t0 > timeout_ticks) return false;
-        __builtin_amdgcn_s_sleep(16);
-    }
-}
-__global__ void __launch_bounds__(64)
-k_halo_wait_rec(HaloWait w, int *counts, SlabDyn *dyn, volatile SlabDyn *mirror) {
-    const int lane = threadIdx.x;
-    int cnt = 0, st = 0;
-    if (lane < 2 && w.ctl[lane]) {
-        const HaloCtl *ctl = w.ctl[lane];
-        if (!halo_poll(&ctl->rec_seq, w.seq, w.timeout_ticks)) st |= SLAB_ST_TIMEOUT;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: the header and the records behind the number
-        if (!st) {
-            cnt = halo_load_sys(&ctl->rec_count);
-            if (halo_load_sys(&ctl->rec_status)) st |= SLAB_ST_PEER;
-            if (halo_load_sys(&ctl->rec_stride) != w.stride) st |= SLAB_ST_STRIDE;
-            if (cnt < 0 || cnt > w.halo_cap) { st |= SLAB_ST_PEER; cnt = 0; }
-        }
-    }
-    int r0 = __shfl(cnt, 0, 64), r1 = __shfl(cnt, 1, 64);
-    st = __shfl(st, 0, 64) | __shfl(st, 1, 64);
-    if (lane == 0) {
-        const int s0 = counts[0], s1 = counts[1], dropped = counts[2];
-        counts[0] = counts[1] = counts[2] = 0;   // the next classify starts from zero without a memset
-        st |= dyn->status;                        // sticky
-        if (s0 > w.halo_cap || s1 > w.halo_cap) st |= SLAB_ST_SEND_OVERFLOW;
-        const int n_old = w.n_old >= 0 ? w.n_old : dyn->n_live;
-        if (st) r0 = r1 = 0;                      // after a failure nothing is appended: every later kernel stays inside its arrays
-        if ((long long)n_old + r0 + r1 > (long long)w.cap) { st |= SLAB_ST_CAPACITY; r0 = r1 = 0; }
-        const int n_app = n_old + r0 + r1, n_live = n_app - dropped;
-        if (w.bound_app > 0 && (n_app > w.bound_app || n_live > w.bound_live)) st |= SLAB_ST_BOUND;
-        int longest = s0 > s1 ? s0 : s1;
-        longest = longest > r0 ? longest : r0; longest = longest > r1 ? longest : r1;
-        longest = longest > w.halo_cap ? w.halo_cap : longest;
-        dyn->n_app = n_app; dyn->n_live = n_live; dyn->n_send[0] = s0 > w.halo_cap ? w.halo_cap : s0; dyn->n_send[1] = s1 > w.halo_cap ? w.halo_cap : s1;
-        dyn->n_recv[0] = r0; dyn->n_recv[1] = r1; dyn->dropped = dropped; dyn->longest = longest; dyn->status = st; dyn->seq = w.seq;
-        if (mirror) {
-            mirror->n_app = n_app; mirror->n_live = n_live; mirror->n_send[0] = dyn->n_send[0]; mirror->n_send[1] = dyn->n_send[1];
-            mirror->n_recv[0] = r0; mirror->n_recv[1] = r1; mirror->dropped = dropped; mirror->longest = longest; mirror->status = st;
-            __threadfence_system();
-            mirror->seq = w.seq;   // written last: a host that reads seq, the counts, then seq again knows they belong together
-        }
-    }
-}
-
-// wait for a field message from each neighbour (numbers in lockstep with the sender's); a timeout goes into dyn->status
-__global__ void __launch_bounds__(64)
-k_halo_wait_fld(const HaloCtl *ctl0, const HaloCtl *ctl1, unsigned seq, long long timeout_ticks, SlabDyn *dyn, volatile SlabDyn *mirror) {
-    const int lane = threadIdx.x;
-    const HaloCtl *ctl = lane == 0 ? ctl0 : ctl1;
-    int st = 0;
-    if (lane < 2 && ctl && !halo_poll(&ctl->fld_seq, seq, timeout_ticks)) st = SLAB_ST_TIMEOUT;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    st = __shfl(st, 0, 64) | __shfl(st, 1, 64);
-    if (lane == 0 && st) { dyn->status |= st; if (mirror) mirror->status = dyn->status; }
-}
-
-// appends the records of both step messages behind the old particles (counts from SlabDyn) and empties the slot tables up to
-// the longest message of the step; grid-stride, so the grid is only a performance hint
 struct HaloTables { int *tab[8]; };
 __global__ void __launch_bounds__(256)
-k_halo_unpack2(const Consts c, const SlabDyn *__restrict__ dyn, int z_lo, int z_hi, const float4 *recv0, const float4 *recv1,
-               float4 *posv, float4 *velm, int *meta, int *pid, unsigned *color, float *rho, int *xidx, float4 *orig, HaloTables t) {
-    const int r0 = dyn->n_recv[0], r1 = dyn->n_recv[1];
-    const int n_old = dyn->n_app - r0 - r1;
+k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, float4 *velm, int *meta, int *pid, unsigned *color,
+               float *rho, int *xidx, float4 *orig, HaloTables t) {
+    __shared__ int s_v[6];   // r0, r1, n_old, longest, status
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        // my own header first (workgroup 0): a neighbour waiting for it is released before I start waiting for its
+        if (blockIdx.x == 0 && lane < 2 && w.out_ctl[lane]) {
+            HaloCtl *ctl = w.out_ctl[lane];
+            const int cnt = w.counts[lane];
+            halo_store_sys(&ctl->rec_count, cnt);
+            halo_store_sys(&ctl->rec_status, w.dyn_old->status | (cnt > w.halo_cap ? SLAB_ST_SEND_OVERFLOW : 0));
+            halo_store_sys(&ctl->rec_stride, w.stride);
+            __threadfence_system();
+            __hip_atomic_store(&ctl->rec_seq, w.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        int cnt = 0, st = 0;
+        if (lane < 2 && w.in_ctl[lane]) {
+            const HaloCtl *ctl = w.in_ctl[lane];
+            if (!halo_poll(&ctl->rec_seq, w.seq, w.timeout_ticks)) st |= SLAB_ST_TIMEOUT;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: the header and the records behind the number
+            if (!st) {
+                cnt = halo_load_sys(&ctl->rec_count);
+                if (halo_load_sys(&ctl->rec_status)) st |= SLAB_ST_PEER;
+                if (halo_load_sys(&ctl->rec_stride) != w.stride) st |= SLAB_ST_STRIDE;
+                if (cnt < 0 || cnt > w.halo_cap) { st |= SLAB_ST_PEER; cnt = 0; }
+            }
+        }
+        int r0 = __shfl(cnt, 0, 64), r1 = __shfl(cnt, 1, 64);
+        st = __shfl(st, 0, 64) | __shfl(st, 1, 64);
+        if (lane == 0) {
+            const int s0 = w.counts[0], s1 = w.counts[1], dropped = w.counts[2];
+            st |= w.dyn_old->status;                        // sticky
+            if (s0 > w.halo_cap || s1 > w.halo_cap) st |= SLAB_ST_SEND_OVERFLOW;
+            const int n_old = w.n_old >= 0 ? w.n_old : w.dyn_old->n_live;
+            if (st) r0 = r1 = 0;                            // after a failure nothing is appended: every later kernel stays inside its arrays
+            if ((long long)n_old + r0 + r1 > (long long)w.cap) { st |= SLAB_ST_CAPACITY; r0 = r1 = 0; }
+            const int n_app = n_old + r0 + r1, n_live = n_app - dropped;
+            if (w.bound_app > 0 && (n_app > w.bound_app || n_live > w.bound_live)) st |= SLAB_ST_BOUND;
+            int longest = s0 > s1 ? s0 : s1;
+            longest = longest > r0 ? longest : r0; longest = longest > r1 ? longest : r1;
+            longest = longest > w.halo_cap ? w.halo_cap : longest;
+            s_v[0] = r0; s_v[1] = r1; s_v[2] = n_old; s_v[3] = longest; s_v[4] = st;
+            // a workgroup that timed out while another did not would append a different set: every workgroup leaves its
+            // verdict in the status word, which the host (and the next header) sees
+            if (st) atomicOr(&w.dyn_new->status, st);
+            if (blockIdx.x == 0) {
+                SlabDyn *d = w.dyn_new;
+                d->n_app = n_app; d->n_live = n_live; d->n_send[0] = s0 > w.halo_cap ? w.halo_cap : s0; d->n_send[1] = s1 > w.halo_cap ? w.halo_cap : s1;
+                d->n_recv[0] = r0; d->n_recv[1] = r1; d->dropped = dropped; d->longest = longest; d->seq = w.seq;
+                w.counts_next[0] = w.counts_next[1] = w.counts_next[2] = 0;   // the next classify starts from zero without a memset
+                if (w.mirror) {
+                    volatile SlabDyn *m = w.mirror;
+                    m->n_app = n_app; m->n_live = n_live; m->n_send[0] = d->n_send[0]; m->n_send[1] = d->n_send[1];
+                    m->n_recv[0] = r0; m->n_recv[1] = r1; m->dropped = dropped; m->longest = longest; m->status = st;
+                    __threadfence_system();
+                    m->seq = w.seq;   // written last: a host that reads seq, the counts, then seq again knows they belong together
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int r0 = s_v[0], r1 = s_v[1], n_old = s_v[2];
     const int rs = orig ? 4 : 3;
     const int stride = (int)(gridDim.x * 256);
     for (int q = blockIdx.x * 256 + threadIdx.x; q < r0 + r1; q += stride) {
         const int side = q < r0 ? 0 : 1;
         const int k = side ? q - r0 : q;
-        const float4 *recv = side ? recv1 : recv0;
+        const float4 *recv = w.recv[side];
         const float4 p = recv[rs * k];
-        const float4 w = recv[rs * k + 2];
-        const int m = __float_as_int(w.x);
+        const float4 v4 = recv[rs * k + 2];
+        const int m = __float_as_int(v4.x);
         const int d = n_old + q;
         posv[d] = p; velm[d] = recv[rs * k + 1];
         if (orig) orig[d] = recv[rs * k + 3];
-        meta[d] = m; pid[d] = __float_as_int(w.y); color[d] = __float_as_uint(w.z); rho[d] = w.w;
+        meta[d] = m; pid[d] = __float_as_int(v4.y); color[d] = __float_as_uint(v4.z); rho[d] = v4.w;
         int xi;
         if (META_GHOST(m)) xi = HALO_PACK(HALO_GHOST + side, k);
         else {  // a migrant, now owned here; echo it back if it sits in my boundary layer facing the sender
@@ -245,7 +227,7 @@ k_halo_unpack2(const Consts c, const SlabDyn *__restrict__ dyn, int z_lo, int z_
         }
         xidx[d] = xi;
     }
-    const int longest = dyn->longest;
+    const int longest = s_v[3];
     for (int k = blockIdx.x * 256 + threadIdx.x; k < longest; k += stride) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) t.tab[q][k] = -1;
@@ -352,20 +334,23 @@ k_halo_unpack_vel(int n_recv, int n_send, const int *ghost_slots, const int *ech
     velm[s] = v;
 }
 
-// ---- field messages of the push transport: both sides in ONE launch, payload straight into the neighbours' inboxes, counts
-// from SlabDyn (grid-stride: the grid is a hint), header = the message number, published by the last workgroup.
+// ---- field messages of the push transport: both sides in ONE launch each way, payload straight into the neighbours' inboxes,
+// counts from SlabDyn (grid-stride: the grid is a hint).  k_halo_pack2 stores; k_halo_unpack2f announces (workgroup 0), waits
+// (every workgroup, bounded) and scatters -- see the protocol at the top.
 // KIND 0: one float (kappa, rho, p / rho^2 ...); 1: xyz of a float4 array (v, predicted x, cg_p; w stays); 2: the four
-// scalars that follow the density pass (rho_raw, rho, p, p / rho^2).  Layout of a message as above:
+// scalars that follow the density pass (rho_raw, rho, p, p / rho^2).  Layout of a message as for the other transports:
 // to `side`: [ my n_send records (send table) | the n_recv records I got from that side (echo-send table) ].
 struct HaloFld {
-    const SlabDyn *dyn;
+    SlabDyn *dyn;                                 // this step's counts
     const int *send_slots[2], *echo_slots[2];     // pack: tables HALO_SEND + side, HALO_ECHO_SEND + side
     const int *ghost_slots[2], *eghost_slots[2];  // unpack: tables HALO_GHOST + side, HALO_ECHO_GHOST + side
     void *out[2];          // the neighbours' field regions for this message (pack) / null
     const void *in[2];     // my own field regions (unpack)
-    HaloCtl *ctl[2];       // the neighbours' control blocks (pack)
+    HaloCtl *out_ctl[2];   // the neighbours' control blocks
+    const HaloCtl *in_ctl[2];
     unsigned seq;
-    int *ticket;
+    long long timeout_ticks;
+    volatile SlabDyn *mirror;
     float *f0, *f1, *f2, *f3;   // KIND 0: f0; KIND 2: rho_raw, rho, prs, ptm
     float4 *v;                  // KIND 1
 };
@@ -383,12 +368,33 @@ __global__ void __launch_bounds__(256) k_halo_pack2(HaloFld a) {
         else if (KIND == 1) ((float4 *)a.out[side])[k] = sl >= 0 ? a.v[sl] : make_float4(0.f, 0.f, 0.f, 0.f);
         else ((float4 *)a.out[side])[k] = sl >= 0 ? make_float4(a.f0[sl], a.f1[sl], a.f2[sl], a.f3[sl]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (halo_last_workgroup(a.ticket) && threadIdx.x < 2 && a.ctl[threadIdx.x])
-        __hip_atomic_store(&a.ctl[threadIdx.x]->fld_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// announce my field message (workgroup 0), then wait for the neighbours' (every workgroup); false after a time-out
+__device__ __forceinline__ bool halo_fld_handshake(HaloCtl *const out_ctl[2], const HaloCtl *const in_ctl[2], unsigned seq,
+                                                   long long timeout_ticks, SlabDyn *dyn, volatile SlabDyn *mirror) {
+    __shared__ int s_ok;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (blockIdx.x == 0 && lane < 2 && out_ctl[lane]) {
+            __threadfence_system();
+            __hip_atomic_store(&out_ctl[lane]->fld_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        int st = 0;
+        if (lane < 2 && in_ctl[lane] && !halo_poll(&in_ctl[lane]->fld_seq, seq, timeout_ticks)) st = SLAB_ST_TIMEOUT;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        st = __shfl(st, 0, 64) | __shfl(st, 1, 64);
+        if (lane == 0) {
+            s_ok = st == 0;
+            if (st) { atomicOr(&dyn->status, st); if (mirror) mirror->status = st; }
+        }
+    }
+    __syncthreads();
+    return s_ok != 0;
 }
 // message from `side`: [ its records = my n_recv (ghost table) | my n_send records (echo-ghost table) ]
 template <int KIND>
 __global__ void __launch_bounds__(256) k_halo_unpack2f(HaloFld a) {
+    if (!halo_fld_handshake(a.out_ctl, a.in_ctl, a.seq, a.timeout_ticks, a.dyn, a.mirror)) return;   // stale payload is not scattered
     const int ns0 = a.dyn->n_send[0], nr0 = a.dyn->n_recv[0], ns1 = a.dyn->n_send[1], nr1 = a.dyn->n_recv[1];
     const int t0 = a.in[0] ? ns0 + nr0 : 0, t1 = a.in[1] ? ns1 + nr1 : 0;
     const int stride = (int)(gridDim.x * 256);
@@ -411,17 +417,17 @@ __global__ void __launch_bounds__(256) k_halo_unpack2f(HaloFld a) {
     }
 }
 
-// transport self-test of the push path: pattern into the neighbours' field regions through the same publish / wait code
-__global__ void __launch_bounds__(256) k_halo_selftest_push(float *out0, float *out1, HaloCtl *ctl0, HaloCtl *ctl1, int n, int tag, unsigned seq, int *ticket) {
+// transport self-test of the push path: a pattern into the neighbours' field regions, then the same handshake and a check
+__global__ void __launch_bounds__(256) k_halo_selftest_push(float *out0, float *out1, int n, int tag) {
     const int stride = (int)(gridDim.x * 256);
     for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
         if (out0) out0[k] = (float)(tag * 1000 + (k % 997));
         if (out1) out1[k] = (float)(tag * 1000 + 500 + (k % 997));
     }
-    HaloCtl *ctl = threadIdx.x == 0 ? ctl0 : ctl1;
-    if (halo_last_workgroup(ticket) && threadIdx.x < 2 && ctl) __hip_atomic_store(&ctl->fld_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void __launch_bounds__(256) k_halo_selftest_check(const float *in0, const float *in1, int n, int tag0, int tag1, int *bad) {
+__global__ void __launch_bounds__(256) k_halo_selftest_check(HaloFld a, int n, int tag0, int tag1, int *bad) {
+    if (!halo_fld_handshake(a.out_ctl, a.in_ctl, a.seq, a.timeout_ticks, a.dyn, a.mirror)) { if (threadIdx.x == 0) atomicAdd(bad, 1 << 20); return; }
+    const float *in0 = (const float *)a.in[0], *in1 = (const float *)a.in[1];
     const int stride = (int)(gridDim.x * 256);
     int b = 0;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {

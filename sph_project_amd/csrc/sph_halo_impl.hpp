@@ -7,60 +7,64 @@ static inline char *inbox_rec(const State &s, char *inbox, int side, unsigned se
 static inline char *inbox_fld(const State &s, char *inbox, int side, unsigned seq) { return inbox + 2 * sizeof(HaloCtl) + 4 * s.push.rec_bytes + (size_t)(side * 2 + (seq & 1u)) * s.push.fld_bytes; }
 
 // in place: marks the particles this rank drops, tags the ones a neighbour needs and writes the two messages -- into the
-// local send buffers, or (push transport) straight into the neighbours' inboxes, announced by the kernel's last workgroup
+// local send buffers, or (push transport) straight into the step-message regions of the neighbours' inboxes
 static void l_halo_classify_pack(State &s, int n) {
     HaloArrays a{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(), s.xidx[s.xcur], s.orig.cur()};
-    HaloPush push{{nullptr, nullptr}, 0u, s.orig.cur() ? 4 : 3, nullptr, s.dyn};
     float4 *dst[2] = {s.sendbuf[0], s.sendbuf[1]};
+    int *counts = s.halo_counts;
+    const int *n_dev = nullptr;
     if (s.push.on) {
         const unsigned seq = ++s.push.rec_seq;
-        for (int side = 0; side < 2; ++side) {
-            if (!s.push.peer[side]) continue;
-            push.ctl[side] = inbox_ctl(s.push.peer[side], 1 - side);   // I am the neighbour's OTHER side
-            dst[side] = (float4 *)inbox_rec(s, s.push.peer[side], 1 - side, seq);
-        }
-        push.seq = seq; push.ticket = s.push.ticket;
+        for (int side = 0; side < 2; ++side)
+            if (s.push.peer[side]) dst[side] = (float4 *)inbox_rec(s, s.push.peer[side], 1 - side, seq);   // I am the neighbour's OTHER side
+        counts = s.halo_counts + 4 * (seq & 1u);   // zeroed by the previous step's k_halo_unpack2
+        if (s.async_counts) n_dev = &s.dyn[(seq - 1) & 1u].n_live;
+        if (n <= 0) return;
     } else {
-        hipMemsetAsync(s.halo_counts, 0, 4 * sizeof(int), s.stream);   // (push: the wait kernel leaves them zeroed)
+        hipMemsetAsync(s.halo_counts, 0, 4 * sizeof(int), s.stream);
         if (n <= 0) return;
     }
-    hipLaunchKernelGGL(k_halo_classify, dim3(cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, s.stream, s.c, n, s.async_counts ? &s.dyn->n_live : (const int *)nullptr,
-                       s.z_lo, s.z_hi, s.has_down, s.has_up, a, dst[0], dst[1], s.halo_cap, s.halo_counts, push);
-}
-
-static void l_halo_wait_rec(State &s, int n_old, int bound_app, int bound_live) {
-    HaloWait w;
-    for (int side = 0; side < 2; ++side) w.ctl[side] = s.push.peer[side] ? inbox_ctl(s.push.inbox, side) : nullptr;
-    w.seq = s.push.rec_seq; w.stride = s.orig.cur() ? 4 : 3; w.cap = s.cap; w.halo_cap = s.halo_cap;
-    w.n_old = n_old; w.bound_app = bound_app; w.bound_live = bound_live; w.timeout_ticks = s.push.timeout_ticks;
-    hipLaunchKernelGGL(k_halo_wait_rec, dim3(1), dim3(64), 0, s.stream, w, s.halo_counts, s.dyn, (volatile SlabDyn *)s.push.mirror);
+    hipLaunchKernelGGL(k_halo_classify, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, n, n_dev, s.z_lo, s.z_hi, s.has_down, s.has_up, a,
+                       dst[0], dst[1], s.halo_cap, counts);
 }
 
 static int halo_grid(int count_hint) {   // grid-stride kernels: enough workgroups for the hint, at least one, never a huge launch
     int g = cdiv(count_hint > 0 ? count_hint : 1, 256);
-    return g > 4096 ? 4096 : g;
+    return g > 2048 ? 2048 : g;
 }
 
-static void l_halo_unpack2(State &s, int count_hint) {
+static void l_halo_unpack2(State &s, int n_old, int bound_app, int bound_live, int count_hint) {
     HaloTables t;
     for (int k = 0; k < 8; ++k) t.tab[k] = s.halo_tab[k];
     const unsigned seq = s.push.rec_seq;
-    hipLaunchKernelGGL(k_halo_unpack2, dim3(halo_grid(count_hint)), dim3(256), 0, s.stream, s.c, s.dyn, s.z_lo, s.z_hi,
-                       (const float4 *)inbox_rec(s, s.push.inbox, 0, seq), (const float4 *)inbox_rec(s, s.push.inbox, 1, seq),
-                       s.posv.cur(), s.velm.cur(), s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(), s.xidx[s.xcur], s.orig.cur(), t);
+    HaloStep w;
+    for (int side = 0; side < 2; ++side) {
+        w.out_ctl[side] = s.push.peer[side] ? inbox_ctl(s.push.peer[side], 1 - side) : nullptr;
+        w.in_ctl[side] = s.push.peer[side] ? inbox_ctl(s.push.inbox, side) : nullptr;
+        w.recv[side] = (const float4 *)inbox_rec(s, s.push.inbox, side, seq);
+    }
+    w.seq = seq; w.stride = s.orig.cur() ? 4 : 3; w.cap = s.cap; w.halo_cap = s.halo_cap;
+    w.n_old = n_old; w.bound_app = bound_app; w.bound_live = bound_live; w.timeout_ticks = s.push.timeout_ticks;
+    w.counts = s.halo_counts + 4 * (seq & 1u); w.counts_next = s.halo_counts + 4 * ((seq + 1) & 1u);
+    w.dyn_old = s.dyn + ((seq - 1) & 1u); w.dyn_new = s.dyn + (seq & 1u);
+    w.mirror = (volatile SlabDyn *)s.push.mirror;
+    s.dyn_cur = s.dyn + (seq & 1u);
+    hipLaunchKernelGGL(k_halo_unpack2, dim3(halo_grid(count_hint)), dim3(256), 0, s.stream, s.c, w, s.z_lo, s.z_hi, s.posv.cur(), s.velm.cur(),
+                       s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(), s.xidx[s.xcur], s.orig.cur(), t);
 }
 
 static HaloFld halo_fld_args(State &s, unsigned seq, float *f0, float4 *v) {
     HaloFld a;
-    a.dyn = s.dyn;
+    a.dyn = s.dyn_cur;
     for (int side = 0; side < 2; ++side) {
         a.send_slots[side] = s.halo_tab[HALO_SEND - 1 + side]; a.echo_slots[side] = s.halo_tab[HALO_ECHO_SEND - 1 + side];
         a.ghost_slots[side] = s.halo_tab[HALO_GHOST - 1 + side]; a.eghost_slots[side] = s.halo_tab[HALO_ECHO_GHOST - 1 + side];
         a.out[side] = s.push.peer[side] ? (void *)inbox_fld(s, s.push.peer[side], 1 - side, seq) : nullptr;
         a.in[side] = s.push.peer[side] ? (const void *)inbox_fld(s, s.push.inbox, side, seq) : nullptr;
-        a.ctl[side] = s.push.peer[side] ? inbox_ctl(s.push.peer[side], 1 - side) : nullptr;
+        a.out_ctl[side] = s.push.peer[side] ? inbox_ctl(s.push.peer[side], 1 - side) : nullptr;
+        a.in_ctl[side] = s.push.peer[side] ? inbox_ctl(s.push.inbox, side) : nullptr;
     }
-    a.seq = seq; a.ticket = s.push.ticket;
+    a.seq = seq; a.timeout_ticks = s.push.timeout_ticks; a.mirror = (volatile SlabDyn *)s.push.mirror;
     a.f0 = f0; a.f1 = s.rho.cur(); a.f2 = s.prs; a.f3 = s.ptm; a.v = v;
     return a;
 }
@@ -72,11 +76,6 @@ static void l_halo_push_fields(State &s, int kind, float *f0, float4 *v, int cou
     else if (kind == 1) hipLaunchKernelGGL(k_halo_pack2<1>, g, b, 0, s.stream, a);
     else hipLaunchKernelGGL(k_halo_pack2<2>, g, b, 0, s.stream, a);
 }
-static void l_halo_wait_fld(State &s) {
-    hipLaunchKernelGGL(k_halo_wait_fld, dim3(1), dim3(64), 0, s.stream, s.push.peer[0] ? inbox_ctl(s.push.inbox, 0) : (const HaloCtl *)nullptr,
-                       s.push.peer[1] ? inbox_ctl(s.push.inbox, 1) : (const HaloCtl *)nullptr, s.push.fld_seq, s.push.timeout_ticks, s.dyn,
-                       (volatile SlabDyn *)s.push.mirror);
-}
 static void l_halo_pull_fields(State &s, int kind, float *f0, float4 *v, int count_hint) {
     HaloFld a = halo_fld_args(s, s.push.fld_seq, kind == 2 ? s.rho_raw : f0, v);
     const dim3 g(halo_grid(count_hint)), b(256);
@@ -84,18 +83,12 @@ static void l_halo_pull_fields(State &s, int kind, float *f0, float4 *v, int cou
     else if (kind == 1) hipLaunchKernelGGL(k_halo_unpack2f<1>, g, b, 0, s.stream, a);
     else hipLaunchKernelGGL(k_halo_unpack2f<2>, g, b, 0, s.stream, a);
 }
-// ring-free self-test: my pattern into both neighbours' field regions (as one field message), wait for theirs, check it
+// self-test: my pattern into both neighbours' field regions (as one field message), the handshake, then check theirs
 static void l_halo_selftest(State &s, int n, int tag, int tag_down, int tag_up, int *bad_dev) {
-    const unsigned seq = ++s.push.fld_seq;
-    float *out[2]; const float *in[2]; HaloCtl *ctl[2];
-    for (int side = 0; side < 2; ++side) {
-        out[side] = s.push.peer[side] ? (float *)inbox_fld(s, s.push.peer[side], 1 - side, seq) : nullptr;
-        in[side] = s.push.peer[side] ? (const float *)inbox_fld(s, s.push.inbox, side, seq) : nullptr;
-        ctl[side] = s.push.peer[side] ? inbox_ctl(s.push.peer[side], 1 - side) : nullptr;
-    }
-    hipLaunchKernelGGL(k_halo_selftest_push, dim3(halo_grid(n)), dim3(256), 0, s.stream, out[0], out[1], ctl[0], ctl[1], n, tag, seq, s.push.ticket);
-    l_halo_wait_fld(s);
-    hipLaunchKernelGGL(k_halo_selftest_check, dim3(halo_grid(n)), dim3(256), 0, s.stream, in[0], in[1], n, tag_down, tag_up, bad_dev);
+    if (!s.dyn_cur) s.dyn_cur = s.dyn;
+    HaloFld a = halo_fld_args(s, ++s.push.fld_seq, nullptr, nullptr);
+    hipLaunchKernelGGL(k_halo_selftest_push, dim3(halo_grid(n)), dim3(256), 0, s.stream, (float *)a.out[0], (float *)a.out[1], n, tag);
+    hipLaunchKernelGGL(k_halo_selftest_check, dim3(halo_grid(n)), dim3(256), 0, s.stream, a, n, tag_down, tag_up, bad_dev);
 }
 
 static void l_halo_unpack_append(State &s, int side, int count, int offset) {
@@ -107,6 +100,11 @@ static void l_halo_unpack_append(State &s, int side, int count, int offset) {
 
 static void l_halo_build_tables(State &s) {
     if (s.c.n == 0) return;
+    if (s.push.on) {   // k_halo_unpack2 emptied the tables; the per-workgroup prep kernel of this sort fills them (one launch less)
+        s.tables_pending = 1; s.perm_n = s.list_n = -1;
+        l_block_prep(s);
+        return;
+    }
     const int longest = s.push.on ? 0 : s.halo_longest;   // longest message of this step (push transport: k_halo_unpack2 reset the tables)
     if (longest > 0)
         hipLaunchKernelGGL(k_halo_tab_reset, dim3(cdiv(longest, 256)), dim3(256), 0, s.stream, longest, s.halo_tab[0], s.halo_tab[1],

@@ -46,8 +46,12 @@ void l_block_prep(State &s) {
     const int n = s.c.n;
     if (n == 0) return;
     const bool lst = !s.c.all_fluid && s.blk_list;
+    BlockPrepTables tabs;
+    for (int k = 0; k < 8; ++k) tabs.tab[k] = s.halo_tab[k];
+    const int *xi = (s.slab_active && s.tables_pending) ? s.xidx[s.xcur] : nullptr;   // push transport: slot tables built here (l_halo_build_tables)
+    s.tables_pending = 0;
     hipLaunchKernelGGL(k_block_prep, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.meta.cur(), s.cell_start,
-                       s.blk_hdr, s.lane_perm, lst ? s.blk_flag : nullptr);
+                       s.blk_hdr, s.lane_perm, lst ? s.blk_flag : nullptr, xi, tabs);
     if (lst) hipLaunchKernelGGL(k_compact_blocks, dim3(1), dim3(256), 0, s.stream, s.blk_flag, cdiv(n, 256), s.blk_list, s.blk_count);   // (tiles past the live count carry flag 0)
     s.list_n = lst ? n : -1;
     s.perm_n = n;
@@ -329,8 +333,8 @@ const Launch *SPH_LAUNCH_FN() {
         L.halo_pack_scalar = l_halo_pack_scalar; L.halo_unpack_scalar = l_halo_unpack_scalar;
         L.halo_pack_vel = l_halo_pack_vel; L.halo_unpack_vel = l_halo_unpack_vel;
         L.loop_criterion = l_loop_criterion;
-        L.halo_wait_rec = l_halo_wait_rec; L.halo_unpack2 = l_halo_unpack2; L.halo_push_fields = l_halo_push_fields;
-        L.halo_wait_fld = l_halo_wait_fld; L.halo_pull_fields = l_halo_pull_fields; L.halo_selftest = l_halo_selftest;
+        L.halo_unpack2 = l_halo_unpack2; L.halo_push_fields = l_halo_push_fields;
+        L.halo_pull_fields = l_halo_pull_fields; L.halo_selftest = l_halo_selftest;
         L.layer_hist = l_layer_hist;
         L.count_ghosts = l_count_ghosts;
         init = true;

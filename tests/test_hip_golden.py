@@ -105,12 +105,17 @@ def test_hip_matches_golden(gpu, path, fast_math):
                 ref = z[pre + key].astype(np.float64)
                 assert np.abs(ref).max() > 0
                 worst[key] = float(np.abs(mine[:ref.shape[0]].astype(np.float64) - ref).max() / np.abs(ref).max())
-        # limits = a few times the worst error any fixture shows in either build (relative to the field's maximum); the loose
-        # ones are quantities that cancel (D rho / Dt, kappa) or integrate a clamped iteration (PCISPH pressure)
-        lim = {"positions": 1e-5, "velocities": 5e-5, "densities": 2e-5, "rest_volumes": 5e-6, "masses": 5e-6, "alphas": 5e-5,
-               "densities_star": 1e-5, "cg_x": 2e-5, "kappa": 1e-3, "kappa_v": 1e-3, "densities_derivatives": 4e-3,
-               "pressures": 2e-3, "accelerations": 2e-3, "rigid_forces": 2e-5, "rigid_torques": 5e-5}
+        # PARITY limits (u = 2^-24): well-conditioned quantities -- sums of <= ~60 same-signed pair terms with ~20 roundings each
+        # (20 u * 1 ~ 1e-6 per particle; 2e-5 leaves room for pow() vs t*t*t near q = 1 and for the fast build's v_rcp / v_rsq),
+        # velocities / positions integrated from them over <= 30 steps (derivation: tests/test_big_golden.py).
+        parity = {"positions": 1e-5, "velocities": 5e-5, "densities": 2e-5, "rest_volumes": 5e-6, "masses": 5e-6, "alphas": 5e-5,
+                  "densities_star": 1e-5, "cg_x": 2e-5, "rigid_forces": 2e-5, "rigid_torques": 5e-5}
+        # REGRESSION GUARDS, not parity claims: quantities that cancel (D rho / Dt, kappa, accelerations: |sum| << sum |terms|) or
+        # amplify (p = 50000 ((rho/rho0)^7 - 1): a density difference times 7 * 50000 / max|p|).  Their error relative to the
+        # field's maximum is the conditioning of the scene, not of the code; the numbers below are a few times the worst error the
+        # fixtures show in either build ("limits fitted to pass") and are kept only to catch a formula that breaks.
+        guard = {"kappa": 1e-3, "kappa_v": 1e-3, "densities_derivatives": 4e-3, "pressures": 2e-3, "accelerations": 2e-3}
         for k, v in worst.items():
-            assert v < lim[k], (cp, k, v, worst)
+            assert v < parity.get(k, guard.get(k)), (cp, k, v, worst)
         slot_fluid, slot_fluid_step = z[pre + "materials"] == 1, cp
     print(os.path.basename(path), "fast" if fast_math else "strict", "final drift %.2e" % d, worst)
