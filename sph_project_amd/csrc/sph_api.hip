@@ -536,6 +536,14 @@ static void ph_neighbor_search(SphHandle *h) {
     h->sort_dirty = false;
 }
 
+// the same without the hash kernel: the push transport's classify / unpack kernels have hashed every particle already
+static void ph_sort_hashed(SphHandle *h) {
+    State &s = h->st;
+    { ProfScope p(h, SPH_K_SCAN); h->L->scan(s); }
+    { ProfScope p(h, SPH_K_SCATTER); if (h->prm.deterministic) h->L->scatter_stable(s); else h->L->scatter(s); }
+    h->sort_dirty = false;
+}
+
 static void ph_rigid_volume(SphHandle *h) {
     // base_solver.py:106.  The reference runs it at the end of every step() (:696) on the grid of that step's sort.
     // Static boundaries: the sum only involves same-object (static) particles, so the value computed once after the

@@ -652,7 +652,7 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
         c.est_recv = m.n_recv[0] + m.n_recv[1];
         h->n = m.n_app;
         refresh_counts(h);
-        ph_neighbor_search(h);
+        ph_sort_hashed(h);
         h->n = m.n_live;
         refresh_counts(h);
         s.halo_longest = m.longest;
@@ -695,7 +695,7 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
       h->L->halo_classify_pack(s, grid_n);
       h->L->halo_unpack2(s, -1, bound_app, bound_live, c.est_recv + c.est_recv / 4 + 4096); }   // (moves dyn_cur to this message's bank)
     h->n = bound_app; refresh_counts(h); s.c.n_dev = &s.dyn_cur->n_app;
-    ph_neighbor_search(h);
+    ph_sort_hashed(h);
     h->n = bound_live; refresh_counts(h); s.c.n_dev = &s.dyn_cur->n_live;
     c.bound_live = bound_live;
     { ProfScope p(h, SPH_K_HALO); h->L->halo_build_tables(s); }

@@ -80,9 +80,13 @@ __device__ __forceinline__ bool halo_poll(const unsigned *word, unsigned seq, lo
 // graveyard cell G behind every live particle, and the live count shrinks by counts[2].
 // counts[0] = records for the lower rank, counts[1] = upper rank, counts[2] = particles that died.
 // send_down / send_up: the local send buffers, or (push transport) the step-message regions of the neighbours' inboxes.
+// hash != null (push transport): the kernel is also this step's k_hash_count for the particles that are here already (cell id,
+// histogram, arrival rank; the dead ones into the graveyard cell G) -- both read the same positions, and the arrivals are hashed
+// by k_halo_unpack2 when they land.
+struct HaloHash { int *cellid, *rank, *cell_count; };
 __global__ void __launch_bounds__(256)
 k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z_lo, int z_hi, int has_down, int has_up, HaloArrays a,
-                float4 *send_down, float4 *send_up, int cap, int *counts) {
+                float4 *send_down, float4 *send_up, int cap, int *counts, HaloHash hash) {
     const int n = n_dev ? *n_dev : n_host;
     const int i = blockIdx.x * 256 + threadIdx.x;
     int side = -1, dead = 0, xi = 0, mnew = 0, mrec = 0;
@@ -108,6 +112,29 @@ k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z
     const int k0 = halo_wave_slot(side == 0, &counts[0]);
     const int k1 = halo_wave_slot(side == 1, &counts[1]);
     halo_wave_slot(dead != 0, &counts[2]);
+    if (hash.cellid) {   // k_hash_count (sph_device.hpp), same wave-aggregated atomics: one per run of equal cell ids
+        const int lane = threadIdx.x & 63;
+        int lin = -1 - lane;
+        if (i < n) {
+            if (dead) lin = c.G;
+            else {
+                const float4 q = a.posv[i];
+                lin = (cell_coord(q.x, c.grid_size, c.nx) * c.ny + cell_coord(q.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, q.z);
+            }
+            hash.cellid[i] = lin;
+        }
+        const int prev = __shfl_up(lin, 1, 64);
+        const bool head = lane == 0 || lin != prev;
+        const unsigned long long hm = __ballot(head);
+        const unsigned long long upto = hm & ((2ull << lane) - 1ull);
+        const int hl = 63 - __clzll(upto);
+        const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
+        const int len = above ? __ffsll(above) : 64 - lane;
+        int base = 0;
+        if (head && i < n) base = atomicAdd(&hash.cell_count[lin], len);
+        base = __shfl(base, hl, 64);
+        if (i < n) hash.rank[i] = base + (lane - hl);
+    }
     if (i >= n) return;
     if (side >= 0) {
         const int k = side == 0 ? k0 : k1;
@@ -144,7 +171,7 @@ struct HaloStep {
 struct HaloTables { int *tab[8]; };
 __global__ void __launch_bounds__(256)
 k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, float4 *velm, int *meta, int *pid, unsigned *color,
-               float *rho, int *xidx, float4 *orig, HaloTables t) {
+               float *rho, int *xidx, float4 *orig, HaloTables t, HaloHash hash) {
     __shared__ int s_v[6];   // r0, r1, n_old, longest, status
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
@@ -226,6 +253,11 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
             xi = cz == edge ? HALO_PACK(HALO_ECHO_SEND + side, k) : 0;
         }
         xidx[d] = xi;
+        if (hash.cellid) {   // the arrival's share of this step's k_hash_count
+            const int lin = (cell_coord(p.x, c.grid_size, c.nx) * c.ny + cell_coord(p.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, p.z);
+            hash.cellid[d] = lin;
+            hash.rank[d] = atomicAdd(&hash.cell_count[lin], 1);
+        }
     }
     const int longest = s_v[3];
     for (int k = blockIdx.x * 256 + threadIdx.x; k < longest; k += stride) {
