@@ -191,8 +191,8 @@ BIG_SCENES = {
     # the same 16^3 block packed tighter than the rest spacing (rho > rho0 from step 0): the solver loops iterate
     "dfsph_4k_compressed": (dam_break_scene(method="dfsph", end=(0.287, 0.287, 0.287), particleSpacing=0.0185, dt=6e-4,
                                             velocity=(0.1, -0.5, 0.0)), 0.002, 74, [1, 2, 4, 6]),
-    "pcisph_4k_compressed": (dam_break_scene(method="pcisph", end=(0.287, 0.287, 0.287), particleSpacing=0.0185, dt=4e-4,
-                                             velocity=(0.1, -0.5, 0.0)), 0.002, 75, [1, 2, 4, 6]),
+    "pcisph_4k_compressed": (dam_break_scene(method="pcisph", end=(0.256, 0.256, 0.256), particleSpacing=0.0165, dt=4e-4,
+                                             velocity=(0.1, -0.5, 0.0)), 0.0015, 75, [1, 2, 4, 6]),
 }
 LEAN_KEYS = ("ids", "positions", "velocities", "densities", "pressures", "materials", "iter_v", "iter_d", "iter_pci", "iter_cg")
 ITER_PATTERNS = (("iter_v", r"DFSPH - iteration V: (\d+)"), ("iter_d", r"DFSPH - iterations: (\d+)"),

@@ -452,9 +452,12 @@ static int push_setup(SphHandle *h) {
     void *inbox = nullptr;
     // memory the other device writes and this one polls: uncached / fine-grained where the runtime offers it (what RCCL uses
     // for its own flags), plain device memory otherwise (enough between two ranks of ONE device)
+    int inbox_kind = 0;   // 0 uncached, 1 fine-grained, 2 plain (coherent only between two ranks of ONE device)
     hipError_t e = hipExtMallocWithFlags(&inbox, bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&inbox, bytes, hipDeviceMallocFinegrained); }
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&inbox, bytes); }
+    if (e != hipSuccess) { (void)hipGetLastError(); inbox_kind = 1; e = hipExtMallocWithFlags(&inbox, bytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { (void)hipGetLastError(); inbox_kind = 2; e = hipMalloc(&inbox, bytes); }
+    char busid[32] = "";
+    if (hipDeviceGetPCIBusId(busid, sizeof(busid), h->device) != hipSuccess) { (void)hipGetLastError(); snprintf(busid, sizeof(busid), "dev%d-pid%d", h->device, (int)getpid()); }
     if (e != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "inbox allocation of %zu bytes: %s", bytes, hipGetErrorString(e)); (void)hipGetLastError(); }
     hipIpcMemHandle_t mine;
     memset(&mine, 0, sizeof(mine));
@@ -467,9 +470,11 @@ static int push_setup(SphHandle *h) {
     if (hipHostMalloc((void **)&s.push.mirror, sizeof(SlabDyn), hipHostMallocDefault) != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "pinned mirror"); (void)hipGetLastError(); }
     else memset(s.push.mirror, 0, sizeof(SlabDyn));
     // handles to the neighbours (even a rank that failed so far takes part: the exchange is collective)
-    struct Hello { unsigned magic; int ok; int rank; int pad; hipIpcMemHandle_t handle; } hello_out, hello_in[2];
+    struct Hello { unsigned magic; int ok; int rank; int inbox_kind; char busid[32]; hipIpcMemHandle_t handle; } hello_out, hello_in[2];
     static_assert(sizeof(Hello) <= 256, "hello message");
-    hello_out.magic = 0x53504831u; hello_out.ok = ok; hello_out.rank = c.rank; hello_out.pad = 0; hello_out.handle = mine;
+    memset(&hello_out, 0, sizeof(hello_out));
+    hello_out.magic = 0x53504831u; hello_out.ok = ok; hello_out.rank = c.rank; hello_out.inbox_kind = inbox_kind; hello_out.handle = mine;
+    memcpy(hello_out.busid, busid, sizeof(hello_out.busid));
     memset(hello_in, 0, sizeof(hello_in));
     if (c.nranks > 1) {
         for (int side = 0; side < 2; ++side) HIPCHK(h, hipMemcpy(s.sendbuf[side], &hello_out, sizeof(Hello), hipMemcpyHostToDevice));
@@ -485,6 +490,12 @@ static int push_setup(SphHandle *h) {
             HIPCHK(h, hipMemcpy(&hello_in[side], s.recvbuf[side], sizeof(Hello), hipMemcpyDeviceToHost));
             if (hello_in[side].magic != 0x53504831u || hello_in[side].rank != peer[side]) { ok = 0; snprintf(why, sizeof(why), "bad hello from rank %d", peer[side]); continue; }
             if (!hello_in[side].ok || !ok) { ok = 0; continue; }
+            // plain (cached) device memory is only coherent between two ranks that share ONE device; across devices the
+            // inbox must be uncached / fine-grained on both ends, or remotely written lines may be read stale out of the L2
+            const bool same_device = !memcmp(hello_in[side].busid, busid, sizeof(busid));
+            if (!same_device && (inbox_kind == 2 || hello_in[side].inbox_kind == 2)) {
+                ok = 0; snprintf(why, sizeof(why), "no uncached / fine-grained device memory for an inbox shared with rank %d on another GPU", peer[side]); continue;
+            }
             void *mapped = nullptr;
             e = hipIpcOpenMemHandle(&mapped, hello_in[side].handle, hipIpcMemLazyEnablePeerAccess);
             if (e != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "hipIpcOpenMemHandle(rank %d): %s", peer[side], hipGetErrorString(e)); (void)hipGetLastError(); continue; }
@@ -520,6 +531,9 @@ static int push_setup(SphHandle *h) {
     char base[24];
     snprintf(base, sizeof(base), "%s", c.transport);
     snprintf(c.transport, sizeof(c.transport), "ipc-push+%s", base);
+    if (getenv("SPH_COMM_VERBOSE"))
+        fprintf(stderr, "[libsph_hip] rank %d on %s: push transport up (inbox %.1f MB, %s device memory)\n", c.rank, busid, bytes / 1e6,
+                inbox_kind == 0 ? "uncached" : (inbox_kind == 1 ? "fine-grained" : "plain"));
     return SPH_OK;
 }
 

@@ -605,6 +605,37 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
     unsigned ca = a0;
     int cq = q0;
     const unsigned tile = lds_addr(sXY);
+#ifdef SPH_P2_PAIR2
+    // A/B variant (tools/experiments): two accepted neighbours of a run per trip -- all their LDS reads issued before the first
+    // pair is evaluated, half the loop control.  Order of accumulation unchanged (first, then second).
+    while (cur) {
+        const int t = (sizeof(M) == 8 ? __ffsll((long long)cur) : __ffs((int)cur)) - 1;
+        cur &= cur - 1;
+        const bool two = cur != 0;
+        const int t2 = two ? (sizeof(M) == 8 ? __ffsll((long long)cur) : __ffs((int)cur)) - 1 : t;
+        if (two) cur &= cur - 1;
+        const unsigned ad = ca + ((unsigned)t << 3), ad2 = ca + ((unsigned)t2 << 3);
+        const float2 xy = lds_ld2a(tile + ad), zw = lds_ld2a(tile + ad + ZW_OFF);
+        const float2 xy2 = lds_ld2a(tile + ad2), zw2 = lds_ld2a(tile + ad2 + ZW_OFF);
+        typename P::BT bj = typename P::BT(), bj2 = typename P::BT();
+        if (P::HAS_B) { bj = sB[ad >> 3]; bj2 = sB[ad2 >> 3]; }
+        typename PassC<P>::type cj = typename PassC<P>::type(), cj2 = typename PassC<P>::type();
+        if (PassC<P>::value) { cj = sC[ad >> 3]; cj2 = sC[ad2 >> 3]; }
+        {
+            const float dx = xi - xy.x, dy = yi - xy.y, dz = zi - zw.x;
+            int j = 0;
+            if (UJ) j = (int)(ad >> 3) - s_loff3[cq];
+            pass_pair(p, c, own, dx, dy, dz, dx * dx + dy * dy + dz * dz, make_float4(xy.x, xy.y, zw.x, zw.y), bj, cj, j);
+        }
+        if (two) {
+            const float dx = xi - xy2.x, dy = yi - xy2.y, dz = zi - zw2.x;
+            int j = 0;
+            if (UJ) j = (int)(ad2 >> 3) - s_loff3[cq];
+            pass_pair(p, c, own, dx, dy, dz, dx * dx + dy * dy + dz * dz, make_float4(xy2.x, xy2.y, zw2.x, zw2.y), bj2, cj2, j);
+        }
+        if (cur == 0) { cur = m1; ca = a1; m1 = m2; a1 = a2; m2 = 0; if (UJ) { cq = q1; q1 = q2; } }
+    }
+#else
     while (cur) {
         const int t = (sizeof(M) == 8 ? __ffsll((long long)cur) : __ffs((int)cur)) - 1;
         cur &= cur - 1;
@@ -622,6 +653,7 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
         pass_pair(p, c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, cj, j);
         if (cur == 0) { cur = m1; ca = a1; m1 = m2; a1 = a2; m2 = 0; if (UJ) { cq = q1; q1 = q2; } }
     }
+#endif
 }
 
 // Per-workgroup data prepared once per sort (k_block_prep), read by every neighbour pass of the sort epoch:
