@@ -91,6 +91,22 @@ struct CgPreparePass {
     }
 };
 
+// ---- one CG iteration in three launches (A p pass, x / r update, p update) instead of six: the kernels that consume a dot
+// product finish the reduction themselves -- every workgroup adds up the per-workgroup partials in the same fixed order, so
+// all of them hold the same alpha / beta -- and workgroup 0 of the p update does the loop's book-keeping (error, iteration
+// count, stop flag).  Partials: rr[2] (|r|^2, ping-pong: the x / r update reads one and writes the other), den (p . Ap, from
+// the A p pass), rold (|r|^2 before the update, the denominator of beta).
+__device__ __forceinline__ float cg_total(const float *part, int nb, const int *blk_list, const int *blk_count, float *s4) {
+    float a = 0.f;
+    if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) a += part[blk_list[k]]; }
+    else for (int k = threadIdx.x; k < nb; k += 256) a += part[k];
+    a = wave_sum(a);
+    __syncthreads();   // s4 may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = a;
+    __syncthreads();
+    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+
 // base_solver.py:374 compute_Ap (+task :386)
 // Bytes / particle: R posv 16 + m 4 + rho 4 + dinv 36 + p 16 -> W Ap 16.
 template <bool AF>
@@ -102,15 +118,45 @@ struct CgApPass {
     static constexpr bool HAS_REDUCE = true;   // per-workgroup partial of p . Ap (the denominator of alpha, :394): no separate dot kernel
     static constexpr int PAIR_WEIGHT = 1;
     static constexpr bool SPLIT3 = true;       // see PassSplit / k_cg_ap_combine
+    static constexpr bool HAS_PROLOGUE = true;
     typedef float4 BT;
     struct Own { float m; float d[9]; float x, y, z; };
     const float4 *posv, *velm; const int *meta; const float *rho; const float4 *cg_p; const float *dinv;
     float4 *cg_Ap; float *red_out;
     float4 *part; int part_stride;             // [3][part_stride] partial sums of a split launch
+    // fuse != 0: update_p (base_solver.py:434) of the PREVIOUS iteration happens here, on the fly: p = r + beta p_old for every
+    // staged neighbour and for the own particle (written to p_out: other workgroups still read p_old), beta = |r_new|^2 / |r_old|^2
+    // reduced by every workgroup from the x / r update's per-workgroup partials (fixed order: all hold the same value) -- one
+    // launch per CG iteration less.  Workgroup (0, 0) also keeps the loop's books for that previous iteration (:445 `while tol > 1e-6`).
+    const float4 *cg_r; float4 *p_out; const float *part_num, *part_den; int nb_part; const int *pl_list, *pl_count;
+    int fuse, looped; float tol;
+    mutable float beta;
+    __device__ bool prologue(DevScalars *scal) const {
+        beta = 0.0f;
+        if (!fuse) return true;
+        __shared__ float s4[4];
+        const float num = cg_total(part_num, nb_part, pl_list, pl_count, s4);
+        const float den = cg_total(part_den, nb_part, pl_list, pl_count, s4);
+        beta = den > 1e-18f ? num / den : 0.0f;
+        const float err = __builtin_sqrtf(num);
+        const bool done = looped && !(err > tol);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            scal->red[5] = beta; scal->red[3] = err;   // cg_beta, cg_error
+            if (done) scal->flags[0] = 1;              // the kernels behind this one (and later iterations) see it at their top
+        }
+        return !done;
+    }
+    __device__ float4 own_p(int i) const {
+        float4 q = cg_p[i];
+        if (fuse) { const float4 r = cg_r[i]; q = make_float4(r.x + beta * q.x, r.y + beta * q.y, r.z + beta * q.z, 0.f); p_out[i] = q; }
+        return q;
+    }
     __device__ void partial(const Consts &, int i, int g, const Own &o) const { part[(size_t)g * part_stride + i] = make_float4(o.x, o.y, o.z, 0.f); }
 
     __device__ float4 stage_impl(int j, BT &bj) const {
-        const float4 p = posv[j], q = cg_p[j];
+        const float4 p = posv[j];
+        float4 q = cg_p[j];
+        if (fuse) { const float4 r = cg_r[j]; q.x = r.x + beta * q.x; q.y = r.y + beta * q.y; q.z = r.z + beta * q.z; }
         const float m = velm[j].w;
         const bool fl = AF || META_MAT(meta[j]) == 1;
         bj = make_float4(q.x, q.y, q.z, fl ? rho[j] : -1.0f);
@@ -160,7 +206,7 @@ struct CgApPass {
 #endif
     }
     __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {
-        const float4 p = cg_p[i];
+        const float4 p = own_p(i);
         float x = o.x * c.dt, y = o.y * c.dt, z = o.z * c.dt;
         x = fdiv(x, c.rho0); y = fdiv(y, c.rho0); z = fdiv(z, c.rho0);
         const float4 a = make_float4(x + p.x, y + p.y, z + p.z, 0.f);
@@ -219,33 +265,25 @@ k_cg_dots(int n, const int *meta, int all_fluid, const float4 *r, const float4 *
     block_sum2(num, den, part_a, part_b, blk);
 }
 
-// ---- one CG iteration in three launches (A p pass, x / r update, p update) instead of six: the kernels that consume a dot
-// product finish the reduction themselves -- every workgroup adds up the per-workgroup partials in the same fixed order, so
-// all of them hold the same alpha / beta -- and workgroup 0 of the p update does the loop's book-keeping (error, iteration
-// count, stop flag).  Partials: rr[2] (|r|^2, ping-pong: the x / r update reads one and writes the other), den (p . Ap, from
-// the A p pass), rold (|r|^2 before the update, the denominator of beta).
-__device__ __forceinline__ float cg_total(const float *part, int nb, const int *blk_list, const int *blk_count, float *s4) {
-    float a = 0.f;
-    if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) a += part[blk_list[k]]; }
-    else for (int k = threadIdx.x; k < nb; k += 256) a += part[k];
-    a = wave_sum(a);
-    __syncthreads();   // s4 may still be read from a previous call
-    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = a;
-    __syncthreads();
-    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
-}
-
 // second half of a split A p pass (CgApPass::SPLIT3): adds the three per-group parts, then CgApPass::finish + its partial of p . Ap
 __global__ void __launch_bounds__(256)
 k_cg_ap_combine(const Consts c, const int *meta, int all_fluid, const float4 *part, int stride, const float4 *p, float4 *Ap,
-                float *part_den, const int *stop_flag, const int *blk_list, const int *blk_count) {
+                float *part_den, const int *stop_flag, const int *blk_list, const int *blk_count, const float4 *r_fuse, float4 *p_out,
+                const DevScalars *scal) {
     if (stop_flag && *stop_flag) return;
     const int blk = cg_block(blk_list, blk_count);
     if (blk < 0) return;
     const int i = blk * 256 + threadIdx.x;
     float dot = 0.f;
     if (i < live_n(c) && is_fluid(meta, i, all_fluid)) {
-        const float4 a0 = part[i], a1 = part[(size_t)stride + i], a2 = part[2 * (size_t)stride + i], pp = p[i];
+        const float4 a0 = part[i], a1 = part[(size_t)stride + i], a2 = part[2 * (size_t)stride + i];
+        float4 pp = p[i];
+        if (r_fuse) {   // fused p update (CgApPass::fuse): beta was reduced and published by the A p pass in front of this kernel
+            const float beta = scal->red[5];
+            const float4 r = r_fuse[i];
+            pp = make_float4(r.x + beta * pp.x, r.y + beta * pp.y, r.z + beta * pp.z, 0.f);
+            p_out[i] = pp;
+        }
         float x = ((a0.x + a1.x) + a2.x) * c.dt, y = ((a0.y + a1.y) + a2.y) * c.dt, z = ((a0.z + a1.z) + a2.z) * c.dt;
         x = fdiv(x, c.rho0); y = fdiv(y, c.rho0); z = fdiv(z, c.rho0);
         const float4 a = make_float4(x + pp.x, y + pp.y, z + pp.z, 0.f);
@@ -271,11 +309,25 @@ k_cg_fold(int nb, const float *part_a, const float *part_b, float *out_a, float 
     if (part_b) { const float b = cg_total(part_b, nb, blk_list, blk_count, s4); if (threadIdx.x == 0) *out_b = b; }
 }
 
+// fused p update: the stop test of an iteration is otherwise made by the NEXT A p pass; at the end of a batch of launches this one
+// workgroup makes it, so that the host's flag read-back sees a convergence reached in the batch's last iteration
+__global__ void __launch_bounds__(256)
+k_cg_check(int nb, const float *part_rr, DevScalars *scal, float tol, const int *blk_list, const int *blk_count) {
+    if (scal->flags[0]) return;
+    __shared__ float s4[4];
+    const float num = cg_total(part_rr, nb, blk_list, blk_count, s4);
+    if (threadIdx.x == 0) {
+        const float err = __builtin_sqrtf(num);
+        scal->red[3] = err;
+        if (!(err > tol)) scal->flags[0] = 1;
+    }
+}
+
 // :394 compute_cg_alpha + :409 update_cg_x + :415 update_cg_r_and_beta (partials)
 __global__ void __launch_bounds__(256)
 k_cg_update_xr2(int n, int nb, const int *meta, int all_fluid, float4 *x, float4 *r, const float4 *p, const float4 *Ap,
                 const float *part_rr, const float *part_den, float *part_rr_next, float *part_rold, DevScalars *scal,
-                const int *stop_flag, const int *blk_list, const int *blk_count, const float *glob) {
+                const int *stop_flag, const int *blk_list, const int *blk_count, const float *glob, int count_iteration) {
     if (stop_flag && *stop_flag) return;
     const int blk = cg_block(blk_list, blk_count);
     if (blk < 0) return;
@@ -283,7 +335,7 @@ k_cg_update_xr2(int n, int nb, const int *meta, int all_fluid, float4 *x, float4
     const float num_a = glob ? glob[0] : cg_total(part_rr, nb, blk_list, blk_count, s4);
     const float den_a = glob ? glob[1] : cg_total(part_den, nb, blk_list, blk_count, s4);
     const float alpha = den_a > 1e-18f ? num_a / den_a : 0.0f;     // :403
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal->red[4] = alpha;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scal->red[4] = alpha; if (count_iteration) scal->flags[1] += 1; }   // (fused p update: this kernel ends the iteration)
     int i = blk * 256 + threadIdx.x;
     float num = 0.f, den = 0.f;
     if (i < n && is_fluid(meta, i, all_fluid)) {

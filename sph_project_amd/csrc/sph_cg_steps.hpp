@@ -21,13 +21,24 @@ static int implicit_viscosity_non_pressure(SphHandle *h) {
         { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_fold(s, which); }
         comm_rc = which == 1 ? slab_allreduce_dev(h, &s.scal->red[7], 1) : slab_allreduce_dev(h, &s.scal->red[6], which == 0 ? 1 : 2);
     };
+    // One CG iteration = A p pass (+ combine when split), x / r update, p update.  Unsharded, the p update is folded into the
+    // NEXT iteration's A p pass (CgApPass::fuse: p = r + beta p_old on the fly while staging; beta, the error and the stop flag
+    // come from the x / r update's partials): two or three launches per iteration instead of three or four.  Sharded, the
+    // ghosts' p has to exist in memory to be exchanged, so the p update stays a kernel of its own.
+    static const char *no_fuse = getenv("SPH_NO_CG_FUSED_P");
+    const bool fused = !slab && !no_fuse && s.cg_p2;
+    s.cg_fused_loop = fused ? 1 : 0;
+    bool first = true;
     auto iteration = [&]() {
         refresh(s.cg_p);
+        s.cg_fuse = (fused && !first) ? 1 : 0;
         { ProfScope p(h, SPH_K_CG_AP); h->L->cg_ap(s); }
+        s.cg_fuse = 0;
         dots(1);
         { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_update_xr(s); }
         dots(2);
-        { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_update_p(s); }
+        if (!fused) { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_update_p(s); }
+        first = false;
     };
     { ProfScope p(h, SPH_K_CG_PREPARE); h->L->cg_prepare(s); }                     // :510
     refresh(s.cg_p);                                                               // the ghosts' initial guess
@@ -39,13 +50,14 @@ static int implicit_viscosity_non_pressure(SphHandle *h) {
     const int max_itr = fixed > 0 ? fixed : 1000;
     if (fixed <= 0) {   // :445 conjugate_gradient_loop, stop test on the device (see device_loop)
         int launched = 0;
-        int rc = device_loop(h, max_itr, 3, 3, 1.0f, 1e-6, iteration, &itr, &launched, &tol);
+        int rc = device_loop(h, max_itr, 3, 3, 1.0f, 1e-6, iteration, &itr, &launched, &tol, fused ? h->L->cg_check : nullptr);
         if (rc) return rc;
     }
     while (fixed > 0 && itr < max_itr) {
         iteration();
         itr++;
     }
+    s.cg_fused_loop = 0;
     if (comm_rc) return comm_rc;
     refresh(s.cg_x);                                                               // solved velocities of the ghosts (:514)
     if (comm_rc) return comm_rc;

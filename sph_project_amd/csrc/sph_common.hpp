@@ -136,6 +136,9 @@ struct State {
     float4 *pacc, *pvel, *ppos, *acc_np;
     // CG (implicit viscosity)
     float4 *cg_p, *cg_Ap, *cg_x, *cg_b, *cg_r, *cg_v0;
+    float4 *cg_p2;       // second search-direction buffer (fused p update: the A p pass reads the old one and writes the new one)
+    int cg_fuse;         // the next A p pass applies the previous iteration's p update on the fly (CgApPass::fuse)
+    int cg_fused_loop;   // this solve runs the two-launch iteration (A p [+ combine], x / r update)
     float *cg_dinv;      // 9 floats per particle
     float4 *cg_part;     // 3 x cap: per-group parts of A p when the pass is split (CgApPass::SPLIT3)
     int cg_split;        // this solve splits its A p passes (few fluid particles: see implicit_viscosity_non_pressure)
@@ -210,6 +213,7 @@ struct Launch {
     void (*clear_fresh)(State &);
     // DFSPH
     void (*dfsph_density_alpha)(State &);
+    void (*dfsph_density_alpha_div)(State &);   // + the first density derivative of the divergence solve (one neighbour walk less per step)
     void (*dfsph_rho_adv)(State &, int mode);   // 0: density derivative (+kappa_v), 1: density star (+kappa)
     void (*dfsph_correct)(State &, int mode);   // 0: divergence step, 1: density step
     void (*advect_boundary)(State &);           // x += dt v, emitter, boundary (DFSPH position update)
@@ -241,6 +245,7 @@ struct Launch {
     void (*cg_ap)(State &);
     void (*cg_prepare2)(State &);
     void (*cg_alpha)(State &);
+    void (*cg_check)(State &);   // fused p update: stop test at the end of a batch of iterations
     void (*cg_update_xr)(State &);
     void (*cg_update_p)(State &);
     void (*cg_prepare_guess)(State &);

@@ -419,6 +419,12 @@ template <class P> struct PassModes<P, decltype((void)P::MODES)> { static conste
 template <class P> constexpr bool pass_builds_masks() { return (PassModes<P>::value & 0b010) != 0; }
 template <class P> constexpr bool pass_reuses_masks() { return (PassModes<P>::value & 0b100) != 0; }
 
+// P::HAS_PROLOGUE: the functor has `bool prologue(DevScalars *) const`, run by every thread of a workgroup before anything else
+// (it may use barriers and set `mutable` members, e.g. a coefficient every workgroup reduces from per-workgroup partials);
+// false = this workgroup has nothing to do.
+template <class P, class = void> struct PassPrologue { static constexpr bool value = false; };
+template <class P> struct PassPrologue<P, decltype((void)P::HAS_PROLOGUE)> { static constexpr bool value = P::HAS_PROLOGUE; };
+
 // Optional second per-candidate payload (P::HAS_C, P::CT): staged into its own LDS array; stage() and pair() of
 // such a functor take it as one more argument.
 template <class P, class = void> struct PassC { static constexpr bool value = false; typedef int type; };
@@ -823,6 +829,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
 
     const int tid = threadIdx.x;
     NBR_STAMP(0);
+    if constexpr (PassPrologue<P>::value) { if (!p.prologue(scal)) return; }   // workgroup-uniform
     const int b = blk_list ? blk_list[blockIdx.x] : xcd_remap(blockIdx.x, nblocks);
     const int i0 = b * BLOCK;
     const int n_live = live_n(c);

@@ -56,6 +56,71 @@ struct DfsphDensityAlphaPass {
 };
 
 // ---------------------------------------------------------------------------------------
+// The three neighbour sums that follow DFSPH's end-of-step sort in ONE walk: compute_density (base_solver.py:522), compute_alpha
+// (DFSPH.py:23) and the compute_density_derivative that opens correct_divergence_error (DFSPH.py:66, :140) -- the first depends on
+// the positions only, the third on positions and velocities, none on the results of the others (kappa_v = D rho / Dt * alpha is
+// per particle: finish()).  One pass less per step than DfsphDensityAlphaPass + DfsphRhoAdvPass<0> (same arithmetic, same order).
+// Bytes / particle: R posv 16 + velm 16 -> W rho 4 + alpha 4 + D rho / Dt 4 + kappa_v 4.
+template <bool AF>
+struct DfsphDensityAlphaDivPass {
+    static constexpr int MODES = 0b011;               // first pass after a sort: computes and stores the acceptance masks
+    static constexpr bool FLUID_BLOCKS_ONLY = true;
+    static constexpr int BLOCK = 256, GROUPS = 3;
+    static constexpr bool USES_J = !AF;
+    static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = true;
+    static constexpr int PAIR_WEIGHT = 3;             // density + alpha + density-derivative passes of the reference
+    struct BT { float x, y, z; };                     // v_j
+    struct Own { float sum, s3, gx, gy, gz, vx, vy, vz, dsum; int cnt; };
+    const float4 *posv, *velm; const int *meta; float *rho, *alpha, *out_adv, *out_kappa; float *red_out;
+
+    __device__ float4 stage_impl(int j, BT &bj) const {
+        float4 p = ldg_idx(posv, j);
+        const float4 v = ldg_idx(velm, j);
+        bj.x = v.x; bj.y = v.y; bj.z = v.z;
+        if (!AF && META_MAT(meta[j]) != 1) p.w = -p.w;
+        return p;
+    }
+    __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
+    __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
+    __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
+        o.sum = o.s3 = o.gx = o.gy = o.gz = o.dsum = 0.0f; o.cnt = 0;
+        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
+        const float4 v = velm[i];
+        o.vx = v.x; o.vy = v.y; o.vz = v.z;
+        return true;
+    }
+    __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a, const BT &bj, int) const {
+        const Geom g = geom(c, r2);
+        const float V = fabsf(a.w);
+        o.sum += V * kernW(c, g);
+        float gx, gy, gz;
+        kernGrad(c, dx, dy, dz, g, gx, gy, gz);
+        const float px = -V * gx, py = -V * gy, pz = -V * gz;
+        if (AF || a.w > 0.0f) o.s3 += px * px + py * py + pz * pz;
+        o.gx += px; o.gy += py; o.gz += pz;
+        // DfsphRhoAdvPass<.., 0>::pair: V_j (v_i - v_j) . grad W, fluid and rigid neighbours alike (DFSPH.py:86-101)
+        o.dsum += V * ((o.vx - bj.x) * gx + (o.vy - bj.y) * gy + (o.vz - bj.z) * gz);
+        o.cnt += 1;
+    }
+    __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
+        float den = pi.w * c.W0;
+        den += o.sum;
+        den *= c.rho0;
+        rho[i] = den;
+        float s = o.s3;
+        s += o.gx * o.gx + o.gy * o.gy + o.gz * o.gz;
+        const float al = s > 1e-5f ? 1.0f / s : 0.0f;
+        alpha[i] = al;
+        float adv = fmaxf(o.dsum, 0.0f);
+        if (o.cnt < 20) adv = 0.0f;
+        out_adv[i] = adv;
+        out_kappa[i] = adv * al;
+        return c.rho0 * adv;
+    }
+    __device__ void passive(const Consts &, int, const float4 &) const {}
+};
+
+// ---------------------------------------------------------------------------------------
 // DFSPH.py:66 compute_density_derivative (+:133 compute_kappa_v, +:206 error) when MODE == 0,
 // DFSPH.py:105 compute_density_star (+:218 compute_kappa, +:286 error) when MODE == 1.
 // Bytes / particle: R posv 16 + velm 16 (+rho, alpha 8) -> W 8.

@@ -47,6 +47,13 @@ static void l_dfsph_density_alpha(State &s) {
     else { DfsphDensityAlphaPass<false> p{s.posv.cur(), s.meta.cur(), s.rho.cur(), s.alpha, s.red_partial}; launch_pass(s, p, 1); }
 }
 
+// density + alpha + the density derivative that opens the divergence solve, one walk (DfsphDensityAlphaDivPass); the partial sums
+// of the residual are left unreduced: the reference does not look at the pre-loop value either (DFSPH.py:140-150)
+static void l_dfsph_density_alpha_div(State &s) {
+    if (s.c.all_fluid) { DfsphDensityAlphaDivPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.alpha, s.rho_deriv, s.kappa_v_next, s.red_partial}; launch_pass(s, p, 1); }
+    else { DfsphDensityAlphaDivPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.alpha, s.rho_deriv, s.kappa_v_next, s.red_partial}; launch_pass(s, p, 1); }
+}
+
 template <int MODE> static void dfsph_rho_adv_t(State &s, int slot) {
     float *out_adv = MODE == 0 ? s.rho_deriv : s.rho_star;
     float *out_k = MODE == 0 ? s.kappa_v_next : s.kappa_next;
@@ -136,11 +143,25 @@ static void l_cg_prepare(State &s) {
 static void l_cg_ap(State &s) {
     const bool split = s.cg_split && s.cg_part && s.c.n > 0;
     s.split_next_pass = split ? 1 : 0;
-    if (s.c.all_fluid) { CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2), s.cg_part, s.cap}; launch_pass(s, p, 2); }
-    else { CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2), s.cg_part, s.cap}; launch_pass(s, p, 2); }
+    // s.cg_fuse: this A p pass applies the previous iteration's p update on the fly (CgApPass::fuse), p_old = cg_p, p_new = cg_p2
+    const int fuse = s.cg_fuse ? 1 : 0;
+    const bool lst = !s.c.all_fluid && s.list_n == s.c.n;
+    const int nb = s.c.n > 0 ? cdiv(s.c.n, 256) : 0;
+    if (s.c.all_fluid) {
+        CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2), s.cg_part, s.cap,
+                         s.cg_r, s.cg_p2, CG_PART(s.cg_parity), CG_PART(3), nb, lst ? s.blk_list : nullptr, lst ? s.blk_count : nullptr,
+                         fuse, s.loop_flag ? 1 : 0, (float)s.loop_thr, 0.0f};
+        launch_pass(s, p, 2);
+    } else {
+        CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2), s.cg_part, s.cap,
+                          s.cg_r, s.cg_p2, CG_PART(s.cg_parity), CG_PART(3), nb, lst ? s.blk_list : nullptr, lst ? s.blk_count : nullptr,
+                          fuse, s.loop_flag ? 1 : 0, (float)s.loop_thr, 0.0f};
+        launch_pass(s, p, 2);
+    }
     if (split)   // the three parts -> A p and the partials of p . A p (what finish() and the pass's reduction do otherwise)
         hipLaunchKernelGGL(k_cg_ap_combine, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.meta.cur(), CG_AF, s.cg_part, s.cap, s.cg_p,
-                           s.cg_Ap, CG_PART(2), s.loop_flag, CG_LIST);
+                           s.cg_Ap, CG_PART(2), s.loop_flag, CG_LIST, fuse ? s.cg_r : (const float4 *)nullptr, s.cg_p2, s.scal);
+    if (fuse) std::swap(s.cg_p, s.cg_p2);   // cg_p is the search direction of the running iteration again
 }
 static void l_cg_prepare2(State &s) {
     if (s.c.n == 0) return;
@@ -167,7 +188,10 @@ static void l_cg_update_xr(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
     hipLaunchKernelGGL(k_cg_update_xr2, dim3(nb), dim3(256), 0, s.stream, s.c.n, nb, s.meta.cur(), CG_AF, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap,
-                       CG_PART(s.cg_parity), CG_PART(2), CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag, CG_LIST, CG_GLOB);
+                       CG_PART(s.cg_parity), CG_PART(2), CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag, CG_LIST, CG_GLOB,
+                       (s.cg_fused_loop && s.loop_flag) ? 1 : 0);
+    // fused p update: nothing else closes the iteration -- the partials just written are what the next A p pass reads
+    if (s.cg_fused_loop) s.cg_parity = 1 - s.cg_parity;
 }
 static void l_cg_update_p(State &s) {
     if (s.c.n == 0) return;
@@ -176,6 +200,10 @@ static void l_cg_update_p(State &s) {
                        CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag ? 1 : 0, (float)s.loop_thr, s.loop_flag, CG_LIST, CG_GLOB);
     s.cg_parity = 1 - s.cg_parity;
 }
+static void l_cg_check(State &s) {
+    if (s.c.n == 0 || !s.loop_flag) return;
+    hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(256), 0, s.stream, cdiv(s.c.n, 256), CG_PART(s.cg_parity), s.scal, (float)s.loop_thr, CG_LIST);
+}
 static void l_cg_prepare_guess(State &s) {
     if (s.c.n == 0) return;
     hipLaunchKernelGGL(k_cg_prepare_guess, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), CG_AF, s.cg_x, s.cg_v0);
@@ -183,8 +211,10 @@ static void l_cg_prepare_guess(State &s) {
 
 static void register_solver_launchers(Launch &L) {
     L.cg_prepare = l_cg_prepare; L.cg_ap = l_cg_ap; L.cg_prepare2 = l_cg_prepare2; L.cg_alpha = l_cg_alpha;
+    L.cg_check = l_cg_check;
     L.cg_update_xr = l_cg_update_xr; L.cg_update_p = l_cg_update_p; L.cg_prepare_guess = l_cg_prepare_guess; L.cg_fold = l_cg_fold;
     L.dfsph_density_alpha = l_dfsph_density_alpha;
+    L.dfsph_density_alpha_div = l_dfsph_density_alpha_div;
     L.dfsph_rho_adv = l_dfsph_rho_adv;
     L.dfsph_correct = l_dfsph_correct;
     L.advect_boundary = l_advect_boundary;

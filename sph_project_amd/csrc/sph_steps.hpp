@@ -24,7 +24,7 @@ static long long dfsph_particle_num(SphHandle *h) { return h->st.slab_active ? h
 // state after exactly the iteration the reference would have stopped at.
 template <class F>
 static int device_loop(SphHandle *h, int max_itr, int slot, int kind, float denom, double thr, F body, int *executed,
-                       int *launched, float *last_val) {
+                       int *launched, float *last_val, void (*batch_end)(State &) = nullptr) {
     State &s = h->st;
     HIPCHK(h, hipMemsetAsync(&s.scal->flags[0], 0, 2 * sizeof(int), s.stream));
     s.loop_flag = &s.scal->flags[0];
@@ -33,6 +33,7 @@ static int device_loop(SphHandle *h, int max_itr, int slot, int kind, float deno
     while (n_launched < max_itr) {
         const int nb = batch < max_itr - n_launched ? batch : max_itr - n_launched;
         for (int k = 0; k < nb; ++k) body();
+        if (batch_end) batch_end(s);
         n_launched += nb;
         hipError_t e = hipMemcpyAsync(h->scal_h->flags, s.scal->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s.stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&h->scal_h->red[slot], &s.scal->red[slot], sizeof(float), hipMemcpyDeviceToHost, s.stream);
@@ -79,11 +80,12 @@ static int wcsph_step(SphHandle *h) {
 }
 
 // DFSPH.py:139 correct_divergence_error
-static int dfsph_divergence(SphHandle *h, bool allow_readback) {
+static int dfsph_divergence(SphHandle *h, bool allow_readback, bool first_derivative_done = false) {
     State &s = h->st;
     const int fixed = h->prm.fixed_iterations;
     const int max_itr = fixed > 0 ? fixed : 1000;
-    { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 0); }
+    // DFSPH.py:140 compute_density_derivative before the loop (dfsph_step_end has it fused into the density + alpha walk)
+    if (!first_derivative_done) { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 0); }
     int itr = 0;
     float avg = 0.0f;
     const float n_all = (float)dfsph_particle_num(h);   // DFSPH.py:212 divides by particle_num (every rank's, under sharding)
@@ -193,9 +195,11 @@ static int dfsph_step_end(SphHandle *h, bool allow_readback) {
     if (s.slab_active) { int rc = slab_neighbor_search(h); if (rc) return rc; }   // + migration / ghost exchange
     else ph_neighbor_search(h);                                               // :316
     ph_rigid_volume(h);
-    { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha(s); } // :317-318
+    static const bool unfused = getenv("SPH_NO_DFSPH_FUSED_DIV") != nullptr;   // A/B switch
+    if (unfused) { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha(s); } // :317-318
+    else { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha_div(s); }     // :317-318 + the D rho / Dt of :140
     if (s.slab_active) { int rc = slab_exchange_scalar(h, s.rho.cur()); if (rc) return rc; }   // ghost densities (kappa_j / rho_j, viscosity)
-    return dfsph_divergence(h, allow_readback);                               // :319
+    return dfsph_divergence(h, allow_readback, !unfused);                     // :319
 }
 
 // PCISPH.py:110 refine.  Under slab sharding the ghosts' p / rho^2 goes out between the two passes of an

@@ -40,14 +40,40 @@ def scene0(scale=1.0):
 
 
 def main():
+    sys.stdout = sys.stderr   # the containers print ("No rigid body in the scene ..."); stdout carries the JSON only
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--scale", type=float, default=0.25)
     ap.add_argument("--scale-steps", type=int, default=12)
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--scene-file", default=None,
+                    help="manual check: a scene file of the reference (needs an untracked copy of its data/ directory; run from its "
+                         "parent): per-step iteration counts and the per-kernel HIP-event table, nothing else")
     args = ap.parse_args()
     from sph_project_amd import product as P
     out = {}
+    if args.scene_file:
+        cfg = json.load(open(args.scene_file))
+        container, solver = P.build_product(cfg, fast_math=1)
+        solver.prepare()
+        eng = container.engine
+        names = [eng.lib.sph_kernel_name(k).decode() for k in range(19)]
+        rows = []
+        eng.profile_enable(-1, True); eng.profile_reset()
+        for _ in range(args.steps):
+            eng.synchronize(); t0 = time.perf_counter()
+            solver.step()
+            st = solver.stats()
+            rows.append({"iter_divergence": int(st["iter_divergence"]), "iter_density": int(st["iter_density"]), "ms": 1e3 * (time.perf_counter() - t0),
+                         "err_density": float(st["err_density"]), "err_divergence": float(st["err_divergence"]),
+                         "lds_fallback_blocks": int(st["lds_fallback_blocks"])})
+        table = {names[k]: eng.profile_read(k) for k in range(19)}
+        n_it = sum(r["iter_divergence"] + r["iter_density"] for r in rows)
+        print(json.dumps({"scene": args.scene_file, "particles": int(container.particle_num[None]), "fluid_particles": int(container.fluid_particle_num[None]),
+                          "steps": args.steps, "ms_per_step": sum(r["ms"] for r in rows) / args.steps, "solver_iterations_per_step": n_it / args.steps,
+                          "kernels_ms_per_step": {k: [v[0] / args.steps, round(v[1] / args.steps, 4)] for k, v in table.items() if v[0]},
+                          "per_step": rows}), file=sys.__stdout__)
+        return
     if not args.skip_full:
         container, solver = P.build_product(scene0(1.0), fast_math=1)
         solver.prepare()
@@ -87,7 +113,7 @@ def main():
     out["scaled_copy"] = {"scale": args.scale, "particles": int(container.particle_num[None]), "fluid_particles": int(container.fluid_particle_num[None]),
                           "steps": args.scale_steps, "hip_iterations_div_den": hip_hist, "oracle_iterations_div_den": ref_hist,
                           "max_difference": worst, "oracle_seconds": t_ref}
-    print(json.dumps(out))
+    print(json.dumps(out), file=sys.__stdout__)
 
 
 if __name__ == "__main__":
