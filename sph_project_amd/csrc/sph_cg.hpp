@@ -222,7 +222,7 @@ __device__ __forceinline__ void block_sum2(float a, float b, float *out_a, float
     a = wave_sum(a); b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blk >= 0) {
         out_a[blk] = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
         out_b[blk] = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
     }
@@ -329,8 +329,11 @@ k_cg_update_xr2(int n, int nb, const int *meta, int all_fluid, float4 *x, float4
                 const float *part_rr, const float *part_den, float *part_rr_next, float *part_rold, DevScalars *scal,
                 const int *stop_flag, const int *blk_list, const int *blk_count, const float *glob, int count_iteration) {
     if (stop_flag && *stop_flag) return;
+    // (a physical workgroup beyond the list of fluid-holding ones has no particles, but workgroup 0 keeps the loop's books
+    //  whatever the list holds -- with NO active fluid particle at all, e.g. an emitter scene before its first release, the
+    //  list is empty and the books would never be kept: 1000 empty iterations per step)
     const int blk = cg_block(blk_list, blk_count);
-    if (blk < 0) return;
+    if (blk < 0 && blockIdx.x != 0) return;
     __shared__ float s4[4];
     const float num_a = glob ? glob[0] : cg_total(part_rr, nb, blk_list, blk_count, s4);
     const float den_a = glob ? glob[1] : cg_total(part_den, nb, blk_list, blk_count, s4);
@@ -338,7 +341,7 @@ k_cg_update_xr2(int n, int nb, const int *meta, int all_fluid, float4 *x, float4
     if (blockIdx.x == 0 && threadIdx.x == 0) { scal->red[4] = alpha; if (count_iteration) scal->flags[1] += 1; }   // (fused p update: this kernel ends the iteration)
     int i = blk * 256 + threadIdx.x;
     float num = 0.f, den = 0.f;
-    if (i < n && is_fluid(meta, i, all_fluid)) {
+    if (blk >= 0 && i < n && is_fluid(meta, i, all_fluid)) {
         float4 xx = x[i];
         const float4 pp = p[i], rr = r[i], a = Ap[i];
         xx.x += alpha * pp.x; xx.y += alpha * pp.y; xx.z += alpha * pp.z;
@@ -358,13 +361,13 @@ k_cg_update_p2(int n, int nb, const int *meta, int all_fluid, const float4 *r, f
                const int *blk_count, const float *glob) {
     if (stop_flag && *stop_flag) return;
     const int blk = cg_block(blk_list, blk_count);
-    if (blk < 0) return;
+    if (blk < 0 && blockIdx.x != 0) return;   // (workgroup 0 keeps the books even when the list is empty, see k_cg_update_xr2)
     __shared__ float s4[4];
     const float num = glob ? glob[0] : cg_total(part_rr_next, nb, blk_list, blk_count, s4);
     const float den = glob ? glob[1] : cg_total(part_rold, nb, blk_list, blk_count, s4);
     const float beta = den > 1e-18f ? num / den : 0.0f;
     int i = blk * 256 + threadIdx.x;
-    if (i < n && is_fluid(meta, i, all_fluid)) {
+    if (blk >= 0 && i < n && is_fluid(meta, i, all_fluid)) {
         const float4 rr = r[i];
         float4 pp = p[i];
         pp.x = rr.x + beta * pp.x; pp.y = rr.y + beta * pp.y; pp.z = rr.z + beta * pp.z;

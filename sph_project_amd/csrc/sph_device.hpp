@@ -808,7 +808,12 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
            unsigned long long *__restrict__ timeline, const int *__restrict__ stop_flag,
            const int *__restrict__ blk_list, const int *__restrict__ blk_count) {
     if (stop_flag && *stop_flag) return;   // iteration launched past the convergence of a device-controlled loop
-    if (blk_list && (int)blockIdx.x >= *blk_count) return;   // only the workgroups that hold fluid were listed
+    if (blk_list && (int)blockIdx.x >= *blk_count) {   // only the workgroups that hold fluid were listed
+        // (a functor whose prologue keeps a solver loop's books gets it run by workgroup (0, 0) even when the list is EMPTY --
+        //  an emitter scene before its first release has no active fluid particle at all)
+        if constexpr (PassPrologue<P>::value) { if (blockIdx.x == 0 && blockIdx.y == 0) p.prologue(scal); }
+        return;
+    }
     constexpr int BLOCK = P::BLOCK;
     constexpr int CAP = nbr_tile_cap<P>();   // LDS particle slots per staging group
     constexpr int NS = (CAP + BLOCK - 1) / BLOCK;   // tile slots staged per thread

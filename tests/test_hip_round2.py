@@ -287,6 +287,32 @@ def test_c5_scaled_buckling_scene(gpu):
     assert abs(solver.stats()["iter_cg"] - it_ref) <= 2 and it_ref >= 5
 
 
+def test_implicit_viscosity_before_the_emitter_releases_anything(gpu):
+    """The reference's final_scene4.json starts with every fluid particle above gravitationUpper: for its first 14 steps there is
+    NO active fluid particle, the CG system is empty and the reference's loop leaves after one pass (|r| = 0, base_solver.py:445-461).
+    Round 2 kept the loop's books in a workgroup that an empty fluid-workgroup list never ran: 1000 empty iterations per step
+    (44 ms instead of 1 ms; found in round 3 by tools/scene0_iterations.py).  Same count as the oracle now, and no fluid moves."""
+    cfg = P.c5_scene(domain_end=(1.2, 2.4, 1.2), start=(0.5, 1.3, 0.56), end=(0.7, 1.9, 0.62), g_upper=1.0, velocity=(0.0, -2.2, 0.0))
+    container, solver = H.build_product(cfg, fast_math=1)
+    solver.prepare()
+    ref = H.build_oracle(cfg)
+    ref.prepare()
+    e = container.engine
+    assert (e.download(L.F_MATERIAL) == 1).sum() == 0   # prepare_emitter froze the whole sheet
+    for step in range(1, 4):
+        t0 = time.perf_counter()
+        solver.step()
+        ms = 1e3 * (time.perf_counter() - t0)
+        ref.step(1)
+        it, it_ref = solver.stats()["iter_cg"], int(ref.scalar("last_iter_cg"))
+        print("empty CG system, step %d: iterations hip %d oracle %d, %.2f ms" % (step, it, it_ref, ms))
+        assert it_ref <= 1 and abs(it - it_ref) <= 1, (it, it_ref)
+    ids = e.download(L.F_PARTICLE_ID)
+    x = H.by_id(ids, e.download(L.F_POSITION))
+    xr = H.by_id(H.oracle_ids(ref), ref.field("particle_positions").copy())
+    assert H.drift(x, xr, container.dh).max() <= 1e-6
+
+
 def test_c5_full_size(gpu):
     """BASELINE configs[4] at its full size: the reference's buckling scene (data/scenes/final_scene3.json without its mesh
     body): DFSPH + implicit viscosity, 2,171,495 particles of which 106,400 fluid, G = 10,000,000 cells, the solvers' own stop
