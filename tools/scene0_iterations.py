@@ -99,7 +99,9 @@ def main():
     solver.prepare()
     ref = H.build_oracle(cfg)
     ref.prepare()
-    hip_hist, ref_hist = [], []
+    import numpy as np
+    from sph_project_amd import _lib as L
+    hip_hist, ref_hist, drift_hist, err_hist = [], [], [], []
     t_ref = 0.0
     for _ in range(args.scale_steps):
         solver.step()
@@ -109,10 +111,19 @@ def main():
         ref.step(1)
         t_ref += time.perf_counter() - t0
         ref_hist.append((int(ref.scalar("last_iter_div")), int(ref.scalar("last_iter_den"))))
+        # how far apart are the two states?  (an iteration count is a threshold crossing of a mean error that creeps towards the
+        # threshold over tens of iterations: a last-bit difference in the error can move the crossing by several iterations)
+        e = container.engine
+        ids = e.download(L.F_PARTICLE_ID)
+        x = H.by_id(ids, e.download(L.F_POSITION))
+        xr = H.by_id(H.oracle_ids(ref), ref.field("particle_positions").copy())
+        drift_hist.append(float(H.drift(x, xr, container.dh).max()))
+        err_hist.append((float(st["err_divergence"]), float(ref.scalar("last_err_div")), float(st["err_density"]), float(ref.scalar("last_err_den"))))
     worst = max(max(abs(a[0] - b[0]), abs(a[1] - b[1])) for a, b in zip(hip_hist, ref_hist))
     out["scaled_copy"] = {"scale": args.scale, "particles": int(container.particle_num[None]), "fluid_particles": int(container.fluid_particle_num[None]),
                           "steps": args.scale_steps, "hip_iterations_div_den": hip_hist, "oracle_iterations_div_den": ref_hist,
-                          "max_difference": worst, "oracle_seconds": t_ref}
+                          "max_difference": worst, "drift_vs_oracle_per_step": drift_hist,
+                          "final_errors_hip_oracle_div_den": err_hist, "oracle_seconds": t_ref}
     print(json.dumps(out), file=sys.__stdout__)
 
 
