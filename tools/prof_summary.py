@@ -82,6 +82,7 @@ def main(out, json_path=None, config="c2", source=None):
         print("   kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs; eff_clock = kernel_cycles / avg duration; hbm_bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB")
         print("   valu_issue = SQ_INSTS_VALU / 1024 SIMDs x 2 cycles / kernel_cycles; waves_parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
         print("   lds_active = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel_cycles); lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE")
+        print("   (GRBM_GUI_ACTIVE also counts the ramp around a launch: the clock and the fractions are meaningful for kernels of ~100 us, not for 5-25 us ones)")
         derived = {}
         for k in sorted(ctr, key=lambda k: -rows.get(k, {"ns": 0})["ns"]):
             if k not in rows or not rows[k]["n"]:

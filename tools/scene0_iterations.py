@@ -24,11 +24,13 @@ sys.path.insert(0, ROOT)
 
 
 def scene0(scale=1.0):
-    """final_scene0.json (Configuration + FluidBlocks verbatim; RigidBodies left out), every length times `scale`."""
+    """final_scene0.json (Configuration + FluidBlocks verbatim; RigidBodies left out).  scale < 1: the block's extents and the free
+    space beside and above it shrink, its distances to the walls it starts next to (0.09 in x, 0.2 in y, 0.2 on both sides in z) do
+    not -- those are what decides how hard the boundary particles compress it."""
     s = scale
     return {
         "Configuration": {
-            "domainStart": [0.0, 0.0, 0.0], "domainEnd": [8.5 * s, 8.0 * s, 2.0 * s], "addDomainBox": True, "particleRadius": 0.01,
+            "domainStart": [0.0, 0.0, 0.0], "domainEnd": [0.09 + (1.61 + 6.8) * s, 0.2 + (3.8 + 4.0) * s, 0.2 + 1.6 * s + 0.2], "addDomainBox": True, "particleRadius": 0.01,
             "density0": 1000, "gravitation": [0.0, -9.81, 0.0], "simulationMethod": "dfsph", "viscosityMethod": "standard",
             "timeStepSize": 0.0006, "viscosity": 10.0, "viscosity_b": 0.3,
         },
