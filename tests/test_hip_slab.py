@@ -42,7 +42,7 @@ def _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.0, seed=0, fixed_iteration
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
-        o, _ = p.communicate(timeout=300)
+        o, _ = p.communicate(timeout=int(os.environ.get("SPH_TEST_RANK_TIMEOUT", "300")))
         logs.append(o.decode())
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"

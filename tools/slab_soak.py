@@ -17,9 +17,13 @@ from sph_project_amd import _lib as L  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 nranks = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+advance = len(sys.argv) > 3 and sys.argv[3] == "advance"   # all steps in ONE call: over the push transport no host read-back at all
+if len(sys.argv) > 4:
+    import tests.test_hip_slab as _ts
+    _ts.TRANSPORT[0] = sys.argv[4]
 cfg = H.dam_break_scene(domain_end=(2.0, 1.2, 1.6), start=(0.1, 0.1, 0.1), end=(0.9, 1.0, 1.5), translation=(0, 0, 0), velocity=(0.0, 0.0, 0.0))
 tmp = Path(tempfile.mkdtemp())
-outs, logs = _run_ranks(cfg, nranks, steps, tmp, rebalance=32)
+outs, logs = _run_ranks(cfg, nranks, steps, tmp, rebalance=32, advance=advance)
 ids = np.concatenate([o["ids"] for o in outs])
 n = len(ids)
 assert len(np.unique(ids)) == n, "a particle is owned twice"
@@ -34,7 +38,7 @@ solver.prepare()
 container.engine.step(steps)
 e = container.engine
 xr = H.by_id(e.download(L.F_PARTICLE_ID), e.download(L.F_POSITION))
-print("soak: %d particles, %d steps, %d ranks; owned per rank %s; slabs %s" % (n, steps, nranks, [len(o["ids"]) for o in outs],
+print("soak (%s, %s): %d particles, %d steps, %d ranks; owned per rank %s; slabs %s" % (str(outs[0]["transport"]), "one call" if advance else "step by step", n, steps, nranks, [len(o["ids"]) for o in outs],
       [(int(o["z_lo"]), int(o["z_hi"])) for o in outs]))
 print("mean position sharded %s  undecomposed %s; max |v| %.2f / %.2f" % (x.mean(0), xr.mean(0), np.linalg.norm(v, axis=1).max(),
       np.linalg.norm(H.by_id(e.download(L.F_PARTICLE_ID), e.download(L.F_VELOCITY)), axis=1).max()))
