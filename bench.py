@@ -11,7 +11,9 @@ N > 1: one process per GPU, no torch anywhere.  `python bench.py --gpus N` spawn
 that already did (torch.distributed.run exports RANK / LOCAL_RANK / WORLD_SIZE) every process is one rank.  The RCCL
 unique id travels through a file in /dev/shm, barriers and the max / sum reductions are RCCL all-reduces behind the
 C-ABI (sph_comm_barrier / sph_comm_allreduce).  Scenes are z-slab sharded (RCCL halo exchange; DFSPH / PCISPH with their
-per-iteration ghost refreshes and all-reduced residuals); --replicas runs independent copies instead and says so.  SPH_COMM_TRANSPORT=shm lets several ranks share one GPU (test rig).
+per-iteration ghost refreshes and all-reduced residuals); --replicas runs independent copies instead and says so.  Halo payload travels
+by device stores into the neighbour's hipIpc-mapped inbox ("push", self-tested at set-up) with RCCL send/recv as the all-ranks fall-back;
+SPH_COMM_TRANSPORT=shm+ipc / shm lets several ranks share one GPU (test rig).
 
 Timing: W untimed warm-up steps, then 3 repetitions of exactly K steps, each enqueued on the library's HIP stream
 between two (device synchronise + barrier) fences, max over ranks; `ms_per_step` is the MEDIAN repetition
@@ -20,9 +22,16 @@ resident in HBM (scene upload outside the region).  The same scene is then advan
 (`in_motion`): the rest lattice holds 29 neighbours per particle, the collapsing column ~39.
 Roofline leg: the dominant kernel (picked by a short all-kernel HIP-event pre-pass) is timed with HIP events on the
 library's own stream inside the timed region; achieved GB/s = algorithmic bytes per launch /
-average launch duration, against 8 TB/s HBM3E peak.
+average launch duration, against the 8 TB/s HBM3E spec AND against the device-to-device copy rate measured in this run
+(`measured_copy_gbs`).  `traffic` and `secondary` (what actually bounds the kernel: VALU issue, parked wave-cycles, LDS,
+effective clock) come from the committed PMC passes of this command under profiles/ and say so (`traffic_source`).
 CPU baseline leg (rank 0, N=1 only): the oracle (this repo's C restatement of the reference algorithm, OpenMP) on
 the host cores, a bounded sample of the same workload, swept over thread counts; the best is reported.
+Extra objects of the line (never `value`): N = 1: `extras.c3` (BASELINE configs[2]: DFSPH, 2+2 iterations, per-walk
+microseconds, 92 B/particle/iteration roofline) and `extras.c5` (configs[4]: the implicit-viscosity buckling scene with the
+solvers' stop tests, CG iterations per step, microseconds per CG iteration, 224 B/particle/iteration roofline); N > 1:
+`c2_strong_scaling` (the metric as BASELINE.json words it: the 1.23 M scene itself over the N ranks) and
+`c4_strong_scaling` (configs[3]), each on a communicator of its own, with the halo transport in effect.
 """
 import argparse
 import json
