@@ -443,19 +443,40 @@ static int push_teardown(SphHandle *h) {
 static int push_setup(SphHandle *h) {
     State &s = h->st; SlabComm &c = h->comm;
     memset(&s.push, 0, sizeof(s.push));
-    s.push.rec_bytes = (size_t)s.halo_cap * 64;        // records of 64 B (with the rest position of a dynamic rigid body)
-    s.push.fld_bytes = (size_t)s.halo_cap * 2 * 16;    // n_send + n_recv <= 2 halo_cap records of <= 16 B
     s.push.timeout_ticks = (long long)(0.5 * c.timeout_s * 1.0e8);   // 100 MHz wall clock; the device gives up before the host does
-    const size_t bytes = 2 * sizeof(HaloCtl) + 4 * s.push.rec_bytes + 4 * s.push.fld_bytes;
     int ok = 1;
     char why[160] = "";
     void *inbox = nullptr;
-    // memory the other device writes and this one polls: uncached / fine-grained where the runtime offers it (what RCCL uses
-    // for its own flags), plain device memory otherwise (enough between two ranks of ONE device)
-    int inbox_kind = 0;   // 0 uncached, 1 fine-grained, 2 plain (coherent only between two ranks of ONE device)
-    hipError_t e = hipExtMallocWithFlags(&inbox, bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) { (void)hipGetLastError(); inbox_kind = 1; e = hipExtMallocWithFlags(&inbox, bytes, hipDeviceMallocFinegrained); }
-    if (e != hipSuccess) { (void)hipGetLastError(); inbox_kind = 2; e = hipMalloc(&inbox, bytes); }
+    size_t bytes = 0;
+    // Memory the other device writes and this one polls: uncached / fine-grained where the runtime offers it (what RCCL uses for its
+    // own flags), plain device memory otherwise (enough between two ranks of ONE device).  Message capacity = particle capacity (no
+    // pile-up in the boundary layers can overflow it); if the runtime will not give that much coherent memory, a quarter of it (a
+    // longer message is then refused by both sides through the status word, it does not corrupt anything).
+    int inbox_kind = 2;   // 0 uncached, 1 fine-grained, 2 plain
+    hipError_t e = hipErrorOutOfMemory;
+    const int caps[2] = {s.halo_cap, std::max(s.halo_cap / 4, std::min(s.halo_cap, 262144))};
+    auto alloc_inbox = [&](int size_class) {   // coherent kinds first; returns hipSuccess with inbox / inbox_kind / bytes set
+        s.push.rec_cap = caps[size_class];
+        s.push.rec_bytes = (size_t)s.push.rec_cap * 64;        // records of 64 B (with the rest position of a dynamic rigid body)
+        s.push.fld_bytes = (size_t)s.push.rec_cap * 2 * 16;    // n_send + n_recv <= 2 rec_cap records of <= 16 B
+        bytes = 2 * sizeof(HaloCtl) + 4 * s.push.rec_bytes + 4 * s.push.fld_bytes;
+        hipError_t r = hipErrorOutOfMemory;
+        for (int kind = 0; kind < 3 && r != hipSuccess; ++kind) {
+            // between devices only coherent memory will do (checked against the neighbours' bus ids below); do not grab the plain
+            // kind at full size when a coherent quarter might still be had
+            if (kind == 2 && size_class == 0 && caps[1] != caps[0] && c.nranks > 1) break;
+            inbox_kind = kind;
+            r = kind == 2 ? hipMalloc(&inbox, bytes) : hipExtMallocWithFlags(&inbox, bytes, kind == 0 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+            if (r != hipSuccess) { (void)hipGetLastError(); inbox = nullptr; }
+        }
+        return r;
+    };
+    int size_class = 0;
+    e = alloc_inbox(0);
+    if (e != hipSuccess && caps[1] != caps[0]) { size_class = 1; e = alloc_inbox(1); }
+    // the layout of an inbox depends on the message capacity: every rank uses the same one (the smallest anybody got)
+    { double cls[1] = {(double)size_class}; int rc = sph_comm_allreduce(h, cls, 1, 1); if (rc) return rc;
+      if ((int)cls[0] != size_class) { if (inbox) hipFree(inbox); inbox = nullptr; size_class = (int)cls[0]; e = alloc_inbox(size_class); } }
     char busid[32] = "";
     if (hipDeviceGetPCIBusId(busid, sizeof(busid), h->device) != hipSuccess) { (void)hipGetLastError(); snprintf(busid, sizeof(busid), "dev%d-pid%d", h->device, (int)getpid()); }
     if (e != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "inbox allocation of %zu bytes: %s", bytes, hipGetErrorString(e)); (void)hipGetLastError(); }

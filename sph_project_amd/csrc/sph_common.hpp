@@ -166,6 +166,7 @@ struct State {
         int on;                        // halo payload travels by device stores into the neighbour's inbox
         char *inbox;                   // mine (device memory the neighbours write)
         char *peer[2];                 // lower / upper neighbour's inbox in my address space (null: no neighbour)
+        int rec_cap;                   // records a step message can hold (normally the particle capacity)
         size_t rec_bytes, fld_bytes;   // size of one step-message / field-message region
         unsigned rec_seq, fld_seq;     // messages sent (= received) so far
         long long timeout_ticks;       // bounded waits of the device (100 MHz wall clock)

@@ -30,7 +30,7 @@ static void l_halo_classify_pack(State &s, int n) {
         if (n <= 0) return;
     }
     hipLaunchKernelGGL(k_halo_classify, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, n, n_dev, s.z_lo, s.z_hi, s.has_down, s.has_up, a,
-                       dst[0], dst[1], s.halo_cap, counts, hash);
+                       dst[0], dst[1], s.push.on ? s.push.rec_cap : s.halo_cap, counts, hash);
 }
 
 static int halo_grid(int count_hint) {   // grid-stride kernels: enough workgroups for the hint, at least one, never a huge launch
@@ -48,7 +48,7 @@ static void l_halo_unpack2(State &s, int n_old, int bound_app, int bound_live, i
         w.in_ctl[side] = s.push.peer[side] ? inbox_ctl(s.push.inbox, side) : nullptr;
         w.recv[side] = (const float4 *)inbox_rec(s, s.push.inbox, side, seq);
     }
-    w.seq = seq; w.stride = s.orig.cur() ? 4 : 3; w.cap = s.cap; w.halo_cap = s.halo_cap;
+    w.seq = seq; w.stride = s.orig.cur() ? 4 : 3; w.cap = s.cap; w.halo_cap = s.push.rec_cap;
     w.n_old = n_old; w.bound_app = bound_app; w.bound_live = bound_live; w.timeout_ticks = s.push.timeout_ticks;
     w.counts = s.halo_counts + 4 * (seq & 1u); w.counts_next = s.halo_counts + 4 * ((seq + 1) & 1u);
     w.dyn_old = s.dyn + ((seq - 1) & 1u); w.dyn_new = s.dyn + (seq & 1u);
