@@ -771,9 +771,30 @@ k_compact_blocks(const int *__restrict__ flag, int nb, int *__restrict__ list, i
 // may use a quarter of the 160 KB: the tile gets what is left after the cell windows, up to 1280 slots (5 per thread).
 // A rest-density workgroup needs ~3 x 34 cells x 8 = 816; moving fluid piles up to 900-1000, and every overflow sends
 // a whole group down the ordered path.
+// "Medium" functors: payload arrays, but a record of <= SPH_NBR_MEDIUM_BYTES bytes and a small pair() (the DFSPH / PCISPH solver walks and
+// the unfused pressure walk: 20-28 B per slot, a dozen flops per pair) that reuse stored masks.  At 4 workgroups per CU they sat at
+// 103-113 VGPRs only because the launch bound allowed 128; a fifth of the CU's LDS still holds a rest-density group (816 slots of 28 B =
+// 22 KB), so they run 5 workgroups per CU (<= 96 VGPRs, 32 KB) -- one more wave per SIMD for walks that are pure latency.
+// What had to give for 96 registers: the staging batch (SPH_MEDIUM_SB slots per thread in flight instead of all 4-5: with 4 the 28-byte
+// walks spill 10 VGPRs, with 2 nothing spills in either the all-fluid or the rigid-aware instantiations).  Measured at C3 / PCISPH
+// (profiles/r03n_ab_medium_occupancy.txt): 24-byte subset -2 %, 28 bytes with spills -3.5 %, 28 bytes / batches of 2 (this) -3 % from
+// rest and -6 % in motion, no spills.  0 bytes = off.
+#ifndef SPH_NBR_MEDIUM_BYTES
+#define SPH_NBR_MEDIUM_BYTES 28
+#endif
+#ifndef SPH_MEDIUM_SB
+#define SPH_MEDIUM_SB 2   // staging slots per batch of a medium functor
+#endif
+template <class P> constexpr int pass_slot_bytes() {
+    return 16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0);
+}
+template <class P> constexpr bool pass_is_medium() {
+    return SPH_FAST && P::HAS_B && pass_slot_bytes<P>() <= SPH_NBR_MEDIUM_BYTES && !pass_builds_masks<P>();
+}
 template <class P> constexpr int nbr_tile_cap() {
-    const int per_slot = 16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0);
-    const int slots = (40960 - 9 * NBR_CS_PITCH * 2 - 1536) / per_slot - NBR_PAD;   // 1.5 KB for the small arrays and the allocation granule
+    const int per_slot = pass_slot_bytes<P>();
+    const int budget = pass_is_medium<P>() ? 32768 : 40960;   // a fifth / a quarter of the CU's 160 KB
+    const int slots = (budget - 9 * NBR_CS_PITCH * 2 - 1536) / per_slot - NBR_PAD;   // 1.5 KB for the small arrays and the allocation granule
     return slots > 1280 ? 1280 : slots / 8 * 8;
 }
 // LDS bytes of k_nbr_pass<P, MASKMODE> (tile + cell_start windows + small change)
@@ -798,7 +819,7 @@ template <class P, int MASKMODE> constexpr int nbr_lds_bytes() {
 #define SPH_NBR_WAVES_HEAVY 4
 #endif
 template <class P, int MASKMODE> constexpr int nbr_waves_per_simd() {
-    return P::HAS_B ? SPH_NBR_WAVES_HEAVY : (sizeof(typename P::Own) <= 8 ? SPH_NBR_WAVES_LIGHT : 4);
+    return P::HAS_B ? (pass_is_medium<P>() ? 5 : SPH_NBR_WAVES_HEAVY) : (sizeof(typename P::Own) <= 8 ? SPH_NBR_WAVES_LIGHT : 4);
 }
 template <class P, int MASKMODE>
 __global__ void __launch_bounds__(P::BLOCK, (nbr_waves_per_simd<P, MASKMODE>()))
@@ -959,7 +980,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             // stage the runs that fit: <= 4 slots per thread; the loads of a batch are all issued before its first LDS
             // write (one global round trip per batch; wide records go in two batches to stay within the VGPR budget);
             // consecutive t -> consecutive j: coalesced
-            constexpr int SB = (P::HAS_B && sizeof(BT) >= 16) ? 2 : NS;   // slots per batch
+            constexpr int SB = (P::HAS_B && sizeof(BT) >= 16) ? 2 : (pass_is_medium<P>() && NS > SPH_MEDIUM_SB ? SPH_MEDIUM_SB : NS);   // slots per batch (medium functors: 96-VGPR budget)
             const int n0 = lo_[0] != INT_MIN ? ln_[0] : 0;
             const int n01 = n0 + (lo_[1] != INT_MIN ? ln_[1] : 0);
 #pragma unroll 1
