@@ -475,6 +475,10 @@ def test_rccl_transport_executes_on_hardware(gpu):
     slab = _bench(args, {"SPH_BENCH_FORCE_SLAB": "1", "SPH_COMM_TRANSPORT": "rccl", "SPH_BENCH_SELFTEST": "1"})
     plain = _bench(args, {})
     assert slab["config"]["pair_interactions_per_step"] == plain["config"]["pair_interactions_per_step"]
+    # the default data plane on top of the RCCL control plane: push transport (no neighbour to map on one rank, but inbox, device-resident
+    # counts, asynchronous steps and launch bounds are all in play)
+    push = _bench(args, {"SPH_BENCH_FORCE_SLAB": "1", "SPH_BENCH_SELFTEST": "1", "SPH_COMM_VERBOSE": "1"})
+    assert push["config"]["pair_interactions_per_step"] == plain["config"]["pair_interactions_per_step"]
 
 
 # --------------------------------------------------------------------------------------------- dynamic rigid body, end to end

@@ -159,3 +159,35 @@ def test_ply_writer_layout(tmp_path):
     lines = p.read_text().splitlines()
     assert lines[0] == "ply" and lines[1] == "format ascii 1.0" and "element vertex 2" in lines
     assert lines[lines.index("end_header") + 1].split() == ["0", "1", "2"]
+
+
+def test_bench_secondary_bound_is_recomputable_from_the_committed_profile():
+    """bench.py attaches PMC-derived figures (HBM traffic, VALU issue, parked wave-cycles, LDS, effective clock) to its roofline object
+    from profiles/pmc_derived.json.  Every one of them must follow from the counters printed in the summary file it names, by the
+    formulas of tools/prof_summary.py (VERDICT r02 #4: "a reader can recompute every number in the line")."""
+    import json
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import prof_summary as ps
+    doc = json.load(open(os.path.join(root, "profiles", "pmc_derived.json")))
+    txt = open(os.path.join(root, doc["_source"])).read()
+    trace = {m.group(1): float(m.group(3)) * 1e3 for m in re.finditer(r"^(\S+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)$", txt, re.M)}
+    block = txt.split("== PMC counters, average per launch ==")[1].split("== derived")[0]
+    ctr, cur = {}, None
+    for line in block.splitlines():
+        if line and not line.startswith(" "):
+            cur = line.strip(); ctr[cur] = {}
+        elif line.strip():
+            a, b = line.split(); ctr[cur][a] = float(b)
+    checked = 0
+    for kernel, kid in (("nbr_pass<DensityPass>", "density"), ("nbr_pass<WcsphForcePass>", "wcsph_forces")):
+        d = ps.derive(trace[kernel], ctr[kernel])
+        for key, val in doc["c2"][kid].items():
+            if key == "avg_us":
+                assert abs(val - trace[kernel] / 1e3) < 0.06
+            else:
+                assert abs(d[key] - val) <= 2e-3 * abs(val) + 1e-9, (kid, key, d[key], val)   # (the summary prints one decimal)
+            checked += 1
+    assert checked >= 14
