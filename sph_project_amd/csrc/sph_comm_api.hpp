@@ -128,9 +128,11 @@ extern "C" int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id1
     // memory control plane + host-staged mailboxes; "shm+ipc" = shared-memory control plane + push data plane (several ranks
     // on one GPU: the test rig of the push transport)
     const char *t = getenv("SPH_COMM_TRANSPORT");
-    if (t && strcmp(t, "auto") && strcmp(t, "ipc") && strcmp(t, "rccl") && strcmp(t, "shm") && strcmp(t, "shm+ipc"))
-        return fail(h, SPH_ERR_INVALID, "SPH_COMM_TRANSPORT=%s: expected auto, ipc, rccl, shm or shm+ipc", t);
-    c.push_wanted = (!t || !strcmp(t, "auto")) ? 1 : ((!strcmp(t, "ipc") || !strcmp(t, "shm+ipc")) ? 2 : 0);
+    // ("shm+auto": shared-memory control plane, push data plane if it can be set up on every rank, else the mailboxes -- the test rig of
+    //  the all-ranks fall-back decision)
+    if (t && strcmp(t, "auto") && strcmp(t, "ipc") && strcmp(t, "rccl") && strcmp(t, "shm") && strcmp(t, "shm+ipc") && strcmp(t, "shm+auto"))
+        return fail(h, SPH_ERR_INVALID, "SPH_COMM_TRANSPORT=%s: expected auto, ipc, rccl, shm, shm+ipc or shm+auto", t);
+    c.push_wanted = (!t || !strcmp(t, "auto") || !strcmp(t, "shm+auto")) ? 1 : ((!strcmp(t, "ipc") || !strcmp(t, "shm+ipc")) ? 2 : 0);
     if (const char *to = getenv("SPH_COMM_TIMEOUT_S")) { const double v = atof(to); if (v > 0.0) c.timeout_s = v; }
     if (t && !strncmp(t, "shm", 3)) {
         if (nranks > SHM_MAX_RANKS) return fail(h, SPH_ERR_INVALID, "shm transport: at most %d ranks", SHM_MAX_RANKS);
@@ -472,6 +474,9 @@ static int push_setup(SphHandle *h) {
         return r;
     };
     int size_class = 0;
+    if (const char *fr = getenv("SPH_COMM_TEST_FAIL_PUSH_RANK")) {   // test hook: this rank cannot set the push transport up
+        if (atoi(fr) == c.rank) { ok = 0; snprintf(why, sizeof(why), "SPH_COMM_TEST_FAIL_PUSH_RANK (test hook)"); }
+    }
     e = alloc_inbox(0);
     if (e != hipSuccess && caps[1] != caps[0]) { size_class = 1; e = alloc_inbox(1); }
     // the layout of an inbox depends on the message capacity: every rank uses the same one (the smallest anybody got)
