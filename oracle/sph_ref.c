@@ -234,13 +234,13 @@ static inline int flatten_grid_index(const SphRef *s, const int idx[3]) {
 /* base_container.py:496 */
 void sphref_init_grid(SphRef *s) {
     memset(s->grid_num_particles, 0, sizeof(int) * (size_t)s->G);
+#pragma omp parallel for schedule(static)   /* per-particle, independent */
     for (int p = 0; p < s->particle_num; p++) {
         int idx[3];
         pos_to_index(s, s->particle_positions[p], idx);
-        int g = flatten_grid_index(s, idx);
-        s->grid_ids[p] = g;
-        s->grid_num_particles[g] += 1;
+        s->grid_ids[p] = flatten_grid_index(s, idx);
     }
+    for (int p = 0; p < s->particle_num; p++) s->grid_num_particles[s->grid_ids[p]] += 1;   /* the histogram stays serial */
     memcpy(s->grid_num_particles_temp, s->grid_num_particles, sizeof(int) * (size_t)s->G);
 }
 
@@ -262,6 +262,7 @@ void sphref_reorder_particles(SphRef *s) {
         s->grid_num_particles_temp[s->grid_ids[p]] = old - 1; /* ti.atomic_sub returns the old value */
         s->grid_ids_new[p] = old - 1 + base_offset;
     }
+#pragma omp parallel for schedule(static)   /* grid_ids_new is a permutation: every target written once */
     for (int p = 0; p < N; p++) {
         int n = s->grid_ids_new[p];
         s->grid_ids_buffer[n] = s->grid_ids[p];
@@ -276,18 +277,21 @@ void sphref_reorder_particles(SphRef *s) {
         for (int c = 0; c < 3; c++) s->particle_colors_buffer[3 * n + c] = s->particle_colors[3 * p + c];
         s->is_dynamic_buffer[n] = s->particle_is_dynamic[p];
     }
-    size_t n = (size_t)N;
-    memcpy(s->grid_ids, s->grid_ids_buffer, n * sizeof(int));
-    memcpy(s->particle_object_ids, s->particle_object_ids_buffer, n * sizeof(int));
-    memcpy(s->rigid_particle_original_positions, s->rigid_particle_original_positions_buffer, n * sizeof(v3));
-    memcpy(s->particle_positions, s->particle_positions_buffer, n * sizeof(v3));
-    memcpy(s->particle_velocities, s->particle_velocities_buffer, n * sizeof(v3));
-    memcpy(s->particle_rest_volumes, s->particle_rest_volumes_buffer, n * sizeof(float));
-    memcpy(s->particle_masses, s->particle_masses_buffer, n * sizeof(float));
-    memcpy(s->particle_densities, s->particle_densities_buffer, n * sizeof(float));
-    memcpy(s->particle_materials, s->particle_materials_buffer, n * sizeof(int));
-    memcpy(s->particle_colors, s->particle_colors_buffer, 3 * n * sizeof(int));
-    memcpy(s->particle_is_dynamic, s->is_dynamic_buffer, n * sizeof(int));
+    /* the copy-back of base_container.py:532-542, one attribute per thread group */
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < N; p++) {
+        s->grid_ids[p] = s->grid_ids_buffer[p];
+        s->particle_object_ids[p] = s->particle_object_ids_buffer[p];
+        s->rigid_particle_original_positions[p] = s->rigid_particle_original_positions_buffer[p];
+        s->particle_positions[p] = s->particle_positions_buffer[p];
+        s->particle_velocities[p] = s->particle_velocities_buffer[p];
+        s->particle_rest_volumes[p] = s->particle_rest_volumes_buffer[p];
+        s->particle_masses[p] = s->particle_masses_buffer[p];
+        s->particle_densities[p] = s->particle_densities_buffer[p];
+        s->particle_materials[p] = s->particle_materials_buffer[p];
+        for (int c = 0; c < 3; c++) s->particle_colors[3 * p + c] = s->particle_colors_buffer[3 * p + c];
+        s->particle_is_dynamic[p] = s->is_dynamic_buffer[p];
+    }
 }
 
 /* base_container.py:544 */
@@ -408,6 +412,7 @@ void sphref_compute_density(SphRef *s) {
 /* WCSPH.py:17 compute_pressure (stiffness 50000, gamma 7: WCSPH.py:12-13) */
 void sphref_wcsph_compute_pressure(SphRef *s) {
     const float stiffness = 50000.0f, gamma = 7.0f;
+#pragma omp parallel for schedule(static)
     for (int p_i = 0; p_i < s->particle_num; p_i++) {
         if (s->particle_materials[p_i] == SPHREF_MAT_FLUID) {
             float rho_i = s->particle_densities[p_i];
@@ -474,6 +479,7 @@ void sphref_compute_pressure_acceleration(SphRef *s) {
 /* base_solver.py:203 */
 void sphref_compute_gravity_acceleration(SphRef *s) {
     v3 g = v3_make((float)s->prm.gravity[0], (float)s->prm.gravity[1], (float)s->prm.gravity[2]);
+#pragma omp parallel for schedule(static)
     for (int p_i = 0; p_i < s->particle_num; p_i++)
         if (s->particle_materials[p_i] == SPHREF_MAT_FLUID) s->particle_accelerations[p_i] = g;
 }
@@ -738,6 +744,7 @@ void sphref_compute_non_pressure_acceleration(SphRef *s) {
 
 /* base_solver.py:643 */
 void sphref_update_fluid_velocity(SphRef *s) {
+#pragma omp parallel for schedule(static)
     for (int p = 0; p < s->particle_num; p++)
         if (s->particle_materials[p] == SPHREF_MAT_FLUID)
             s->particle_velocities[p] = v3_add(s->particle_velocities[p], v3_scale_l(s->dt, s->particle_accelerations[p]));
@@ -745,6 +752,7 @@ void sphref_update_fluid_velocity(SphRef *s) {
 
 /* base_solver.py:652 (incl. the emitter branch :660-666) */
 void sphref_update_fluid_position(SphRef *s) {
+#pragma omp parallel for schedule(static)
     for (int p = 0; p < s->particle_num; p++) {
         if (s->particle_materials[p] == SPHREF_MAT_FLUID) {
             s->particle_positions[p] = v3_add(s->particle_positions[p], v3_scale_l(s->dt, s->particle_velocities[p]));
@@ -770,6 +778,7 @@ void sphref_enforce_domain_boundary_3D(SphRef *s) {
     const float pad = (float)s->prm.padding;
     const float hi[3] = {(float)(s->prm.domain_size[0] - s->prm.padding), (float)(s->prm.domain_size[1] - s->prm.padding),
                          (float)(s->prm.domain_size[2] - s->prm.padding)};
+#pragma omp parallel for schedule(static)
     for (int p = 0; p < s->particle_num; p++) {
         if (s->particle_materials[p] == SPHREF_MAT_FLUID && s->particle_is_dynamic[p]) {
             float pos[3] = {s->particle_positions[p].x, s->particle_positions[p].y, s->particle_positions[p].z};
