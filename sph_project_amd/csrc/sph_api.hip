@@ -173,6 +173,7 @@ extern "C" void sph_destroy(SphHandle *h) {
     hipSetDevice(h->device);
     if (h->st.stream) hipStreamSynchronize(h->st.stream);
     slab_comm_destroy(h->comm);
+    if (h->st.push.mirror) { hipHostFree(h->st.push.mirror); h->st.push.mirror = nullptr; }
     for (auto &s : h->prof) for (auto &pr : s.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->ev_pool) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
