@@ -113,14 +113,21 @@ template <bool AF>
 struct CgApPass {
     static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
-    static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
+    static constexpr bool USES_J = false;  // pair() never looks at j (rigid neighbours are skipped: they enter D_ii and b only)
+    static constexpr bool MEDIUM_OK = true; // 5 workgroups per CU although its record is 32 B (sph_device.hpp pass_is_medium): a split A p pass of
+                                            // a 100 k-particle sheet is 3 x 416 = 1248 workgroups -- at 4 per CU (1024 resident) the last 224 run as a
+                                            // second, mostly empty round; at 5 per CU (1280) all of them are resident at once
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
     static constexpr bool HAS_REDUCE = true;   // per-workgroup partial of p . Ap (the denominator of alpha, :394): no separate dot kernel
     static constexpr int PAIR_WEIGHT = 1;
     static constexpr bool SPLIT3 = true;       // see PassSplit / k_cg_ap_combine
     static constexpr bool HAS_PROLOGUE = true;
     typedef float4 BT;
+#if SPH_FAST
+    struct Own { float m; float x, y, z; };
+#else
     struct Own { float m; float d[9]; float x, y, z; };
+#endif
     const float4 *posv, *velm; const int *meta; const float *rho; const float4 *cg_p; const float *dinv;
     float4 *cg_Ap; float *red_out;
     float4 *part; int part_stride;             // [3][part_stride] partial sums of a split launch
@@ -151,7 +158,22 @@ struct CgApPass {
         if (fuse) { const float4 r = cg_r[i]; q = make_float4(r.x + beta * q.x, r.y + beta * q.y, r.z + beta * q.z, 0.f); p_out[i] = q; }
         return q;
     }
-    __device__ void partial(const Consts &, int i, int g, const Own &o) const { part[(size_t)g * part_stride + i] = make_float4(o.x, o.y, o.z, 0.f); }
+    // fast build: the pair loop accumulates s = sum t (grad W) and D^-1 is applied to the sum afterwards (linear: D^-1 sum t g = sum t D^-1 g);
+    // nine registers less in the loop than carrying D^-1 through it, which is what lets the pass run 5 workgroups per CU
+    __device__ void apply_dinv(int i, float &x, float &y, float &z) const {
+#if SPH_FAST
+        const float *d = dinv + (size_t)i * 9;
+        const float sx = x, sy = y, sz = z;
+        x = d[0] * sx + d[1] * sy + d[2] * sz;
+        y = d[3] * sx + d[4] * sy + d[5] * sz;
+        z = d[6] * sx + d[7] * sy + d[8] * sz;
+#endif
+    }
+    __device__ void partial(const Consts &, int i, int g, const Own &o) const {
+        float x = o.x, y = o.y, z = o.z;
+        apply_dinv(i, x, y, z);
+        part[(size_t)g * part_stride + i] = make_float4(x, y, z, 0.f);
+    }
 
     __device__ float4 stage_impl(int j, BT &bj) const {
         const float4 p = posv[j];
@@ -168,8 +190,10 @@ struct CgApPass {
     __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
         if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
         o.m = velm[i].w;
+#if !SPH_FAST
 #pragma unroll
         for (int k = 0; k < 9; ++k) o.d[k] = dinv[(size_t)i * 9 + k];
+#endif
         o.x = o.y = o.z = 0.0f;
         return true;
     }
@@ -184,9 +208,7 @@ struct CgApPass {
 #if SPH_FAST
         // (-A) = -s g R^T  =>  Dinv (-A) p = -s (R.p) (Dinv g)
         const float t = -s * (R[0] * bj.x + R[1] * bj.y + R[2] * bj.z);
-        o.x += t * (o.d[0] * g[0] + o.d[1] * g[1] + o.d[2] * g[2]);
-        o.y += t * (o.d[3] * g[0] + o.d[4] * g[1] + o.d[5] * g[2]);
-        o.z += t * (o.d[6] * g[0] + o.d[7] * g[1] + o.d[8] * g[2]);
+        o.x += t * g[0]; o.y += t * g[1]; o.z += t * g[2];   // D^-1 applied to the sum (apply_dinv)
 #else
         // M = Dinv (-A), x += M p, with the roundings of the literal form (nA = -(s (g R^T)); M = Dinv nA; M p summed left
         // to right) but column by column, so that only one column of nA and of M is alive at a time (the 18 temporaries
@@ -207,6 +229,7 @@ struct CgApPass {
     }
     __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {
         const float4 p = own_p(i);
+        apply_dinv(i, o.x, o.y, o.z);
         float x = o.x * c.dt, y = o.y * c.dt, z = o.z * c.dt;
         x = fdiv(x, c.rho0); y = fdiv(y, c.rho0); z = fdiv(z, c.rho0);
         const float4 a = make_float4(x + p.x, y + p.y, z + p.z, 0.f);

@@ -788,8 +788,11 @@ k_compact_blocks(const int *__restrict__ flag, int nb, int *__restrict__ list, i
 template <class P> constexpr int pass_slot_bytes() {
     return 16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0);
 }
-template <class P> constexpr bool pass_is_medium() {
-    return SPH_FAST && P::HAS_B && pass_slot_bytes<P>() <= SPH_NBR_MEDIUM_BYTES && !pass_builds_masks<P>();
+template <class P, class = void> struct PassMediumOk { static constexpr bool value = false; };
+template <class P> struct PassMediumOk<P, decltype((void)P::MEDIUM_OK)> { static constexpr bool value = P::MEDIUM_OK; };
+template <class P> constexpr bool pass_is_medium() {   // by record size, or opted in by the functor (P::MEDIUM_OK: records up to 32 B)
+    return SPH_FAST && P::HAS_B && !pass_builds_masks<P>() &&
+           (pass_slot_bytes<P>() <= SPH_NBR_MEDIUM_BYTES || (PassMediumOk<P>::value && pass_slot_bytes<P>() <= 32));
 }
 template <class P> constexpr int nbr_tile_cap() {
     const int per_slot = pass_slot_bytes<P>();
