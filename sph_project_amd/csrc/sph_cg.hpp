@@ -114,9 +114,9 @@ struct CgApPass {
     static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = false;  // pair() never looks at j (rigid neighbours are skipped: they enter D_ii and b only)
-    static constexpr bool MEDIUM_OK = true; // 5 workgroups per CU although its record is 32 B (sph_device.hpp pass_is_medium): a split A p pass of
-                                            // a 100 k-particle sheet is 3 x 416 = 1248 workgroups -- at 4 per CU (1024 resident) the last 224 run as a
-                                            // second, mostly empty round; at 5 per CU (1280) all of them are resident at once
+    // (tried in round 3: 5 workgroups per CU for this 32-byte-record walk, so that all 3 x 416 split workgroups of the buckling sheet are
+    //  resident at once instead of 1024 + a mostly empty second round: cg_ap 24.3 -> 25.6 us, C5 slower -- the smaller tile and the
+    //  96-register budget cost more than the second round; P::MEDIUM_OK stays available in sph_device.hpp)
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
     static constexpr bool HAS_REDUCE = true;   // per-workgroup partial of p . Ap (the denominator of alpha, :394): no separate dot kernel
     static constexpr int PAIR_WEIGHT = 1;
