@@ -545,6 +545,11 @@ def run_rank(args, rank, world, local_rank):
             "frac_of_measured_copy": (achieved / copy_gbs) if (achieved and copy_gbs) else None,
             "step_frac_of_measured_copy": (step_bytes / (elapsed / args.steps) / 1e9 / copy_gbs) if copy_gbs else None,
             "secondary": secondary,
+            # the two neighbour walks of a WCSPH step are within 2-3 % of each other, so which one is "dominant" can flip between runs --
+            # and with it `frac` (24 vs 96 algorithmic bytes per particle).  Both, from the all-kernel event pre-pass of this run:
+            "all_kernels": {k: {"avg_us": 1e3 * v[1] / v[0], "alg_bytes_per_launch": ALG_BYTES[k] * n_fluid,
+                                "frac": ALG_BYTES[k] * n_fluid / (v[1] / v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                            for k, v in table.items() if k in ALG_BYTES},
             "note": "the neighbour passes are not HBM-bound: per the PMC passes they run at ~2.4 GHz with about half of the VALU issue "
                     "slots used and 40-50 % of the wave-cycles parked on waits (latency of staging + dependent LDS gathers); "
                     "`secondary` (from profiles/, not this run) carries those figures; DESIGN.md 5",
