@@ -287,6 +287,17 @@ def test_c5_scaled_buckling_scene(gpu):
     assert abs(solver.stats()["iter_cg"] - it_ref) <= 2 and it_ref >= 5
 
 
+def test_measured_copy_rate_is_plausible(gpu):
+    """sph_measure_copy_rate (the second denominator of the bench's roofline): between 1 and 8 TB/s on an MI355X, and repeatable."""
+    container, solver = H.build_product(P.dam_break_scene(end=(0.1, 0.1, 0.1)))
+    a = container.engine.measure_copy_rate(1 << 28, 8)
+    b = container.engine.measure_copy_rate(1 << 28, 8)
+    print("device copy rate: %.0f / %.0f GB/s" % (a, b))
+    assert 1000.0 < a < 8000.0 and 1000.0 < b < 8000.0 and abs(a - b) < 0.35 * max(a, b)
+    with pytest.raises(L.SphError):
+        container.engine.measure_copy_rate(16, 1)
+
+
 def test_implicit_viscosity_before_the_emitter_releases_anything(gpu):
     """The reference's final_scene4.json starts with every fluid particle above gravitationUpper: for its first 14 steps there is
     NO active fluid particle, the CG system is empty and the reference's loop leaves after one pass (|r| = 0, base_solver.py:445-461).

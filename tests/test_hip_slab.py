@@ -397,3 +397,20 @@ def test_push_transport_is_all_ranks_or_none(gpu, tmp_path, transport):
     # and without the hook the same command line comes up with the push transport
     outs2, _ = _run_ranks(cfg, 2, 3, tmp_path, extra_env={"SPH_COMM_TRANSPORT": "shm+auto"})
     assert [str(o["transport"]) for o in outs2] == ["ipc-push+shm"] * 2
+
+
+def test_exact_launch_flavour_of_the_push_transport(gpu, tmp_path, transport):
+    """SPH_SLAB_ASYNC=0: WCSPH steps over the push transport with the counts read back once per step and exact launch grids (what the
+    iterative solvers always use) -- same particles, same pairs as the asynchronous flavour."""
+    if transport != "shm+ipc":
+        pytest.skip("push transport only")
+    cfg = H.dam_break_scene(domain_end=(1.0, 1.0, 1.2), start=(0.1, 0.1, 0.08), end=(0.3, 0.3, 1.12), translation=(0, 0, 0),
+                            velocity=(0.0, -0.3, 2.0), particleSpacing=0.019)
+    outs_a, _ = _run_ranks(cfg, 2, 15, tmp_path, advance=True)
+    outs_s, _ = _run_ranks(cfg, 2, 15, tmp_path, advance=True, extra_env={"SPH_SLAB_ASYNC": "0", "SPH_COMM_TRANSPORT": "shm+ipc"})
+    for a, b in zip(outs_a, outs_s):
+        assert str(b["transport"]) == "ipc-push+shm"
+        oa, ob = np.argsort(a["ids"]), np.argsort(b["ids"])
+        np.testing.assert_array_equal(a["ids"][oa], b["ids"][ob])
+        np.testing.assert_array_equal(a["pos"][oa], b["pos"][ob])     # the same kernels in the same order: bit-identical
+        assert int(a["pairs"]) == int(b["pairs"])
