@@ -406,8 +406,9 @@ def test_exact_launch_flavour_of_the_push_transport(gpu, tmp_path, transport):
         pytest.skip("push transport only")
     cfg = H.dam_break_scene(domain_end=(1.0, 1.0, 1.2), start=(0.1, 0.1, 0.08), end=(0.3, 0.3, 1.12), translation=(0, 0, 0),
                             velocity=(0.0, -0.3, 2.0), particleSpacing=0.019)
-    outs_a, _ = _run_ranks(cfg, 2, 15, tmp_path, advance=True)
-    outs_s, _ = _run_ranks(cfg, 2, 15, tmp_path, advance=True, extra_env={"SPH_SLAB_ASYNC": "0", "SPH_COMM_TRANSPORT": "shm+ipc"})
+    (tmp_path / "a").mkdir(); (tmp_path / "s").mkdir()
+    outs_a, _ = _run_ranks(cfg, 2, 15, tmp_path / "a", advance=True)
+    outs_s, _ = _run_ranks(cfg, 2, 15, tmp_path / "s", advance=True, extra_env={"SPH_SLAB_ASYNC": "0", "SPH_COMM_TRANSPORT": "shm+ipc"})
     for a, b in zip(outs_a, outs_s):
         assert str(b["transport"]) == "ipc-push+shm"
         oa, ob = np.argsort(a["ids"]), np.argsort(b["ids"])
