@@ -188,7 +188,9 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
         int cnt = 0, st = 0;
         if (lane < 2 && w.in_ctl[lane]) {
             const HaloCtl *ctl = w.in_ctl[lane];
-            if (!halo_poll(&ctl->rec_seq, w.seq, w.timeout_ticks)) st |= SLAB_ST_TIMEOUT;
+            // (after a time-out the exchange is dead: later waits give up at once instead of stacking 30 s each on the stream)
+            const long long patience = (w.dyn_old->status & SLAB_ST_TIMEOUT) ? 0 : w.timeout_ticks;
+            if (!halo_poll(&ctl->rec_seq, w.seq, patience)) st |= SLAB_ST_TIMEOUT;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: the header and the records behind the number
             if (!st) {
                 cnt = halo_load_sys(&ctl->rec_count);
@@ -412,7 +414,8 @@ __device__ __forceinline__ bool halo_fld_handshake(HaloCtl *const out_ctl[2], co
             __hip_atomic_store(&out_ctl[lane]->fld_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         int st = 0;
-        if (lane < 2 && in_ctl[lane] && !halo_poll(&in_ctl[lane]->fld_seq, seq, timeout_ticks)) st = SLAB_ST_TIMEOUT;
+        const long long patience = (dyn->status & SLAB_ST_TIMEOUT) ? 0 : timeout_ticks;   // fail fast once the exchange is dead
+        if (lane < 2 && in_ctl[lane] && !halo_poll(&in_ctl[lane]->fld_seq, seq, patience)) st = SLAB_ST_TIMEOUT;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         st = __shfl(st, 0, 64) | __shfl(st, 1, 64);
         if (lane == 0) {

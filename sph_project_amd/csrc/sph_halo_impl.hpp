@@ -37,6 +37,14 @@ static int halo_grid(int count_hint) {   // grid-stride kernels: enough workgrou
     int g = cdiv(count_hint > 0 ? count_hint : 1, 256);
     return g > 2048 ? 2048 : g;
 }
+// The kernels that WAIT for a neighbour's message (every workgroup polls) stay small: a spinning workgroup holds its CU slot, and when
+// several ranks share one GPU (the test rig; 8 ranks x hundreds of pollers filled every slot of the chip and the kernels that had to
+// PRODUCE the awaited messages could not be scheduled until the waits timed out) the pollers must leave room for everybody's producers.
+// 64 workgroups stride through 100 k records in ~6 trips each: a few microseconds.
+static int halo_grid_wait(int count_hint) {
+    const int g = halo_grid(count_hint);
+    return g > 64 ? 64 : g;
+}
 
 static void l_halo_unpack2(State &s, int n_old, int bound_app, int bound_live, int count_hint) {
     HaloTables t;
@@ -54,7 +62,7 @@ static void l_halo_unpack2(State &s, int n_old, int bound_app, int bound_live, i
     w.dyn_old = s.dyn + ((seq - 1) & 1u); w.dyn_new = s.dyn + (seq & 1u);
     w.mirror = (volatile SlabDyn *)s.push.mirror;
     s.dyn_cur = s.dyn + (seq & 1u);
-    hipLaunchKernelGGL(k_halo_unpack2, dim3(halo_grid(count_hint)), dim3(256), 0, s.stream, s.c, w, s.z_lo, s.z_hi, s.posv.cur(), s.velm.cur(),
+    hipLaunchKernelGGL(k_halo_unpack2, dim3(halo_grid_wait(count_hint)), dim3(256), 0, s.stream, s.c, w, s.z_lo, s.z_hi, s.posv.cur(), s.velm.cur(),
                        s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(), s.xidx[s.xcur], s.orig.cur(), t, HaloHash{s.cellid, s.rank, s.cell_count});
 }
 
@@ -83,7 +91,7 @@ static void l_halo_push_fields(State &s, int kind, float *f0, float4 *v, int cou
 }
 static void l_halo_pull_fields(State &s, int kind, float *f0, float4 *v, int count_hint) {
     HaloFld a = halo_fld_args(s, s.push.fld_seq, kind == 2 ? s.rho_raw : f0, v);
-    const dim3 g(halo_grid(count_hint)), b(256);
+    const dim3 g(halo_grid_wait(count_hint)), b(256);
     if (kind == 0) hipLaunchKernelGGL(k_halo_unpack2f<0>, g, b, 0, s.stream, a);
     else if (kind == 1) hipLaunchKernelGGL(k_halo_unpack2f<1>, g, b, 0, s.stream, a);
     else hipLaunchKernelGGL(k_halo_unpack2f<2>, g, b, 0, s.stream, a);
@@ -93,7 +101,7 @@ static void l_halo_selftest(State &s, int n, int tag, int tag_down, int tag_up, 
     if (!s.dyn_cur) s.dyn_cur = s.dyn;
     HaloFld a = halo_fld_args(s, ++s.push.fld_seq, nullptr, nullptr);
     hipLaunchKernelGGL(k_halo_selftest_push, dim3(halo_grid(n)), dim3(256), 0, s.stream, (float *)a.out[0], (float *)a.out[1], n, tag);
-    hipLaunchKernelGGL(k_halo_selftest_check, dim3(halo_grid(n)), dim3(256), 0, s.stream, a, n, tag_down, tag_up, bad_dev);
+    hipLaunchKernelGGL(k_halo_selftest_check, dim3(halo_grid_wait(n)), dim3(256), 0, s.stream, a, n, tag_down, tag_up, bad_dev);
 }
 
 static void l_halo_unpack_append(State &s, int side, int count, int offset) {
