@@ -446,6 +446,18 @@ def test_bench_spawns_two_ranks_without_torch(gpu):
     assert "import torch" not in src and "torch.distributed" not in src.replace("torch.distributed.run", "")
 
 
+def test_bench_eight_ranks_share_one_gpu(gpu):
+    """The driver's 8-rank job (weak scaling: 8 x 1,231,200 particles, every rank topology: two edge ranks, six with both neighbours) with all
+    ranks on this box's ONE GPU -- push transport, asynchronous steps, 8-way control plane.  Round 3 found here that workgroups spinning on a
+    neighbour's message hold their CU slots: with every workgroup of the consuming kernels polling, 8 ranks filled the chip with pollers and
+    the kernels that had to produce the awaited messages were never scheduled (all waits timed out); the waiting kernels are capped at 64
+    workgroups now.  Oversubscription only -- one rank per GPU cannot starve itself -- but a hang is a hang."""
+    out = _bench(["--gpus", "8", "--steps", "5", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline", "--motion-step", "0", "--no-extras"],
+                 {"SPH_COMM_TRANSPORT": "shm+ipc", "SPH_COMM_TIMEOUT_S": "60"}, timeout=900)
+    assert out["n_gpus"] == 8 and out["config"]["particles"] == 8 * 1231200 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"].startswith("z-slab x8, ipc-push+shm") and out["value"] > 0
+
+
 def test_bench_stops_all_ranks_when_one_dies(gpu):
     """A rank that dies leaves its neighbour blocked in a halo receive; the launcher stops the survivors (its own children, by
     pid) and exits non-zero instead of hanging."""
