@@ -252,7 +252,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     CHK_CREATE(dalloc(h, &s.acc, cap));
     s.nbr_mask = nullptr; s.masks_valid = 0;
     s.nbr_mask_hi = nullptr;
-    if (!getenv("SPH_NO_MASK_REUSE")) { CHK_CREATE(dalloc(h, &s.nbr_mask, cap * 9)); CHK_CREATE(dalloc(h, &s.nbr_mask_hi, cap * 9)); }
+    if (!getenv("SPH_NO_MASK_REUSE")) { CHK_CREATE(dalloc(h, &s.nbr_mask, cap * 9 + 256)); CHK_CREATE(dalloc(h, &s.nbr_mask_hi, cap * 9 + 256)); }   // + 256: the lanes past the last particle of the last tile read (and drop) a word too
     s.lane_perm = nullptr; s.perm_n = -1;
     s.loop_flag = nullptr; s.loop_slot = 0; s.loop_kind = 0; s.loop_denom = 1.0f; s.loop_thr = 0.0;
     CHK_CREATE(dalloc(h, &s.blk_hdr, (cap + 255) / 256 * 20));

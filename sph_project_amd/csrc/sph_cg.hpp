@@ -40,12 +40,13 @@ struct CgPreparePass {
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
     __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
-        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
+        bool ok = true;   // no early return: begin()'s loads go out with the rest of the prologue (k_nbr_pass)
+        if (!AF || c.ghosts) ok = META_ACTIVE_FLUID(meta[i]);
         o.m = velm[i].w; o.rho = rho[i];
 #pragma unroll
         for (int k = 0; k < 9; ++k) o.a[k] = 0.0f;
         o.bx = o.by = o.bz = 0.0f;
-        return true;
+        return ok;
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int) const {
@@ -188,14 +189,15 @@ struct CgApPass {
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
     __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
-        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
+        bool ok = true;   // no early return: begin()'s loads go out with the rest of the prologue (k_nbr_pass)
+        if (!AF || c.ghosts) ok = META_ACTIVE_FLUID(meta[i]);
         o.m = velm[i].w;
 #if !SPH_FAST
 #pragma unroll
         for (int k = 0; k < 9; ++k) o.d[k] = dinv[(size_t)i * 9 + k];
 #endif
         o.x = o.y = o.z = 0.0f;
-        return true;
+        return ok;
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int) const {

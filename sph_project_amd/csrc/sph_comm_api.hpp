@@ -304,7 +304,7 @@ extern "C" int sph_comm_allreduce(SphHandle *h, double *inout, int count, int op
     HIPCHK(h, hipMemcpyAsync(c.red_dev, c.red_host, sizeof(double) * count, hipMemcpyHostToDevice, s.stream));
     NCCLCHK(h, ncclAllReduce(c.red_dev, c.red_dev, (size_t)count, ncclDouble, op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin), (ncclComm_t)c.nccl, s.stream));
     HIPCHK(h, hipMemcpyAsync(c.red_host, c.red_dev, sizeof(double) * count, hipMemcpyDeviceToHost, s.stream));
-    HIPCHK(h, hipStreamSynchronize(s.stream));
+    { int rcs = stream_sync_bounded(h, "all-reduce over RCCL"); if (rcs) return rcs; }
     memcpy(inout, c.red_host, sizeof(double) * count);
     return SPH_OK;
 }
@@ -340,7 +340,7 @@ extern "C" int sph_comm_selftest(SphHandle *h, int n) {
         NCCLCHK(h, ncclRecv(c.self_dev + n, (size_t)n, ncclFloat, from, (ncclComm_t)c.nccl, s.stream));
         NCCLCHK(h, ncclGroupEnd());
         HIPCHK(h, hipMemcpyAsync(dst.data(), c.self_dev + n, sizeof(float) * n, hipMemcpyDeviceToHost, s.stream));
-        HIPCHK(h, hipStreamSynchronize(s.stream));
+        { int rcs = stream_sync_bounded(h, "RCCL self-test"); if (rcs) return rcs; }
     } else {
         // shm: the mailbox pair of the "up" direction, wrapped around (rank size-1 -> rank 0 uses its unused up box)
         if ((size_t)n * 4 > c.mbox_cap) return fail(h, SPH_ERR_CAPACITY, "comm_selftest: %d floats exceed the mailbox", n);
@@ -413,7 +413,7 @@ static int comm_exchange(SphHandle *h, const void *send[2], const size_t bytes_s
         }
         NCCLCHK(h, ncclGroupEnd());
         HIPCHK(h, hipMemcpyAsync(c.cnt_host + 4, c.cnt_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
-        HIPCHK(h, hipStreamSynchronize(s.stream));
+        { int rcs = stream_sync_bounded(h, "halo count exchange over RCCL"); if (rcs) return rcs; }
         bytes_recv[0] = has[0] ? (size_t)c.cnt_host[6] : 0;
         bytes_recv[1] = has[1] ? (size_t)c.cnt_host[7] : 0;
     }
@@ -509,7 +509,7 @@ static int push_setup(SphHandle *h) {
         const size_t bs[2] = {sizeof(Hello), sizeof(Hello)};
         size_t br[2] = {sizeof(Hello), sizeof(Hello)};
         int rc = comm_exchange(h, send, bs, recv, br, true); if (rc) return rc;
-        HIPCHK(h, hipStreamSynchronize(s.stream));
+        rc = stream_sync_bounded(h, "push transport hello exchange"); if (rc) return rc;   // a dead neighbour must not hang the setup
         const int peer[2] = {c.rank - 1, c.rank + 1};
         for (int side = 0; side < 2; ++side) {
             if (!(side == 0 ? s.has_down : s.has_up)) continue;
@@ -617,7 +617,7 @@ static int slab_rebalance(SphHandle *h) {
     if (c.kind == 1) {
         NCCLCHK(h, ncclAllReduce(c.hist_dev, c.hist_dev, (size_t)len, ncclInt32, ncclSum, (ncclComm_t)c.nccl, s.stream));
         HIPCHK(h, hipMemcpyAsync(c.hist_host, c.hist_dev, sizeof(int) * len, hipMemcpyDeviceToHost, s.stream));
-        HIPCHK(h, hipStreamSynchronize(s.stream));
+        { int rcs = stream_sync_bounded(h, "histogram all-reduce over RCCL"); if (rcs) return rcs; }
     } else {
         HIPCHK(h, hipMemcpyAsync(c.hist_host, c.hist_dev, sizeof(int) * len, hipMemcpyDeviceToHost, s.stream));
         HIPCHK(h, hipStreamSynchronize(s.stream));

@@ -422,6 +422,14 @@ template <class P> constexpr bool pass_reuses_masks() { return (PassModes<P>::va
 // P::HAS_PROLOGUE: the functor has `bool prologue(DevScalars *) const`, run by every thread of a workgroup before anything else
 // (it may use barriers and set `mutable` members, e.g. a coefficient every workgroup reduces from per-workgroup partials);
 // false = this workgroup has nothing to do.
+// P::MASK_PIPELINE = false: the functor has no three registers to spare for next round's mask words across its pair loop; they are
+// then loaded at the top of the round (still without a wait of their own).
+template <class P, class = void> struct PassMaskPipe { static constexpr bool value = true; };
+template <class P> struct PassMaskPipe<P, decltype((void)P::MASK_PIPELINE)> { static constexpr bool value = P::MASK_PIPELINE; };
+template <class P, class = void> struct PassUsesJ0 { static constexpr bool value = true; };
+template <class P> struct PassUsesJ0<P, decltype((void)P::USES_J)> { static constexpr bool value = P::USES_J; };
+// (default: the all-fluid instantiations pipeline; the ones that tell rigid neighbours apart -- USES_J -- run closer to their limit)
+template <class P> constexpr bool pass_mask_pipe() { return PassMaskPipe<P>::value && !(P::HAS_B && PassUsesJ0<P>::value); }
 template <class P, class = void> struct PassPrologue { static constexpr bool value = false; };
 template <class P> struct PassPrologue<P, decltype((void)P::HAS_PROLOGUE)> { static constexpr bool value = P::HAS_PROLOGUE; };
 
@@ -782,6 +790,9 @@ k_compact_blocks(const int *__restrict__ flag, int nb, int *__restrict__ list, i
 #ifndef SPH_NBR_MEDIUM_BYTES
 #define SPH_NBR_MEDIUM_BYTES 28
 #endif
+#ifndef SPH_HEAVY_SB
+#define SPH_HEAVY_SB 3   // staging slots per batch of the wide records (32-36 B per slot; all 5 at once spill at 128 VGPRs)
+#endif
 #ifndef SPH_MEDIUM_SB
 #define SPH_MEDIUM_SB 2   // staging slots per batch of a medium functor
 #endif
@@ -799,6 +810,42 @@ template <class P> constexpr int nbr_tile_cap() {
     const int budget = pass_is_medium<P>() ? 32768 : 40960;   // a fifth / a quarter of the CU's 160 KB
     const int slots = (budget - 9 * NBR_CS_PITCH * 2 - 1536) / per_slot - NBR_PAD;   // 1.5 KB for the small arrays and the allocation granule
     return slots > 1280 ? 1280 : slots / 8 * 8;
+}
+// Staging plan of one round of one x-offset group (workgroup-uniform; see the group loop of k_nbr_pass): which of the group's three
+// runs go into the tile (bit q of rm), at which tile offset (lo_[q] = offset - run start; INT_MIN: not staged), how many slots in all.
+template <int CAP>
+__device__ __forceinline__ void nbr_plan(const int *__restrict__ hdr, int g, int qa, int fg, int (&rs_)[3], int (&ln_)[3], int (&lo_)[3],
+                                         int &total, int &qb, unsigned &rm, bool &overflow) {
+    total = 0; qb = 3; rm = 7u; overflow = false;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        rs_[q] = hdr[2 + g * 3 + q];
+        ln_[q] = hdr[11 + g * 3 + q] > 0 ? hdr[11 + g * 3 + q] : 0;
+    }
+    // Thin grids (nz <= the workgroup's cell span + 2: small scenes, and the slabs of a sharded scene -- C4 on 8 ranks has 12
+    // layers per rank): the three runs of a group are windows of one and the same stretch of the sorted arrays, nz cells apart,
+    // and overlap.  Stage that stretch ONCE (all three runs share one tile offset) instead of three overlapping copies:
+    // 34 + 2 nz cells instead of 102 -- at nz = 12 40 % less staging traffic and LDS, and piled-up groups fit more often.
+    const int ulen = rs_[2] + ln_[2] - rs_[0];
+    const bool chain = ln_[0] > 0 && ln_[1] > 0 && ln_[2] > 0 && rs_[1] >= rs_[0] && rs_[1] <= rs_[0] + ln_[0] &&
+                       rs_[2] >= rs_[1] && rs_[2] <= rs_[1] + ln_[1] && ulen >= ln_[2];
+    if (qa == 0 && chain && ulen <= CAP && fg != 1 && fg != 5) {
+        lo_[0] = lo_[1] = lo_[2] = -rs_[0];
+        total = ulen;
+    } else if (qa == 0 && ln_[0] + ln_[1] + ln_[2] <= CAP && fg != 1) {   // the usual case: the whole group fits
+        lo_[0] = -rs_[0]; lo_[1] = ln_[0] - rs_[1]; lo_[2] = ln_[0] + ln_[1] - rs_[2];
+        total = ln_[0] + ln_[1] + ln_[2];
+    } else {   // the round is the longest prefix [qa, qb) of the runs not yet done that fits
+        rm = 0u; qb = qa;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            lo_[q] = INT_MIN;
+            if (q >= qa && q == qb && !overflow) {
+                if (fg != 1 && total + ln_[q] <= CAP) { lo_[q] = total - rs_[q]; total += ln_[q]; qb = q + 1; rm |= 1u << q; }
+                else if (q == qa) { overflow = true; qb = q + 1; rm |= 1u << q; }
+            }
+        }
+    }
 }
 // LDS bytes of k_nbr_pass<P, MASKMODE> (tile + cell_start windows + small change)
 // debug (build with -DSPH_TIMELINE, run with SPH_DEBUG_MODE=20): shader-clock stamps of workgroup phases, thread 0, slot k of 16 per workgroup
@@ -819,7 +866,7 @@ template <class P, int MASKMODE> constexpr int nbr_lds_bytes() {
 #define SPH_NBR_WAVES_LIGHT (SPH_FAST ? 5 : 4)
 #endif
 #ifndef SPH_NBR_WAVES_HEAVY
-#define SPH_NBR_WAVES_HEAVY 4
+#define SPH_NBR_WAVES_HEAVY (SPH_FAST ? 4 : 3)   // strict build (IEEE division / sqrt sequences): 3, i.e. <= 168 VGPRs, rather than spills
 #endif
 template <class P, int MASKMODE> constexpr int nbr_waves_per_simd() {
     return P::HAS_B ? (pass_is_medium<P>() ? 5 : SPH_NBR_WAVES_HEAVY) : (sizeof(typename P::Own) <= 8 ? SPH_NBR_WAVES_LIGHT : 4);
@@ -851,8 +898,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     float2 *const sZW = sT + (CAP + PAD);
     constexpr int ZW_OFF = (CAP + PAD) * 8;
     __shared__ BT sB[P::HAS_B ? CAP + PAD : 1];
-    typedef typename PassC<P>::type CT;
-    __shared__ CT sC[PassC<P>::value ? CAP + PAD : 1];
+    __shared__ typename PassC<P>::type sC[PassC<P>::value ? CAP + PAD : 1];
     __shared__ unsigned short s_cs[9][NBR_CS_PITCH];   // cell_start - run start
     __shared__ int s_loff[9];   // tile offset - run start of every run (INT_MIN: not staged)
 
@@ -878,27 +924,68 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     bool cs_lds = span >= 0 && span <= NBR_CS_SPAN;
 #pragma unroll
     for (int k = 0; k < 9; ++k) cs_lds = cs_lds && hdr[11 + k] < 65536;   // windows are cached as 16-bit offsets
-    // in flight together: own particle, cell_start windows (entry e of run k <-> cell cfirst + shift_k - 1 + e)
-    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) pi = p.posv[i];
-    if (cs_lds && tid < span + 4) {
+    // In flight together, behind the one dependent load above (the lane permutation): own particle and what begin() reads of it,
+    // the first staging round, the cell_start windows.  Straight-line code on a clamped index: a load inside a divergent `if (valid)`
+    // gets an `s_waitcnt vmcnt(0)` at the end of its block (the merge of its result), which used to serialise the prologue into
+    // five memory round trips (permutation -> position -> windows -> begin() -> first staging round).  begin() only reads.
+    const int ic = valid ? i : i0;
+    const float4 pi = p.posv[ic];
+    Own own;
+    bool active = p.begin(c, ic, pi, own) && valid;
+    unsigned mk0[3] = {0u, 0u, 0u};   // first mask words of the first group's runs
+    if (MASKMODE == 2 && pass_mask_pipe<P>()) {
+        const int g0 = (PassSplit<P>::value && gridDim.y == 3) ? (int)blockIdx.y : 0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            int cell = cfirst + (k / 3 - 1) * c.ny * c.nz + (k % 3 - 1) * c.nz - 1 + tid;
-            cell = cell < 0 ? 0 : (cell > c.G ? c.G : cell);
-            s_cs[k][tid] = (unsigned short)(cell_start[cell] - hdr[2 + k]);
+        for (int q = 0; q < 3; ++q) mk0[q] = nbr_mask[(size_t)(g0 * 3 + q) * mask_stride + i];   // (the array has a tile of slack)
+    }
+    // -DSPH_PRESTAGE (off): the first staging round depends on the header alone, so its global loads can go out HERE and be written to
+    // the tile after the prologue's barrier; the records sit in registers only across the prologue, where little else is live.  One
+    // round trip less per workgroup -- and 1-2 % SLOWER at C2 / C3 (profiles/r03w_ab_round_trips.txt): kept as a switch, like PAIR2.
+    typedef typename PassC<P>::type CT;
+    const int g_first = (PassSplit<P>::value && gridDim.y == GROUPS) ? (int)blockIdx.y : 0;
+#ifdef SPH_PRESTAGE
+    constexpr bool PRESTAGE = SPH_FAST || sizeof(BT) < 16;   // (the strict build's widest functors sit at the 128-VGPR limit already)
+#else
+    constexpr bool PRESTAGE = false;
+#endif
+    float4 pa_[PRESTAGE ? NS : 1];
+    BT pb_[PRESTAGE ? NS : 1];
+    CT pc_[PRESTAGE ? NS : 1];
+    int ptotal = 0;
+    if constexpr (PRESTAGE) {
+        int rs_[RPG], ln_[RPG], lo_[RPG], qb; unsigned rm; bool overflow;
+        nbr_plan<CAP>(hdr, g_first, 0, c.force_global, rs_, ln_, lo_, ptotal, qb, rm, overflow);
+        if (c.force_global == 10 || c.force_global == 11) ptotal = 0;
+        const int n0 = lo_[0] != INT_MIN ? ln_[0] : 0;
+        const int n01 = n0 + (lo_[1] != INT_MIN ? ln_[1] : 0);
+        if (ptotal > 0) {   // uniform.  Slots past the end re-read the last record (same cache line) instead of branching:
+#pragma unroll              // the whole prologue stays one basic block, and the scheduler puts every load ahead of the first wait
+            for (int u = 0; u < NS; ++u) {
+                int t = tid + u * BLOCK;
+                t = t < ptotal ? t : ptotal - 1;
+                const int j = t < n0 ? t - lo_[0] : (t < n01 ? t - lo_[1] : t - lo_[2]);
+                pa_[u] = pass_stage(p, c, j, pb_[u], pc_[u]);
+            }
         }
     }
-    Own own;
-    bool active = false;
-    int cx = 0, cy = 0, cz = 0, lin = 0;
-    if (valid) {
-        cx = cell_coord(pi.x, c.grid_size, c.nx);
-        cy = cell_coord(pi.y, c.grid_size, c.ny);
-        cz = cell_coord_z(c, pi.z);
-        lin = (cx * c.ny + cy) * c.nz + cz;
-        active = p.begin(c, i, pi, own);
+    if (cs_lds) {   // uniform; threads past the window re-read its last entry
+        const int tc = tid < span + 4 ? tid : span + 3;
+        int cs_[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            int cell = cfirst + (k / 3 - 1) * c.ny * c.nz + (k % 3 - 1) * c.nz - 1 + tc;
+            cell = cell < 0 ? 0 : (cell > c.G ? c.G : cell);
+            cs_[k] = cell_start[cell];
+        }
+        if (tid < span + 4) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s_cs[k][tid] = (unsigned short)(cs_[k] - hdr[2 + k]);
+        }
     }
+    const int cx = cell_coord(pi.x, c.grid_size, c.nx);
+    const int cy = cell_coord(pi.y, c.grid_size, c.ny);
+    const int cz = cell_coord_z(c, pi.z);
+    const int lin = (cx * c.ny + cy) * c.nz + cz;
     if (__syncthreads_or(active ? 1 : 0)) {  // workgroup-uniform; also publishes s_cs
         NBR_STAMP(1);
         // this lane's z window
@@ -908,6 +995,21 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         const int e1 = e0 + (z1 - z0) + 1;
         unsigned npairs = 0;
         const int gsplit = (PassSplit<P>::value && gridDim.y == GROUPS) ? (int)blockIdx.y : -1;   // uniform: one group only
+        bool prestaged = false;   // the first round's records are already on their way (above)
+        unsigned mkn[RPG] = {mk0[0], mk0[1], mk0[2]};   // first mask words of the coming round's group
+        if constexpr (PRESTAGE) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int t = tid + u * BLOCK;
+                if (t < ptotal) {
+                    sXY[t] = make_float2(pa_[u].x, pa_[u].y);
+                    sZW[t] = make_float2(pa_[u].z, pa_[u].w);
+                    if (P::HAS_B) sB[t] = pb_[u];
+                    if (PassC<P>::value) sC[t] = pc_[u];
+                }
+            }
+            prestaged = true;
+        }
 #pragma unroll 1
         for (int g = gsplit >= 0 ? gsplit : 0, qa = 0; g < (c.force_global == 11 ? 0 : (gsplit >= 0 ? gsplit + 1 : GROUPS)); ) {
             // One group = the three runs of an x offset.  Its runs are staged in ROUNDS (uniform plan): a round takes the longest
@@ -916,49 +1018,51 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             // A run that does not fit the tile on its own is a round of its own and is walked out of L2.  Runs are consumed in
             // order, so the accumulation order stays the reference's.
             int rs_[RPG], ln_[RPG], lo_[RPG];
-            int total = 0, qb = RPG;
-            unsigned rm = 7u;            // runs of this round (bit q)
-            bool overflow = false;
-#pragma unroll
-            for (int q = 0; q < RPG; ++q) {
-                rs_[q] = hdr[2 + g * RPG + q];
-                ln_[q] = hdr[11 + g * RPG + q] > 0 ? hdr[11 + g * RPG + q] : 0;
-            }
-            // Thin grids (nz <= the workgroup's cell span + 2: small scenes, and the slabs of a sharded scene -- C4 on 8 ranks has 12
-            // layers per rank): the three runs of a group are windows of one and the same stretch of the sorted arrays, nz cells apart,
-            // and overlap.  Stage that stretch ONCE (all three runs share one tile offset) instead of three overlapping copies:
-            // 34 + 2 nz cells instead of 102 -- at nz = 12 40 % less staging traffic and LDS, and piled-up groups fit more often.
-            const int ulen = rs_[2] + ln_[2] - rs_[0];
-            const bool chain = ln_[0] > 0 && ln_[1] > 0 && ln_[2] > 0 && rs_[1] >= rs_[0] && rs_[1] <= rs_[0] + ln_[0] &&
-                               rs_[2] >= rs_[1] && rs_[2] <= rs_[1] + ln_[1] && ulen >= ln_[2];
-            if (qa == 0 && chain && ulen <= CAP && c.force_global != 1 && c.force_global != 5) {
-                lo_[0] = lo_[1] = lo_[2] = -rs_[0];
-                total = ulen;
-            } else if (qa == 0 && ln_[0] + ln_[1] + ln_[2] <= CAP && c.force_global != 1) {   // the usual case: the whole group fits
-                lo_[0] = -rs_[0]; lo_[1] = ln_[0] - rs_[1]; lo_[2] = ln_[0] + ln_[1] - rs_[2];
-                total = ln_[0] + ln_[1] + ln_[2];
-            } else {   // the round is the longest prefix [qa, qb) of the runs not yet done that fits
-                rm = 0u; qb = qa;
-#pragma unroll
-                for (int q = 0; q < RPG; ++q) {
-                    lo_[q] = INT_MIN;
-                    if (q >= qa && q == qb && !overflow) {
-                        if (c.force_global != 1 && total + ln_[q] <= CAP) { lo_[q] = total - rs_[q]; total += ln_[q]; qb = q + 1; rm |= 1u << q; }
-                        else if (q == qa) { overflow = true; qb = q + 1; rm |= 1u << q; }
-                    }
-                }
-            }
+            int total, qb;
+            unsigned rm;                 // runs of this round (bit q)
+            bool overflow;
+            nbr_plan<CAP>(hdr, g, qa, c.force_global, rs_, ln_, lo_, total, qb, rm, overflow);
 #define NBR_IN_ROUND(q) ((rm >> (q)) & 1u)
             if (tid < RPG) {
                 s_loff[g * RPG + tid] = tid == 0 ? lo_[0] : (tid == 1 ? lo_[1] : lo_[2]);
                 if (overflow && tid == qa && (tid == 0 ? ln_[0] : (tid == 1 ? ln_[1] : ln_[2])) > 0) atomicAdd(&scal->fallback[c.stat_bank][b & (SPH_STAT_SLOTS - 1)], 1ull);
             }
-            // first mask word of this group's runs ([run][particle] layout): issued first, nothing below depends on them
-            // until the staging barrier has passed
-            unsigned mk[RPG] = {0u, 0u, 0u}, mh[RPG] = {0u, 0u, 0u};
-            if (MASKMODE == 2 && active && c.force_global != 12) {
+            // Everything this round reads from global memory goes out in ONE round trip (round 3; it used to be up to five: a load
+            // under a divergent `if` is waited for at the end of its block, and the batches of a wide record waited for each other):
+            // the first mask words were requested one iteration ago (mkn), the staging loads follow here on clamped indices (slots
+            // past the end re-read the last record), then the next round's mask words and the rare second mask words; the first
+            // wait is the one in front of the tile writes.
+            unsigned mk[RPG], mh[RPG] = {0u, 0u, 0u};
+            if constexpr (pass_mask_pipe<P>() || MASKMODE != 2) {
 #pragma unroll
-                for (int q = 0; q < RPG; ++q) if (NBR_IN_ROUND(q)) mk[q] = nbr_mask[(size_t)(g * RPG + q) * mask_stride + i];
+                for (int q = 0; q < RPG; ++q) mk[q] = mkn[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < RPG; ++q) mk[q] = nbr_mask[(size_t)(g * RPG + q) * mask_stride + i];
+            }
+            // stage the runs that fit; consecutive t -> consecutive j: coalesced.  SB slots per batch: all of them where the
+            // registers allow it (the medium functors' 96-VGPR budget and the strict build's wide records do not).
+            constexpr int SB = pass_is_medium<P>() ? (NS > SPH_MEDIUM_SB ? SPH_MEDIUM_SB : NS)
+                                                   : ((P::HAS_B && sizeof(BT) >= 16) ? ((PassUsesJ0<P>::value || !SPH_FAST) ? 2 : (SPH_HEAVY_SB < NS ? SPH_HEAVY_SB : NS)) : NS);
+            const int n0 = lo_[0] != INT_MIN ? ln_[0] : 0;
+            const int n01 = n0 + (lo_[1] != INT_MIN ? ln_[1] : 0);
+            const bool stage_now = total > 0 && c.force_global != 10 && !prestaged;   // uniform
+            float4 a_[SB];
+            BT b_[SB];
+            CT c_[SB];
+            if (stage_now) {
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    int t = tid + u * BLOCK;
+                    t = t < total ? t : total - 1;
+                    const int j = t < n0 ? t - lo_[0] : (t < n01 ? t - lo_[1] : t - lo_[2]);
+                    a_[u] = pass_stage(p, c, j, b_[u], c_[u]);
+                }
+            }
+            if (MASKMODE == 2 && pass_mask_pipe<P>()) {   // first mask words of the NEXT round's group ([run][particle] layout)
+                const int gn = qb >= RPG ? (g + 1 < GROUPS ? g + 1 : g) : g;
+#pragma unroll
+                for (int q = 0; q < RPG; ++q) mkn[q] = nbr_mask[(size_t)(gn * RPG + q) * mask_stride + i];
             }
             // candidate sub-ranges of this lane's particle in the three runs (from the cached cell_start windows)
             bool inr[RPG];
@@ -985,22 +1089,26 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     wide = wide || m_[q] > 32;
                     longrun = longrun || m_[q] > 64;
                 }
-                // second word only for the runs beyond 32 candidates; a run without candidates (or out of range) may hold
-                // a stale first word
+                // second word only for the runs beyond 32 candidates; a run without candidates (or out of range, or of another
+                // round, or of an inactive lane) may hold a stale first word
                 if (MASKMODE == 2 && m_[q] > 32 && c.force_global != 12) mh[q] = nbr_mask_hi[(size_t)k * mask_stride + i];
-                if (MASKMODE == 2 && m_[q] <= 0) mk[q] = 0u;
+                if (MASKMODE == 2 && (m_[q] <= 0 || c.force_global == 12)) mk[q] = 0u;
             }
-            // stage the runs that fit: <= 4 slots per thread; the loads of a batch are all issued before its first LDS
-            // write (one global round trip per batch; wide records go in two batches to stay within the VGPR budget);
-            // consecutive t -> consecutive j: coalesced
-            constexpr int SB = (P::HAS_B && sizeof(BT) >= 16) ? 2 : (pass_is_medium<P>() && NS > SPH_MEDIUM_SB ? SPH_MEDIUM_SB : NS);   // slots per batch (medium functors: 96-VGPR budget)
-            const int n0 = lo_[0] != INT_MIN ? ln_[0] : 0;
-            const int n01 = n0 + (lo_[1] != INT_MIN ? ln_[1] : 0);
+            if (stage_now) {
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int t = tid + u * BLOCK;
+                    if (t < total) {
+                        sXY[t] = make_float2(a_[u].x, a_[u].y);
+                        sZW[t] = make_float2(a_[u].z, a_[u].w);
+                        if (P::HAS_B) sB[t] = b_[u];
+                        if (PassC<P>::value) sC[t] = c_[u];
+                    }
+                }
+            }
+            // the remaining batches of a record too wide to be staged at once
 #pragma unroll 1
-            for (int u0 = 0; u0 < NS && u0 * BLOCK < total && c.force_global != 10; u0 += SB) {
-                float4 a_[SB];
-                BT b_[SB];
-                CT c_[SB];
+            for (int u0 = SB; u0 < NS && u0 * BLOCK < total && stage_now; u0 += SB) {
 #pragma unroll
                 for (int u = 0; u < SB; ++u) {
                     const int t = tid + (u0 + u) * BLOCK;
@@ -1020,6 +1128,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     }
                 }
             }
+            prestaged = false;
             __syncthreads();
             NBR_STAMP(2 + g * 4);
             // the merged loop handles runs of <= 64 candidates out of the tile (one or two mask words per run); anything

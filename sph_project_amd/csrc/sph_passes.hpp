@@ -103,7 +103,8 @@ struct NonPressurePass {
     }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
     __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
-        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
+        bool ok = true;   // no early return: begin()'s loads go out with the rest of the prologue (k_nbr_pass)
+        if (!AF || c.ghosts) ok = META_ACTIVE_FLUID(meta[i]);
         float4 v = velm[i];
         if (visc_vel) { const float4 u = visc_vel[i]; v.x = u.x; v.y = u.y; v.z = u.z; }  // base_solver.py:464
         o.vx = v.x; o.vy = v.y; o.vz = v.z; o.m = v.w;
@@ -111,7 +112,7 @@ struct NonPressurePass {
         o.st_m = fdiv(c.st, v.w);
         o.sx = o.sy = o.sz = 0.0f;
         o.ax = o.ay = o.az = 0.0f;
-        return true;
+        return ok;
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int j) const {
@@ -211,14 +212,15 @@ struct PressurePass {
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
     __device__ bool begin(const Consts &c, int i, const float4 &pi, Own &o) const {
-        if (!AF) { const int m = meta[i]; if (!META_ACTIVE_FLUID(m) || !META_DYN(m)) return false; }
-        else if (c.ghosts && META_GHOST(meta[i])) return false;
+        bool ok = true;   // no early return: begin()'s loads go out with the rest of the prologue (k_nbr_pass)
+        if (!AF) { const int m = meta[i]; ok = META_ACTIVE_FLUID(m) && META_DYN(m); }
+        else if (c.ghosts) ok = !META_GHOST(meta[i]);
         o.x = pi.x; o.y = pi.y; o.z = pi.z; o.m0 = rho0 * pi.w;
         o.pt = ptm[i]; o.p = prs[i];
         const float r = rho[i];
         o.rho2 = r * r;
         o.ax = o.ay = o.az = 0.0f;
-        return true;
+        return ok;
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int j) const {
@@ -269,6 +271,10 @@ struct WcsphForcePass {
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, HAS_C = true, COUNT_PAIRS = true;
+#ifndef SPH_FORCE_MASK_PIPE
+#define SPH_FORCE_MASK_PIPE 0
+#endif
+    static constexpr bool MASK_PIPELINE = SPH_FORCE_MASK_PIPE && AF;   // the pair loop holds 111-124 of 128 VGPRs: batches of 3 OR the pipeline
     static constexpr int PAIR_WEIGHT = 3;  // surface tension (:210) + viscosity (:232) + pressure (:136)
     static constexpr bool HAS_REDUCE = false;
     typedef float4 BT;
@@ -297,11 +303,15 @@ struct WcsphForcePass {
         return make_float4(p.x, p.y, p.z, fl ? v.w : rho0 * p.w);
     }
     __device__ bool begin(const Consts &c, int i, const float4 &pi, Own &o) const {
+        // no early return: the loads below are unconditional, so that they go out together with the rest of the prologue
+        // (k_nbr_pass calls begin() on a clamped index; the result is only used where it returns true)
         o.dyn = 1;
-        if (AF && c.ghosts && META_GHOST(meta[i])) return false;   // all-fluid slab: ghosts are neighbours only
+        bool ok = true;
+        if (AF && c.ghosts) ok = !META_GHOST(meta[i]);   // all-fluid slab: ghosts are neighbours only (uniform branch)
         if (!AF) {
             const int m = meta[i];
-            if (!META_ACTIVE_FLUID(m)) return false;
+            ok = META_ACTIVE_FLUID(m);
+            if (!ok) return false;   // (this instantiation sits at the 128-VGPR limit: it keeps its old shape)
             o.dyn = META_DYN(m);
         }
         const float4 v = velm[i];
@@ -315,7 +325,7 @@ struct WcsphForcePass {
         const float r = rho[i];
         o.rho2 = r * r;
         o.px = o.py = o.pz = 0.0f;
-        return true;
+        return ok;
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, const CT &cj, int j) const {

@@ -84,10 +84,11 @@ struct DfsphDensityAlphaDivPass {
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
     __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
         o.sum = o.s3 = o.gx = o.gy = o.gz = o.dsum = 0.0f; o.cnt = 0;
-        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
+        bool ok = true;   // no early return: begin()'s loads go out with the rest of the prologue (k_nbr_pass)
+        if (!AF || c.ghosts) ok = META_ACTIVE_FLUID(meta[i]);
         const float4 v = velm[i];
         o.vx = v.x; o.vy = v.y; o.vz = v.z;
-        return true;
+        return ok;
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a, const BT &bj, int) const {
         const Geom g = geom(c, r2);
@@ -143,10 +144,11 @@ struct DfsphRhoAdvPass {
         return ldg_idx(posv, j);
     }
     __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
-        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
+        bool ok = true;   // no early return: begin()'s loads go out with the rest of the prologue (k_nbr_pass)
+        if (!AF || c.ghosts) ok = META_ACTIVE_FLUID(meta[i]);
         const float4 v = velm[i];
         o.vx = v.x; o.vy = v.y; o.vz = v.z; o.sum = 0.0f; o.cnt = 0;
-        return true;
+        return ok;
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int) const {
@@ -202,12 +204,13 @@ struct DfsphCorrectPass {
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
     __device__ bool begin(const Consts &c, int i, const float4 &pi, Own &o) const {
-        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
+        bool ok = true;   // no early return: begin()'s loads go out with the rest of the prologue (k_nbr_pass)
+        if (!AF || c.ghosts) ok = META_ACTIVE_FLUID(meta[i]);
         o.k = kappa[i]; o.rho = rho[i];
         if (MODE == 1) { const float4 v = velm[i]; o.vx = v.x; o.vy = v.y; o.vz = v.z; }
         else { o.vx = o.vy = o.vz = 0.0f; }
         o.m0 = pi.w * rho0;
-        return true;
+        return ok;
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int j) const {
@@ -273,10 +276,11 @@ struct PcisphRhoStarPass {
         return p;
     }
     __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
-        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
+        bool ok = true;   // no early return: begin()'s loads go out with the rest of the prologue (k_nbr_pass)
+        if (!AF || c.ghosts) ok = META_ACTIVE_FLUID(meta[i]);
         const float4 q = ppos[i];
         o.px = q.x; o.py = q.y; o.pz = q.z; o.sum = 0.0f;
-        return true;
+        return ok;
     }
     __device__ void pair(const Consts &c, Own &o, float, float, float, float, const float4 &a, const BT &bj, int) const {
         const float dx = o.px - bj.x, dy = o.py - bj.y, dz = o.pz - bj.z;
@@ -322,10 +326,11 @@ struct PcisphPressureAccelPass {
     __device__ BT loadB(int j) const { BT b; stage_impl(j, b); return b; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const { return stage_impl(j, bj); }
     __device__ bool begin(const Consts &c, int i, const float4 &, Own &o) const {
-        if ((!AF || c.ghosts) && !META_ACTIVE_FLUID(meta[i])) return false;
+        bool ok = true;   // no early return: begin()'s loads go out with the rest of the prologue (k_nbr_pass)
+        if (!AF || c.ghosts) ok = META_ACTIVE_FLUID(meta[i]);
         o.pt = ptm[i];
         o.ax = o.ay = o.az = 0.0f;
-        return true;
+        return ok;
     }
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int) const {
