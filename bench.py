@@ -541,6 +541,7 @@ def run_rank(args, rank, world, local_rank):
             "launches": int(launches), "avg_launch_us": 1e6 * avg_s,
             "alg_bytes_per_launch": ALG_BYTES[dom] * n_fluid,
             "step_achieved": step_bytes / (elapsed / args.steps) / 1e9, "step_alg_bytes": step_bytes,
+            "step_frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,   # whole step: does not depend on which kernel is "dominant"
             "measured_copy_gbs": copy_gbs,
             "frac_of_measured_copy": (achieved / copy_gbs) if (achieved and copy_gbs) else None,
             "step_frac_of_measured_copy": (step_bytes / (elapsed / args.steps) / 1e9 / copy_gbs) if copy_gbs else None,
@@ -551,7 +552,8 @@ def run_rank(args, rank, world, local_rank):
                                 "frac": ALG_BYTES[k] * n_fluid / (v[1] / v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                             for k, v in table.items() if k in ALG_BYTES},
             "note": "the neighbour passes are not HBM-bound: per the PMC passes they run at ~2.4 GHz with about half of the VALU issue "
-                    "slots used and 40-50 % of the wave-cycles parked on waits (latency of staging + dependent LDS gathers); "
+                    "slots used and 40-50 % of the wave-cycles parked (4-5 resident waves per SIMD, about half of them runnable: occupancy, "
+                    "not serialised loads -- halving a workgroup's memory round trips moved them 2 %, profiles/r03w_ab_round_trips.txt); "
                     "`secondary` (from profiles/, not this run) carries those figures; DESIGN.md 5",
         },
     }

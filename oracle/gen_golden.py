@@ -193,6 +193,9 @@ BIG_SCENES = {
                                             velocity=(0.1, -0.5, 0.0)), 0.002, 74, [1, 2, 4, 6]),
     "pcisph_4k_compressed": (dam_break_scene(method="pcisph", end=(0.256, 0.256, 0.256), particleSpacing=0.0165, dt=4e-4,
                                              velocity=(0.1, -0.5, 0.0)), 0.0015, 75, [1, 2, 4, 6]),
+    # the path of configs[4] (DFSPH + implicit viscosity: matrix-free CG, base_solver.py:509) at the same 16^3 size, CG history kept
+    "visc_4k": (dam_break_scene(method="dfsph", end=(0.31, 0.31, 0.31), dt=6e-4, viscosity=50.0, viscosity_method="implicit",
+                                velocity=(0.1, -0.5, 0.0)), 0.003, 76, [1, 2, 5, 10]),
 }
 LEAN_KEYS = ("ids", "positions", "velocities", "densities", "pressures", "materials", "iter_v", "iter_d", "iter_pci", "iter_cg")
 ITER_PATTERNS = (("iter_v", r"DFSPH - iteration V: (\d+)"), ("iter_d", r"DFSPH - iterations: (\d+)"),
