@@ -787,6 +787,9 @@ k_compact_blocks(const int *__restrict__ flag, int nb, int *__restrict__ list, i
 // walks spill 10 VGPRs, with 2 nothing spills in either the all-fluid or the rigid-aware instantiations).  Measured at C3 / PCISPH
 // (profiles/r03n_ab_medium_occupancy.txt): 24-byte subset -2 %, 28 bytes with spills -3.5 %, 28 bytes / batches of 2 (this) -3 % from
 // rest and -6 % in motion, no spills.  0 bytes = off.
+#ifndef SPH_NBR_HEAVY_BUDGET
+#define SPH_NBR_HEAVY_BUDGET 40960   // LDS bytes per workgroup of the functors that are neither light nor medium (A/B: 32768 with SPH_NBR_WAVES_HEAVY=5)
+#endif
 #ifndef SPH_NBR_MEDIUM_BYTES
 #define SPH_NBR_MEDIUM_BYTES 28
 #endif
@@ -807,7 +810,7 @@ template <class P> constexpr bool pass_is_medium() {   // by record size, or opt
 }
 template <class P> constexpr int nbr_tile_cap() {
     const int per_slot = pass_slot_bytes<P>();
-    const int budget = pass_is_medium<P>() ? 32768 : 40960;   // a fifth / a quarter of the CU's 160 KB
+    const int budget = pass_is_medium<P>() ? 32768 : SPH_NBR_HEAVY_BUDGET;   // a fifth / a quarter of the CU's 160 KB
     const int slots = (budget - 9 * NBR_CS_PITCH * 2 - 1536) / per_slot - NBR_PAD;   // 1.5 KB for the small arrays and the allocation granule
     return slots > 1280 ? 1280 : slots / 8 * 8;
 }

@@ -113,7 +113,10 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     if (!(MODES & (1 << mask_mode))) mask_mode = 0;   // every functor has mode 0
     const int gy = (PassSplit<P>::value && s.split_next_pass) ? 3 : 1;   // one workgroup per (tile, x-offset group)
     s.split_next_pass = 0;
-#define SPH_LAUNCH_NBR(M) hipLaunchKernelGGL((k_nbr_pass<P, M>), dim3(nb, gy), dim3(P::BLOCK), 0, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc)
+    // debug ("time against resident workgroups"): SPH_DEBUG_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup lower the
+    // number of workgroups a CU can hold without touching the code
+    static const int extra_lds = getenv("SPH_DEBUG_EXTRA_LDS") ? atoi(getenv("SPH_DEBUG_EXTRA_LDS")) : 0;
+#define SPH_LAUNCH_NBR(M) hipLaunchKernelGGL((k_nbr_pass<P, M>), dim3(nb, gy), dim3(P::BLOCK), extra_lds, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc)
     if (mask_mode == 1) {
         if constexpr ((MODES & 0b010) != 0) { SPH_LAUNCH_NBR(1); s.masks_valid = 1; }
     } else if (mask_mode == 2) {
