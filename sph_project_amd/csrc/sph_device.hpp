@@ -1137,7 +1137,11 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             // the merged loop handles runs of <= 64 candidates out of the tile (one or two mask words per run); anything
             // else (tile overflow, a pile-up of > 64 particles in three cells, forced debug modes) walks its runs one by
             // one, wave-uniformly
+#ifdef SPH_EXPERIMENT_NO_ORDERED_PATH
+            if (false) {
+#else
             if (overflow || c.force_global == 1 || c.force_global == 4 || __any(longrun)) {
+#endif
 #pragma unroll 1
                 for (int q = 0; q < RPG; ++q) {
                     const int k = g * RPG + q;
