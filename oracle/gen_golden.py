@@ -193,6 +193,11 @@ BIG_SCENES = {
                                             velocity=(0.1, -0.5, 0.0)), 0.002, 74, [1, 2, 4, 6]),
     "pcisph_4k_compressed": (dam_break_scene(method="pcisph", end=(0.256, 0.256, 0.256), particleSpacing=0.0165, dt=4e-4,
                                              velocity=(0.1, -0.5, 0.0)), 0.0015, 75, [1, 2, 4, 6]),
+    # boundary particles at size: the 16^3 block inside a sampled domain box, falling onto its floor (the rigid-aware instantiations of
+    # every pass: fluid-rigid density / viscosity / pressure terms, base_solver.py:136-178, :232-262)
+    "wcsph_box_4k": (dam_break_scene(domain_end=(0.5, 0.5, 0.5), start=(0.06, 0.045, 0.06), end=(0.37, 0.355, 0.37),
+                                     translation=(0.0, 0.0, 0.0), add_domain_box=True, viscosity_b=0.3, velocity=(0.1, -1.0, 0.05)),
+                     0.003, 77, [1, 5, 10, 20]),
     # the path of configs[4] (DFSPH + implicit viscosity: matrix-free CG, base_solver.py:509) at the same 16^3 size, CG history kept
     "visc_4k": (dam_break_scene(method="dfsph", end=(0.31, 0.31, 0.31), dt=6e-4, viscosity=50.0, viscosity_method="implicit",
                                 velocity=(0.1, -0.5, 0.0)), 0.003, 76, [1, 2, 5, 10]),
