@@ -5,7 +5,9 @@ reference's own, unmodified source files run under oracle/taichi_shim (a serial 
   * c1_wcsph_jitter     : the same block perturbed and moving, 20 steps;
   * dfsph_4k, pcisph_4k : 16^3 = 4,096 particles, 10 steps, the solvers' own stop tests, iteration history of every step;
   * *_4k_compressed     : the same block packed tighter than the rest spacing, so that the solver loops iterate;
-  * visc_4k             : the 16^3 block under DFSPH + implicit viscosity (the path of configs[4]), CG iteration history of every step.
+  * visc_4k             : the 16^3 block under DFSPH + implicit viscosity (the path of configs[4]), CG iteration history of every step;
+  * wcsph_box_4k        : the 16^3 block falling onto the floor of a sampled domain box (3,429 boundary particles, 20 steps): the rigid-aware
+                          instantiations of every pass at size.  (An impact: densities follow the drifted positions, measured drho ~1e-5.)
 
 Checked here: the CPU oracle (every run of the CPU suite) and the HIP path, strict and fast build (GPU suite), with the SURVEY 8(c)
 metric -- per-particle position drift relative to max(|x|, dh), matched by particle id -- at EVERY checkpoint, the velocities, and the
@@ -72,15 +74,8 @@ def _check(z, pre, ids, x, v, rho, prs, dh, tag):
 def test_oracle_matches_reference_source_at_config0_size(path):
     """CPU: oracle/sph_ref.c against the big fixtures -- the pin of the checker itself at the size SURVEY 8(c) asked for."""
     z, cfg = _load(path)
-    c = SimConfig(config=cfg)
-    geo, sol = scene.derive_geometry(c), scene.derive_solver_constants(c)
-    n = z["init_positions"].shape[0]
-    sim = oracle_ref.RefSim(scene.params_dict(geo, sol, c.get_cfg("simulationMethod"), int(z["geo_particle_max_num"])))
-    color = np.zeros((n, 3), np.int32)
-    color[:, 0] = np.arange(n)
-    sim.set_object(0, 1, 0)
-    sim.add_particles(0, z["init_positions"], z["init_velocities"], z["init_densities"], np.zeros(n, np.float32), z["init_materials"],
-                      z["init_is_dynamic"], color)
+    from tests.test_oracle_golden import _oracle_from_fixture   # objects in insertion order (fluid blocks, then the sampled domain box)
+    sim, geo = _oracle_from_fixture(z, cfg)
     sim.prepare()
     np.testing.assert_array_equal(H.oracle_ids(sim), z["prep_ids"])            # the sort is exact
     np.testing.assert_array_equal(sim.field("particle_positions"), z["prep_positions"])
