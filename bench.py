@@ -551,6 +551,11 @@ def run_rank(args, rank, world, local_rank):
             "all_kernels": {k: {"avg_us": 1e3 * v[1] / v[0], "alg_bytes_per_launch": ALG_BYTES[k] * n_fluid,
                                 "frac": ALG_BYTES[k] * n_fluid / (v[1] / v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                             for k, v in table.items() if k in ALG_BYTES},
+            "runner_up": (lambda ru: None if ru is None else {"kernel": ru, "avg_launch_us": 1e3 * table[ru][1] / table[ru][0],
+                                                               "frac": ALG_BYTES[ru] * n_fluid / (table[ru][1] / table[ru][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                               "note": "second kernel by time; when it is within a few per cent of `kernel`, which of the two "
+                                                                       "is 'dominant' -- and with it `frac` (their algorithmic bytes differ 4x) -- can flip between runs"})(
+                max((k for k in table if k in ALG_BYTES and k != dom), key=lambda k: table[k][1], default=None)),
             "note": "the neighbour passes are not HBM-bound: per the PMC passes they run at ~2.4 GHz with about half of the VALU issue "
                     "slots used and 40-50 % of the wave-cycles parked (4-5 resident waves per SIMD, about half of them runnable: occupancy, "
                     "not serialised loads -- halving a workgroup's memory round trips moved them 2 %, profiles/r03w_ab_round_trips.txt); "
