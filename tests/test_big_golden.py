@@ -8,6 +8,9 @@ reference's own, unmodified source files run under oracle/taichi_shim (a serial 
   * visc_4k             : the 16^3 block under DFSPH + implicit viscosity (the path of configs[4]), CG iteration history of every step;
   * wcsph_box_4k        : the 16^3 block falling onto the floor of a sampled domain box (3,429 boundary particles, 20 steps): the rigid-aware
                           instantiations of every pass at size.  (An impact: densities follow the drifted positions, measured drho ~1e-5.)
+  * dfsph_box_4k        : the same impact under DFSPH, the first TWO steps (6 + 4 divergence and 19 + 8 density iterations with the rigid terms
+                          of alpha and of D rho / Dt).  Not more: from the third step on a hard DFSPH impact is chaotic -- the C oracle and
+                          the interpreter agree in every iteration count of ten steps and are 2e-5 apart after 5, 1e-2 after 10.
 
 Checked here: the CPU oracle (every run of the CPU suite) and the HIP path, strict and fast build (GPU suite), with the SURVEY 8(c)
 metric -- per-particle position drift relative to max(|x|, dh), matched by particle id -- at EVERY checkpoint, the velocities, and the
