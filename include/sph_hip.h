@@ -59,7 +59,7 @@ typedef struct {
     int32_t fixed_iterations;/* 0: reference stopping rules; >0: exactly this many DFSPH/PCISPH/CG iterations */
     int32_t fast_math;       /* 0: IEEE div/sqrt, no FMA contraction; 1: v_rcp/v_rsq + FMA */
     int32_t device;          /* HIP device ordinal, -1: current */
-    int32_t force_global;    /* debug: bypass the LDS cell-tile path (neighbour loops read L2 directly) */
+    int32_t force_global;    /* debug mode of the neighbour passes: 0 normal; 1 every candidate run through the tile in chunks; 4 every group down the ordered walk; ... */
     int32_t deterministic;   /* 1: stable within-cell order (bit-reproducible sums) */
 } SphParams;
 

@@ -525,7 +525,8 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
                                             const typename PassC<P>::type *sC, int cap,
                                             unsigned &npairs, unsigned stored, unsigned stored_hi, unsigned *store_to,
                                             unsigned *store_hi) {
-    if (LDS) {
+    static_assert(LDS, "candidates come from the tile (the L2 walk of rounds 1-2 is gone: process_chunk)");
+    {
         int it = 0;
         for (int j0 = js; __any(j0 < je); j0 += 32, ++it) {  // wave-uniform trip count
             int m = je - j0;
@@ -560,35 +561,46 @@ __device__ __forceinline__ void process_run(const Consts &c, const P &p, typenam
                 pass_pair(p, c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, cj, j0 + t);
             }
         }
-    } else {
-        if (MASKMODE == 1 && js >= je) *store_to = 0u;
-        for (int j0 = js; j0 < je; j0 += 32) {
-            const int m = (je - j0) < 32 ? (je - j0) : 32;
-            unsigned mask = 0;
-            constexpr int UNR = MASKMODE == 2 ? 1 : 4;
-#pragma unroll UNR
-            for (int t = 0; t < m; ++t) {
-                const int j = j0 + t;
-                const float4 a = p.loadA(j);
-                const float dx = xi - a.x, dy = yi - a.y, dz = zi - a.z;
-                const float r2 = dx * dx + dy * dy + dz * dz;
-                const unsigned ok = (r2 < c.h2 && j != i) ? 1u : 0u;
-                mask |= ok << t;
-            }
-            if (MASKMODE == 1 && j0 == js) *store_to = mask;
-            if (MASKMODE == 1 && j0 == js + 32) *store_hi = mask;
-            npairs += __popc(mask);
-            while (mask) {
-                const int t = __ffs(mask) - 1;
-                mask &= mask - 1;
-                const int j = j0 + t;
-                typename P::BT bj = typename P::BT();
-                typename PassC<P>::type cj = typename PassC<P>::type();
-                const float4 a = pass_stage(p, c, j, bj, cj);
-                const float dx = xi - a.x, dy = yi - a.y, dz = zi - a.z;
-                const float r2 = dx * dx + dy * dy + dz * dz;
-                pass_pair(p, c, own, dx, dy, dz, r2, a, bj, cj, j);
-            }
+    }
+}
+
+// Tile overflow (one run longer than the tile; every run in debug mode 1): the run goes through the tile in chunks of CAP slots and every
+// lane walks the part of its candidates [js, je) that lies in the chunk [cs, ce) (sorted indices), in 32-candidate blocks aligned to js --
+// so the two stored mask words keep their meaning -- and ascending throughout: the reference's order.  Masks are always recomputed here (a
+// stored word may come from a pass with a larger tile, which did not overflow); the pass that stores them collects its two words over the
+// chunks in w01.  (Until round 3 such a run was walked out of L2, candidate by candidate; that variant cost every instantiation of
+// k_nbr_pass 10-20 VGPRs it almost never used: the density pass needs 96 with it, 80 without -- a sixth workgroup per CU.)
+template <int ZW_OFF, int MASKMODE, class P>
+__device__ __forceinline__ void process_chunk(const Consts &c, const P &p, typename P::Own &own, int i, float xi, float yi, float zi,
+                                              int js, int je, int cs, int ce, const float2 *sXY, const float2 *sZW,
+                                              const typename P::BT *sB, const typename PassC<P>::type *sC, unsigned &npairs,
+                                              unsigned long long &w01) {
+    const int lo = js > cs ? js : cs, hi = je < ce ? je : ce;   // this lane's candidates inside the chunk: [lo, hi)
+    int k = lo > js ? (lo - js) >> 5 : 0;
+    for (; __any(lo < hi && js + 32 * k < hi); ++k) {           // wave-uniform trip count; a lane that is done passes m = 0
+        const int b0r = js + 32 * k;                            // block k of this lane's run
+        const int b0 = b0r > lo ? b0r : lo;
+        const int b1 = b0r + 32 < hi ? b0r + 32 : hi;
+        int m = lo < hi ? b1 - b0 : 0;
+        m = m < 0 ? 0 : m;
+        const int base = m > 0 ? b0 - cs : 0;                   // tile slot of candidate b0
+        unsigned nm = phase1_mask<ZW_OFF, true>(sXY, base, m, xi, yi, zi, c.h2);   // bit t = candidate b0 + t (the lean form: few registers, no reads past the chunk)
+        const unsigned self = (unsigned)(i - b0);
+        if (self < 32u) nm &= ~(1u << self);                    // p_i != p_j (base_container.py:559)
+        if (MASKMODE == 1 && m > 0 && k < 2) w01 |= (unsigned long long)nm << (unsigned)(b0 - js);   // bit t of the two words = candidate js + t
+        npairs += __popc(nm);
+        while (nm) {
+            const int t = __ffs(nm) - 1;
+            nm &= nm - 1;
+            const float2 xy = sXY[base + t];
+            const float2 zw = sZW[base + t];
+            const float dx = xi - xy.x, dy = yi - xy.y, dz = zi - zw.x;
+            const float r2 = dx * dx + dy * dy + dz * dz;
+            typename P::BT bj = typename P::BT();
+            if (P::HAS_B) bj = sB[base + t];
+            typename PassC<P>::type cj = typename PassC<P>::type();
+            if (PassC<P>::value) cj = sC[base + t];
+            pass_pair(p, c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, cj, b0 + t);
         }
     }
 }
@@ -866,7 +878,7 @@ template <class P, int MASKMODE> constexpr int nbr_lds_bytes() {
 // 141 -> 127 us (profiles/r02_ab_*.txt).  The functors with payload arrays are capped at 4 by their 33-38 KB tiles; the
 // strict build and the 5-float DFSPH density+alpha accumulator spill at 96 and stay at 4 (tools/check_spills.py gates).
 #ifndef SPH_NBR_WAVES_LIGHT
-#define SPH_NBR_WAVES_LIGHT (SPH_FAST ? 5 : 4)
+#define SPH_NBR_WAVES_LIGHT (SPH_FAST ? 6 : 4)
 #endif
 #ifndef SPH_NBR_WAVES_HEAVY
 #define SPH_NBR_WAVES_HEAVY (SPH_FAST ? 4 : 3)   // strict build (IEEE division / sqrt sequences): 3, i.e. <= 168 VGPRs, rather than spills
@@ -985,17 +997,27 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             for (int k = 0; k < 9; ++k) s_cs[k][tid] = (unsigned short)(cs_[k] - hdr[2 + k]);
         }
     }
-    const int cx = cell_coord(pi.x, c.grid_size, c.nx);
-    const int cy = cell_coord(pi.y, c.grid_size, c.ny);
-    const int cz = cell_coord_z(c, pi.z);
-    const int lin = (cx * c.ny + cy) * c.nz + cz;
-    if (__syncthreads_or(active ? 1 : 0)) {  // workgroup-uniform; also publishes s_cs
-        NBR_STAMP(1);
-        // this lane's z window
+    // What the group loop keeps of this lane's cell: two window-cache entries and nine "column exists" bits (three registers instead of
+    // cx, cy, z0, z1 - z0; the rare path that reads the windows from global memory recomputes the cell from the position).
+    int e0, e1;
+    unsigned dom = 0u;
+    {
+        const int cx = cell_coord(pi.x, c.grid_size, c.nx);
+        const int cy = cell_coord(pi.y, c.grid_size, c.ny);
+        const int cz = cell_coord_z(c, pi.z);
+        const int lin = (cx * c.ny + cy) * c.nz + cz;
         const int z0 = cz > 0 ? cz - 1 : 0;
         const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
-        const int e0 = (lin - cfirst) + (z0 - cz) + 1;   // s_cs entry of (.., .., z0) in every run
-        const int e1 = e0 + (z1 - z0) + 1;
+        e0 = (lin - cfirst) + (z0 - cz) + 1;   // s_cs entry of (.., .., z0) in every run
+        e1 = e0 + (z1 - z0) + 1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int xx = cx + k / 3 - 1, yy = cy + k % 3 - 1;
+            if (xx >= 0 && xx < c.nx && yy >= 0 && yy < c.ny) dom |= 1u << k;
+        }
+    }
+    if (__syncthreads_or(active ? 1 : 0)) {  // workgroup-uniform; also publishes s_cs
+        NBR_STAMP(1);
         unsigned npairs = 0;
         const int gsplit = (PassSplit<P>::value && gridDim.y == GROUPS) ? (int)blockIdx.y : -1;   // uniform: one group only
         bool prestaged = false;   // the first round's records are already on their way (above)
@@ -1018,7 +1040,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             // One group = the three runs of an x offset.  Its runs are staged in ROUNDS (uniform plan): a round takes the longest
             // prefix of the runs not yet done that fits the tile, laid out back to back -- normally all three in one round; where
             // the fluid has piled up, two rounds (e.g. {0, 1} then {2}) instead of sending the group down the slow ordered walk.
-            // A run that does not fit the tile on its own is a round of its own and is walked out of L2.  Runs are consumed in
+            // A run that does not fit the tile on its own is a round of its own and goes through the tile in chunks.  Runs are consumed in
             // order, so the accumulation order stays the reference's.
             int rs_[RPG], ln_[RPG], lo_[RPG];
             int total, qb;
@@ -1074,8 +1096,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
 #pragma unroll
             for (int q = 0; q < RPG; ++q) {
                 const int k = g * RPG + q;
-                const int xx = cx + g - 1, yy = cy + q - 1;
-                inr[q] = NBR_IN_ROUND(q) && active && xx >= 0 && xx < c.nx && yy >= 0 && yy < c.ny;
+                inr[q] = NBR_IN_ROUND(q) && active && ((dom >> k) & 1u);
                 js_[q] = 0; m_[q] = 0;
                 if (inr[q]) {
                     if (cs_lds) {
@@ -1084,7 +1105,13 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                         const int o0 = lds_ld_u16(&s_cs[k][e0]);
                         js_[q] = rs_[q] + o0;
                         m_[q] = lds_ld_u16(&s_cs[k][e1]) - o0;
-                    } else {
+                    } else {   // (a workgroup spanning more cells than the window cache holds: sparse spray)
+                        float px = pi.x, py = pi.y, pz = pi.z;
+                        asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));   // keeps the recomputation IN this branch (it is loop-invariant: hoisted, it would hold four registers for every workgroup)
+                        const int xx = cell_coord(px, c.grid_size, c.nx) + g - 1, yy = cell_coord(py, c.grid_size, c.ny) + q - 1;
+                        const int cz = cell_coord_z(c, pz);
+                        const int z0 = cz > 0 ? cz - 1 : 0;
+                        const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
                         const int lin0 = (xx * c.ny + yy) * c.nz + z0;
                         js_[q] = cell_start[lin0];
                         m_[q] = cell_start[lin0 + (z1 - z0) + 1] - js_[q];
@@ -1137,11 +1164,36 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             // the merged loop handles runs of <= 64 candidates out of the tile (one or two mask words per run); anything
             // else (tile overflow, a pile-up of > 64 particles in three cells, forced debug modes) walks its runs one by
             // one, wave-uniformly
-#ifdef SPH_EXPERIMENT_NO_ORDERED_PATH
-            if (false) {
-#else
-            if (overflow || c.force_global == 1 || c.force_global == 4 || __any(longrun)) {
-#endif
+            if (overflow) {
+                // (workgroup-uniform) this round is ONE run, and it does not fit the tile: through the tile in chunks (process_chunk)
+                const int k = g * RPG + qa;
+                const int rsq = qa == 0 ? rs_[0] : (qa == 1 ? rs_[1] : rs_[2]);
+                const int lnq = qa == 0 ? ln_[0] : (qa == 1 ? ln_[1] : ln_[2]);
+                const bool in = qa == 0 ? inr[0] : (qa == 1 ? inr[1] : inr[2]);
+                const int js = in ? (qa == 0 ? js_[0] : (qa == 1 ? js_[1] : js_[2])) : 0;
+                const int m = in ? (qa == 0 ? m_[0] : (qa == 1 ? m_[1] : m_[2])) : 0;
+                unsigned long long w01 = 0ull;
+#pragma unroll 1
+                for (int cs0 = 0; cs0 < lnq; cs0 += CAP) {
+                    const int cl = lnq - cs0 < CAP ? lnq - cs0 : CAP;
+                    for (int t = tid; t < cl; t += BLOCK) {
+                        BT bj; CT cj;
+                        const float4 a = pass_stage(p, c, rsq + cs0 + t, bj, cj);
+                        sXY[t] = make_float2(a.x, a.y);
+                        sZW[t] = make_float2(a.z, a.w);
+                        if (P::HAS_B) sB[t] = bj;
+                        if (PassC<P>::value) sC[t] = cj;
+                    }
+                    __syncthreads();
+                    process_chunk<ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, rsq + cs0, rsq + cs0 + cl, sXY, sZW, sB, sC, npairs, w01);
+                    __syncthreads();
+                }
+                if (MASKMODE == 1 && in) {
+                    nbr_mask[(size_t)k * mask_stride + i] = (unsigned)w01;
+                    if (m > 32) nbr_mask_hi[(size_t)k * mask_stride + i] = (unsigned)(w01 >> 32);
+                }
+            } else if (c.force_global == 4 || __any(longrun)) {
+                // a pile-up of more than 64 candidates in three cells (or debug mode 4): the runs one by one, out of the tile, wave-uniformly
 #pragma unroll 1
                 for (int q = 0; q < RPG; ++q) {
                     const int k = g * RPG + q;
@@ -1154,13 +1206,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     unsigned *mslot_hi = nbr_mask_hi + (size_t)k * mask_stride + i;
                     unsigned stored = 0, stored_hi = 0;
                     if (MASKMODE == 2) { stored = q == 0 ? mk[0] : (q == 1 ? mk[1] : mk[2]); stored_hi = q == 0 ? mh[0] : (q == 1 ? mh[1] : mh[2]); }
-                    // loff is workgroup-uniform, so every lane of the wave takes the same branch (process_run uses __any)
-                    if (loff != INT_MIN) process_run<true, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, loff, sXY, sZW, sB, sC, CAP, npairs, stored, stored_hi, mslot, mslot_hi);
-                    else {
-                        // tile overflow: candidates straight from L2; stored masks are recomputed there, and when this pass
-                        // is the one that stores masks the slots get the same bits the LDS path would have produced
-                        process_run<false, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, 0, sXY, sZW, sB, sC, CAP, npairs, stored, stored_hi, mslot, mslot_hi);
-                    }
+                    process_run<true, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, loff, sXY, sZW, sB, sC, CAP, npairs, stored, stored_hi, mslot, mslot_hi);
                 }
             } else {
                 // acceptance masks of the three runs, then one merged loop

@@ -128,7 +128,7 @@ def test_lds_tile_equals_global_path(gpu):
                                            (0.0140, "runs of ~70 candidates: beyond two mask words, ordered path")])
 def test_all_neighbour_paths_agree(gpu, spacing, label):
     """The merged loop (one or two mask words per run, lane permutation), the ordered LDS path (mode 4) and the
-    direct-from-L2 path (mode 1) visit the same pairs in the same order: bitwise identical states and pair counts,
+    chunk path of oversized runs (mode 1: every run) visit the same pairs in the same order: bitwise identical states and pair counts,
     whatever the number of candidates per run.  Against the oracle: pair counts identical, drift within tolerance."""
     cfg = H.dam_break_scene(end=(0.2, 0.2, 0.2), particleSpacing=spacing, dt=1e-4)
     out = []
@@ -153,12 +153,33 @@ def test_all_neighbour_paths_agree(gpu, spacing, label):
     assert d.max() <= 1e-5
 
 
+@pytest.mark.parametrize("method,spacing", [("dfsph", 0.0060), ("dfsph", 0.0064), ("pcisph", 0.0060), ("wcsph", 0.0060)])
+def test_oversized_runs_through_the_tile_in_chunks(gpu, method, spacing):
+    """A run longer than a functor's tile goes through the tile in chunks (process_chunk), and tiles differ between functors (1280 slots
+    for the payload-free passes, ~1064 for the 32-36-byte records, in between for the solver walks): the pass that STORES the
+    acceptance masks may take the chunk path for a run that a later pass reads out of its larger tile with those stored masks, and
+    the other way round.  ~300 particles per cell puts the run lengths right across those capacities.  One step (the block is far
+    too dense to be stepped further), default paths against debug mode 1 (every run through the chunk path, every mask recomputed):
+    bitwise the same state and the same number of pairs."""
+    cfg = H.dam_break_scene(method=method, end=(0.118, 0.118, 0.118), particleSpacing=spacing, dt=1e-5)
+    out = []
+    for fg in (0, 1):
+        container, solver = H.build_product(cfg, jitter=0.3 * spacing, seed=5, force_global=fg, fixed_iterations=2)
+        solver.prepare()
+        solver.step()
+        out.append((_state(container), solver.stats()))
+    assert out[0][1]["lds_fallback_blocks"] > 0    # some runs did overflow a tile in the default build
+    for k in ("x", "v", "rho"):
+        np.testing.assert_array_equal(out[0][0][k], out[1][0][k])
+    assert out[0][1]["pair_interactions"] == out[1][1]["pair_interactions"]
+
+
 @pytest.mark.parametrize("spacing,label", [(0.0080, "125 particles per cell: a group's three runs exceed the tile -> staged in rounds"),
-                                           (0.0058, "~330 per cell: single runs exceed the tile -> walked out of L2, 32 candidates at a time")])
+                                           (0.0058, "~330 per cell: single runs exceed the tile -> through the tile in chunks")])
 def test_piled_up_cells_density(gpu, spacing, label):
     """Extreme pile-ups (the domain clamp of the reference parks particles in the boundary cells): the density pass alone -- a
-    full step would blow such a block apart -- through every path: default (rounds / L2 walk as the tile allows), ordered LDS
-    walk (mode 4), everything from L2 (mode 1); bitwise the same densities and pair counts, and the oracle's."""
+    full step would blow such a block apart -- through every path: default (rounds / chunks as the tile allows), ordered LDS
+    walk (mode 4), every run in chunks (mode 1); bitwise the same densities and pair counts, and the oracle's."""
     cfg = H.dam_break_scene(end=(0.118, 0.118, 0.118), particleSpacing=spacing)
     out = []
     for fg in (0, 4, 1):
