@@ -516,8 +516,9 @@ __device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int
     return nm;
 }
 
-// Ordered path: lane i walks run [js, je) itself, 32 candidates at a time.  Used for the groups the balanced
-// path below does not take (tile overflow, runs longer than 32 candidates, sparse cell windows).
+// Ordered walk out of the tile: lane i walks run [js, je) itself, 32 candidates at a time.  Used for the groups the merged loop
+// below does not take (a run of more than 64 candidates somewhere in the wave; debug mode 4).  A run that does not fit the tile
+// takes process_chunk instead.
 template <bool LDS, int ZW_OFF, int MASKMODE, class P>
 __device__ __forceinline__ void process_run(const Consts &c, const P &p, typename P::Own &own, int i, float xi,
                                             float yi, float zi, int js, int je, int loff, const float2 *sXY,

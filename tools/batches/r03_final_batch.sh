@@ -1,7 +1,8 @@
-# round 3, final: build check, smoke, full GPU suite, the driver's default bench line
+# round 3, final: smoke, full GPU suite, kernel trace + PMC passes, the driver's default bench line
 O=gpurun_out/r03final; mkdir -p $O
 timeout -s KILL 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout -s KILL 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/tests.log
+timeout -s KILL 600 bash tools/prof.sh r03final --motion-step 0 > $O/prof.log 2>&1; echo "prof rc=$?"
 timeout -s KILL 600 python bench.py > $O/bench_driver_line.json 2> $O/bench.err; echo "bench rc=$?"
 python - <<'PY'
 import json
