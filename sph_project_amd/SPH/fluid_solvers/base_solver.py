@@ -3,6 +3,8 @@
 :136, surface tension :210, viscosity :232, boundary :575, integration :643-:666) runs inside
 libsph_hip; this class keeps the constants, the prepare()/step() protocol (:683-:696), late object
 insertion and the host rigid-solver hook."""
+import os
+
 import numpy as np
 
 from sph_project_amd import _lib as F
@@ -87,7 +89,10 @@ class BaseSolver:
         the steps are only enqueued -- like a Taichi kernel launch, observable behaviour stays synchronous because every
         read of a field / of stats() drains the stream first.  Solver loops with their own stop tests read a flag back per
         batch of iterations anyway."""
-        if self.container.METHOD == "wcsph" or self.container.params_dict.get("fixed_iterations", 0) > 0:
+        asynchronous = self.container.METHOD == "wcsph" or self.container.params_dict.get("fixed_iterations", 0) > 0
+        if asynchronous and os.environ.get("SPH_SYNC_STEPS", "0") not in ("", "0"):
+            asynchronous = False   # opt-out: every step() returns only when the device is done, errors surface in the call that caused them
+        if asynchronous:
             self.engine.step_async(n)
         else:
             self.engine.step(n)

@@ -485,10 +485,11 @@ static int push_setup(SphHandle *h) {
     char busid[32] = "";
     if (hipDeviceGetPCIBusId(busid, sizeof(busid), h->device) != hipSuccess) { (void)hipGetLastError(); snprintf(busid, sizeof(busid), "dev%d-pid%d", h->device, (int)getpid()); }
     if (e != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "inbox allocation of %zu bytes: %s", bytes, hipGetErrorString(e)); (void)hipGetLastError(); }
+    c.inbox_alloc = inbox;   // owned from here on, whatever `ok` says (push_teardown / comm_free release it)
     hipIpcMemHandle_t mine;
     memset(&mine, 0, sizeof(mine));
     if (ok) {
-        c.inbox_alloc = inbox; s.push.inbox = (char *)inbox;
+        s.push.inbox = (char *)inbox;
         e = hipMemset(inbox, 0, 2 * sizeof(HaloCtl));
         if (e == hipSuccess && c.nranks > 1) e = hipIpcGetMemHandle(&mine, inbox);
         if (e != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "hipIpcGetMemHandle: %s", hipGetErrorString(e)); (void)hipGetLastError(); }
@@ -685,8 +686,11 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
         { ProfScope p(h, SPH_K_HALO);
           h->L->halo_classify_pack(s, h->n);
           h->L->halo_unpack2(s, h->n, 0, 0, c.est_recv + c.est_recv / 4 + 4096); }
+        int dev_status = 0;   // every workgroup ORs its verdict into the device word; the mirror carries workgroup 0's only
+        HIPCHK(h, hipMemcpyAsync(&dev_status, &s.dyn_cur->status, sizeof(int), hipMemcpyDeviceToHost, s.stream));
         rc = stream_sync_bounded(h, "halo exchange (step message)"); if (rc) return rc;
-        const SlabDyn m = *(const SlabDyn *)s.push.mirror;
+        SlabDyn m = *(const SlabDyn *)s.push.mirror;
+        m.status |= dev_status;
         if (m.status) return fail(h, SPH_ERR_COMM, "halo exchange failed (status %d): %s", m.status, slab_status_text(m.status));
         for (int side = 0; side < 2; ++side) { c.n_send[side] = m.n_send[side]; c.n_recv[side] = m.n_recv[side]; }
         c.est_recv = m.n_recv[0] + m.n_recv[1];
@@ -706,17 +710,20 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
         HIPCHK(h, hipMemcpyAsync(&s.dyn_cur->n_live, c.n_stage, sizeof(int), hipMemcpyHostToDevice, s.stream));   // (the bank the next message reads as "last step's")
         live_known = h->n; app_known = (long long)h->n + c.est_recv; grid_n = h->n;
         s.push.mirror->seq = s.push.rec_seq; s.push.mirror->n_live = h->n; s.push.mirror->n_app = (int)app_known; s.push.mirror->status = 0;
+        s.push.mirror->wseq = 0;   // (the stream is idle here: slab_settle drained it)
     } else {
         volatile SlabDyn *mv = s.push.mirror;
         struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
         for (unsigned spins = 0;; ++spins) {
-            const unsigned q0 = mv->seq;
+            const unsigned q0 = mv->wseq;   // bumped before AND after the fields are written: odd = being written
+            __sync_synchronize();
             live_known = mv->n_live; app_known = mv->n_app;
             const int st = mv->status;
+            const unsigned sq = mv->seq;
             __sync_synchronize();
-            if (mv->seq != q0) continue;   // torn read: the wait kernel was writing
+            if ((q0 & 1u) || mv->wseq != q0) continue;   // torn read: the settle kernel was writing
             if (st) return slab_settle(h);  // drains the stream and reports
-            lag = (int)(s.push.rec_seq - q0);
+            lag = (int)(s.push.rec_seq - sq);
             if (lag <= SLAB_MAX_LAG) break;
             if ((spins & 1023) == 1023) {
                 struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -750,11 +757,17 @@ static int slab_neighbor_search(SphHandle *h, bool allow_async = false) {
     // its particles take it along when they change owner.  EVERY rank must have been told about the body (sph_set_object):
     // the record size travels in the message header and a mismatch fails on both sides instead of mis-parsing the payload.
     const size_t rec = s.orig.cur() ? 64 : 48;
+    bool cut_moved = false;
     if (c.rebalance_every > 0 && h->prepared && h->steps > 0 && h->steps % c.rebalance_every == 0 && !h->any_rigid_object) {
         int rc = slab_settle(h); if (rc) return rc;
+        const int moves = c.rebalance_moves;
         rc = slab_rebalance(h); if (rc) return rc;
+        cut_moved = c.rebalance_moves != moves;
     }
-    if (s.push.on) return slab_neighbor_search_push(h, allow_async && c.async_enabled != 0);
+    // A cut that moved hands a whole cell layer over in this step's message: ~n / layers particles on top of the usual trickle, more than
+    // the margin of an asynchronous launch bound as soon as a slab has fewer than 16 layers (C4 on 8 ranks: 12).  That one step runs with
+    // exact launches (one read-back); est_recv then holds the layer, and the following asynchronous steps are sized from real counts.
+    if (s.push.on) return slab_neighbor_search_push(h, allow_async && c.async_enabled != 0 && !cut_moved);
     { ProfScope p(h, SPH_K_HALO); h->L->halo_classify_pack(s, h->n); }
     const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
     void *recv[2] = {s.recvbuf[0], s.recvbuf[1]};

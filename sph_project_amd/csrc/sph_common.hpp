@@ -68,6 +68,7 @@ struct SlabDyn {
     int longest;     // longest of the four messages (slot tables are reset up to here)
     int status;      // sticky: SLAB_ST_*
     unsigned seq;    // number of the step message these counts belong to
+    unsigned wseq;   // pinned mirror only: 2 seq + 1 while the settle kernel writes the fields, 2 seq + 2 when they are complete (seqlock)
 };
 struct HaloCtl {            // push transport: header block of one side of a rank's inbox, 256 bytes, written by that neighbour
     unsigned rec_seq;       // number of the last complete step message (stored last, system-scope release)

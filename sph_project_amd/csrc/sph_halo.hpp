@@ -208,8 +208,14 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
             const int n_old = w.n_old >= 0 ? w.n_old : w.dyn_old->n_live;
             if (st) r0 = r1 = 0;                            // after a failure nothing is appended: every later kernel stays inside its arrays
             if ((long long)n_old + r0 + r1 > (long long)w.cap) { st |= SLAB_ST_CAPACITY; r0 = r1 = 0; }
-            const int n_app = n_old + r0 + r1, n_live = n_app - dropped;
-            if (w.bound_app > 0 && (n_app > w.bound_app || n_live > w.bound_live)) st |= SLAB_ST_BOUND;
+            int n_app = n_old + r0 + r1, n_live = n_app - dropped;
+            if (w.bound_app > 0 && (n_app > w.bound_app || n_live > w.bound_live)) {
+                // the grids of this step were launched for fewer particles: appending the arrivals would leave some of them unhashed and
+                // unscattered and the cell lists inconsistent for up to SLAB_MAX_LAG more steps.  Nothing is appended (as for every other
+                // failure); the arrivals of this step are LOST, the state is not recoverable: restart with SPH_SLAB_ASYNC=0.
+                st |= SLAB_ST_BOUND; r0 = r1 = 0;
+                n_app = n_old; n_live = n_app - dropped;
+            }
             int longest = s0 > s1 ? s0 : s1;
             longest = longest > r0 ? longest : r0; longest = longest > r1 ? longest : r1;
             longest = longest > w.halo_cap ? w.halo_cap : longest;
@@ -224,10 +230,14 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
                 w.counts_next[0] = w.counts_next[1] = w.counts_next[2] = 0;   // the next classify starts from zero without a memset
                 if (w.mirror) {
                     volatile SlabDyn *m = w.mirror;
+                    m->wseq = 2u * w.seq + 1u;   // odd: fields in flux (the host's reader retries)
+                    __threadfence_system();
                     m->n_app = n_app; m->n_live = n_live; m->n_send[0] = d->n_send[0]; m->n_send[1] = d->n_send[1];
                     m->n_recv[0] = r0; m->n_recv[1] = r1; m->dropped = dropped; m->longest = longest; m->status = st;
                     __threadfence_system();
-                    m->seq = w.seq;   // written last: a host that reads seq, the counts, then seq again knows they belong together
+                    m->seq = w.seq;
+                    __threadfence_system();
+                    m->wseq = 2u * w.seq + 2u;   // even again: a host that reads wseq, the fields, then the same even wseq has one consistent set
                 }
             }
         }

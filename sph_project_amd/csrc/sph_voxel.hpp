@@ -114,7 +114,11 @@ static int contains_lattice(const double *vert, int nv, const int32_t *faces, in
             std::sort(zc.begin(), zc.end());
             if (zc.size() % 2) zc.pop_back();   // grazing contact: drop the odd one out
             for (int k = 0; k < nz; ++k) {
-                const size_t below = (size_t)(std::upper_bound(zc.begin(), zc.end(), zs[k]) - zc.begin());   // crossings at or below
+                // crossings at or below z, "at" with a tolerance of 1e-9 of the mesh size: a lattice that starts ON a face (np.arange from the
+                // bounds' minimum, base_container.py:686-690: the lower faces of a box-shaped body) meets crossings computed 1 ulp above or
+                // below its own z -- without the tolerance 14 of the 225 points on the lower z face of the reference's cube.obj were dropped.
+                // Together with the positive column shift this makes containment half-open, [lo, hi), on all three axes, like np.arange.
+                const size_t below = (size_t)(std::upper_bound(zc.begin(), zc.end(), zs[k] + size * 1e-9) - zc.begin());
                 inside[((size_t)i * ny + j) * nz + k] = (below % 2) == 1;
             }
         }

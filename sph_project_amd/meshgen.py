@@ -113,7 +113,7 @@ def contains_lattice(mesh, axes):
         zc = np.sort(np.asarray(zc))
         if len(zc) % 2:                                     # grazing contact: drop the closest pair member
             zc = zc[:-1]
-        below = np.searchsorted(zc, zs, side="right")       # crossings at or below every lattice z
+        below = np.searchsorted(zc, zs + size * 1e-9, side="right")   # crossings at or below every lattice z (tolerance: sph_voxel.hpp)
         inside[i, j, :] = (below % 2) == 1
     return inside
 

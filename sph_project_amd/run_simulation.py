@@ -23,13 +23,40 @@ from SPH.containers import DFSPHContainer, WCSPHContainer, PCISPHContainer  # no
 from SPH.fluid_solvers import DFSPHSolver, WCSPHSolver, PCISPHSolver  # noqa: E402
 
 
+PLY_COMMENT = "created by PLYWriter"   # taichi.tools.PLYWriter's default `comment`
+
+
 def write_ply_ascii(path, pos):
-    """ASCII PLY with float x y z per vertex (Taichi PLYWriter.add_vertex_pos + export_ascii)."""
-    pos = np.asarray(pos, dtype=np.float32)
+    """What `PLYWriter(num_vertices=n); add_vertex_pos(x, y, z); export_ascii(path)` leaves on disk (run_simulation.py:139-144).
+    Layout restated from Taichi's python/taichi/tools/ply.py (>= 1.6; the package is absent here, so the layout is NOT compared with
+    a Taichi run): `print_header` writes "ply", "format ascii 1.0", "comment created by PLYWriter", "element vertex N", one
+    "property float x|y|z" line per channel (`add_vertex_pos` registers the three channels as "float" and casts the data to
+    np.float32) and "end_header"; `export_ascii` then appends one line per vertex, every value as `str(np.float32)` -- the shortest
+    digits that round-trip -- FOLLOWED by a blank, i.e. "x y z \n".  `ndarray.astype(str)` produces exactly those strings."""
+    pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
     with open(path, "w") as f:
-        f.write("ply\nformat ascii 1.0\ncomment created by sph_project_amd\n")
+        f.write(f"ply\nformat ascii 1.0\ncomment {PLY_COMMENT}\n")
         f.write(f"element vertex {pos.shape[0]}\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
-        np.savetxt(f, pos, fmt="%.9g")
+        if pos.shape[0]:
+            f.write(" \n".join(map(" ".join, pos.astype(str).tolist())) + " \n")
+
+
+def read_ply_ascii(path):
+    """Vertex positions of an ASCII PLY as (n, 3) float32 (what surface_reconstruction.py / splashsurf read back)."""
+    with open(path) as f:
+        assert f.readline().strip() == "ply"
+        n, props = None, []
+        for line in f:
+            tok = line.split()
+            if tok[:2] == ["element", "vertex"]:
+                n = int(tok[2])
+            elif tok[:1] == ["property"]:
+                props.append(tok[-1])
+            elif tok[:1] == ["end_header"]:
+                break
+        data = np.loadtxt(f, dtype=np.float32, ndmin=2) if n else np.zeros((0, len(props)), np.float32)
+    assert data.shape == (n, len(props)), (data.shape, n, props)
+    return data[:, [props.index(k) for k in ("x", "y", "z")]]
 
 
 def main(argv=None):
@@ -86,11 +113,12 @@ def main(argv=None):
         cnt = nxt
         container.engine.synchronize()
         te = time.perf_counter()
-        frames += 1
+        wrote = False
         if output_ply:
             os.makedirs(f"{out_dir}/{cnt:06}", exist_ok=True)
             for f_body_id in container.object_id_fluid_body:
                 write_ply_ascii(f"{out_dir}/{cnt:06}/particle_object_{f_body_id}.ply", container.dump(obj_id=f_body_id)["position"])
+                wrote = True
         if output_obj:   # run_simulation.py:146-150
             os.makedirs(f"{out_dir}/{cnt:06}", exist_ok=True)
             for r_body_id in container.object_id_rigid_body:
@@ -98,6 +126,8 @@ def main(argv=None):
                     continue
                 with open(f"{out_dir}/{cnt:06}/mesh_object_{r_body_id}.obj", "w") as f:
                     f.write(container.object_collection[r_body_id]["mesh"].export(file_type="obj"))
+                wrote = True
+        frames += 1 if wrote else 0
         t_export += time.perf_counter() - te
         cnt += 1
     container.engine.synchronize()

@@ -98,30 +98,55 @@ def test_late_fluid_block_and_late_static_rigid_body(gpu, method):
     assert rigid.sum() == n_r and len(np.unique(mine["V"][rigid])) > 1
 
 
-def test_dump_matches_object_slices(gpu):
-    """BaseContainer.dump (base_container.py:599): positions / velocities of one object id in the current sorted order."""
+def _two_block_scene():
     cfg = H.dam_break_scene(end=(0.12, 0.12, 0.12))
     cfg["FluidBlocks"].append({"objectId": 3, "start": [0.0, 0.0, 0.0], "end": [0.07, 0.07, 0.07], "translation": [0.3, 0.1, 0.3],
                                "scale": [1, 1, 1], "velocity": [0.1, 0.0, 0.0], "density": 1000.0, "color": [1, 2, 3], "entryTime": -1.0})
+    return cfg
+
+
+def _oracle_dump(ref, oid):
+    """BaseContainer.dump (base_container.py:599-609) on the oracle's state: positions / velocities of the particles whose object
+    id is `oid`, in the current sorted order (the oracle's stable counting sort = serial execution of :510-515)."""
+    sel = ref.field("particle_object_ids") == oid
+    return ref.field("particle_positions")[sel].copy(), ref.field("particle_velocities")[sel].copy(), H.oracle_ids(ref)[sel]
+
+
+def test_dump_matches_the_oracle(gpu):
+    """BaseContainer.dump (base_container.py:599): positions / velocities of one object id in the current sorted order -- against the
+    ORACLE's dump of the same scene after the same steps (same particles in the same order, values to the parity limit), not only
+    against the product's own download."""
+    cfg = _two_block_scene()
     container, solver = H.build_product(cfg)
     solver.prepare()
+    ref = H.build_oracle(cfg)
+    ref.prepare()
     for _ in range(3):
         solver.step()
+    H.oracle_step(ref, 3)
     e = container.engine
-    obj = e.download(L.F_OBJECT_ID)
+    obj, pid = e.download(L.F_OBJECT_ID), e.download(L.F_PARTICLE_ID)
     for oid, n_expect in ((0, 216), (3, 64)):
         d = container.dump(obj_id=oid)
         assert d["position"].shape == (n_expect, 3) and d["velocity"].shape == (n_expect, 3)
-        assert d["position"].dtype == np.float32
+        assert d["position"].dtype == np.float32 and d["velocity"].dtype == np.float32
+        xr, vr, idr = _oracle_dump(ref, oid)
+        np.testing.assert_array_equal(pid[obj == oid], idr)                      # same particles, same (sorted) order
+        assert H.drift(d["position"], xr, container.dh).max() <= 1e-5
+        assert np.abs(d["velocity"] - vr).max() <= 5e-5 * max(float(np.abs(vr).max()), 1e-30)
         np.testing.assert_array_equal(d["position"], e.download(L.F_POSITION)[obj == oid])
         np.testing.assert_array_equal(d["velocity"], e.download(L.F_VELOCITY)[obj == oid])
     assert container.object_id_fluid_body == {0, 3}
 
 
-def test_run_simulation_driver_on_scene_file(gpu, tmp_path):
-    """The drop-in driver on a JSON scene in the reference's format: frame directories and ASCII PLY per fluid object
-    ({scene}_output/{cnt:06}/particle_object_{id}.ply, run_simulation.py:137-144) with the loop arithmetic of :28-39."""
-    cfg = H.dam_break_scene(end=(0.12, 0.12, 0.12))
+def test_run_simulation_driver_writes_the_reference_frames(gpu, tmp_path):
+    """The drop-in driver on a JSON scene in the reference's format: frame directories and one ASCII PLY per fluid object
+    ({scene}_output/{cnt:06}/particle_object_{id}.ply, run_simulation.py:137-144) with the loop arithmetic of :28-39 -- and the
+    NUMBERS in every file: a frame written at count c holds dump(obj_id) after c + 1 steps (the reference steps, then exports, then
+    counts: :126-151); every PLY of every frame is parsed and compared vertex for vertex, in file order, with the oracle's dump at
+    that step.  Header and number format are Taichi's PLYWriter.export_ascii as restated in tests/test_host_cpu.py::test_ply_writer_layout."""
+    from sph_project_amd.run_simulation import read_ply_ascii
+    cfg = _two_block_scene()
     cfg["Configuration"].update(exportPly=True, fps=500, totalTime=0.0064)   # output_interval = int((1/500)/4e-4) = 5, 16 rounds
     scene_file = tmp_path / "tiny_dam.json"
     scene_file.write_text(json.dumps(cfg))
@@ -129,15 +154,33 @@ def test_run_simulation_driver_on_scene_file(gpu, tmp_path):
                        cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Simulation Finished: 16 steps" in r.stdout, r.stdout
+    assert "writing 4 frame(s)" in r.stdout, r.stdout
     out = tmp_path / "tiny_dam_output"
     frames = sorted(os.listdir(out))
     assert frames == ["000000", "000005", "000010", "000015"], frames
-    lines = (out / "000010" / "particle_object_0.ply").read_text().splitlines()
-    assert lines[0] == "ply" and lines[1] == "format ascii 1.0"
-    n = int([l for l in lines if l.startswith("element vertex")][0].split()[-1])
-    assert n == 216
-    body = np.loadtxt(lines[lines.index("end_header") + 1:])
-    assert body.shape == (216, 3) and np.isfinite(body).all()
+    ref = H.build_oracle(cfg)
+    ref.prepare()
+    done = 0
+    for fr in frames:
+        H.oracle_step(ref, int(fr) + 1 - done)
+        done = int(fr) + 1
+        assert sorted(os.listdir(out / fr)) == ["particle_object_0.ply", "particle_object_3.ply"]
+        for oid, n_expect in ((0, 216), (3, 64)):
+            path = out / fr / f"particle_object_{oid}.ply"
+            head = path.read_text().split("end_header\n")[0]
+            assert head == (f"ply\nformat ascii 1.0\ncomment created by PLYWriter\nelement vertex {n_expect}\n"
+                            "property float x\nproperty float y\nproperty float z\n"), head
+            x = read_ply_ascii(str(path))
+            xr, _, _ = _oracle_dump(ref, oid)
+            assert x.shape == xr.shape == (n_expect, 3)
+            d = H.drift(x, xr, 0.04)
+            assert d.max() <= 1e-5, (fr, oid, d.max())
+    # a scene that exports nothing counts no frames
+    cfg["Configuration"].update(exportPly=False)
+    scene_file.write_text(json.dumps(cfg))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "sph_project_amd", "run_simulation.py"), "--scene_file", str(scene_file),
+                        "--output_dir", str(tmp_path / "none")], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "writing 0 frame(s)" in r.stdout, r.stdout + r.stderr
 
 
 # --------------------------------------------------------------------------------------------- BASELINE configs

@@ -153,12 +153,32 @@ def test_oracle_pair_metric_counts_four_wcsph_passes():
 
 
 def test_ply_writer_layout(tmp_path):
-    from sph_project_amd.run_simulation import write_ply_ascii
+    """The bytes `ti.tools.PLYWriter(num_vertices=n).add_vertex_pos(x, y, z).export_ascii(path)` writes (run_simulation.py:139-144),
+    restated from Taichi's python/taichi/tools/ply.py (print_header + export_ascii; default comment "created by PLYWriter"; every
+    value is `str(np.float32)` followed by one blank).  Taichi is not installed here: the expected text below is that restatement
+    written out by hand, not the output of a Taichi run."""
+    from sph_project_amd.run_simulation import read_ply_ascii, write_ply_ascii
     p = tmp_path / "a.ply"
-    write_ply_ascii(str(p), np.arange(6, dtype=np.float32).reshape(2, 3))
+    pos = np.array([[0.0, 1.0, 2.5], [0.1, -3.0e-5, 123456.7], [1.0 / 3.0, 1e16, -0.0]], dtype=np.float32)
+    write_ply_ascii(str(p), pos)
+    expected = ("ply\nformat ascii 1.0\ncomment created by PLYWriter\nelement vertex 3\n"
+                "property float x\nproperty float y\nproperty float z\nend_header\n"
+                "0.0 1.0 2.5 \n0.1 -3e-05 123456.7 \n0.33333334 1e+16 -0.0 \n")
+    assert p.read_text() == expected
+    # the body is what export_ascii's python loop produces, value by value
+    body = "".join("".join(str(v) + " " for v in row) + "\n" for row in pos)
+    assert p.read_text().endswith("end_header\n" + body)
+    # shortest round-trip digits: reading the file back gives the float32 values bit for bit
+    rng = np.random.default_rng(5)
+    big = np.concatenate([rng.uniform(-8, 8, (2000, 3)), rng.uniform(-1e-6, 1e-6, (50, 3)), rng.uniform(-1e9, 1e9, (50, 3))]).astype(np.float32)
+    write_ply_ascii(str(p), big)
+    back = read_ply_ascii(str(p))
+    assert back.dtype == np.float32 and np.array_equal(back.view(np.uint32), big.view(np.uint32))
     lines = p.read_text().splitlines()
-    assert lines[0] == "ply" and lines[1] == "format ascii 1.0" and "element vertex 2" in lines
-    assert lines[lines.index("end_header") + 1].split() == ["0", "1", "2"]
+    assert lines[lines.index("end_header") + 7] == "".join(str(v) + " " for v in big[6])
+    write_ply_ascii(str(p), np.zeros((0, 3), np.float32))     # an object that has not entered yet
+    assert p.read_text().endswith("element vertex 0\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+    assert read_ply_ascii(str(p)).shape == (0, 3)
 
 
 def test_bench_secondary_bound_is_recomputable_from_the_committed_profile():
