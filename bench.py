@@ -166,26 +166,32 @@ def exchange_unique_id(lib, rank, suffix=""):
 # ----------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(cfg, steps):
     """Oracle (kind "port") timed on the host.  Test infrastructure used as the *measured baseline only*; nothing of
-    it is on the product path.  Thread counts are swept (the OpenMP loops stop scaling long before 256 threads)."""
+    it is on the product path.  Thread counts are swept and the best one is reported, with the speed-up over one thread.
+    Threads are bound (OMP_PROC_BIND=spread over OMP_PLACES=cores, set before libgomp is loaded) and the oracle first-touches
+    its arrays page-interleaved over the threads, so that a two-socket box is not limited by the memory of one node."""
     import ctypes
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
     from tests import helpers as H
     ncpu = os.cpu_count() or 1
     sim = H.build_oracle(cfg, fixed_iterations=2 if cfg["Configuration"]["simulationMethod"] != "wcsph" else 0)
     omp = ctypes.CDLL("libgomp.so.1")
     sim.prepare()
     sim.step(1)  # warm-up (page faults, thread pool)
-    sweep = sorted({t for t in (8, 16, 32, 64, ncpu // 2, ncpu) if 1 <= t <= ncpu})
+    sweep = sorted({t for t in (1, 8, 16, 32, 64, ncpu // 2, ncpu) if 1 <= t <= ncpu})
     best = None
     table = {}
     for t in sweep:
         omp.omp_set_num_threads(int(t))
+        k = 1 if t == 1 else steps   # (one thread: one step, ~2 s at C2)
         t0 = time.perf_counter()
-        sim.step(steps)
+        sim.step(k)
         dt = time.perf_counter() - t0
-        table[t] = sim.fluid_particle_num * steps / dt
+        table[t] = sim.fluid_particle_num * k / dt
         if best is None or table[t] > table[best]:
             best = t
         best_dt = dt if best == t else best_dt
+    steps = 1 if best == 1 else steps
     n, pairs = sim.fluid_particle_num, sim.last_pairs
     sim.close()
     model = ""
@@ -196,7 +202,8 @@ def cpu_baseline(cfg, steps):
                 break
     except OSError:
         pass
-    return dict(value=table[best], cores=best, secs=best_dt, pairs_per_s=pairs * steps / best_dt, sweep=table, model=model, ncpu=ncpu)
+    return dict(value=table[best], cores=best, secs=best_dt, pairs_per_s=pairs * steps / best_dt, sweep=table, model=model, ncpu=ncpu,
+                speedup_over_1_thread=table[best] / table[1] if 1 in table else None)
 
 
 # ----------------------------------------------------------------------------------------------- fixed scenes on N GPUs
@@ -297,7 +304,51 @@ def extra_c3(args, names):
                                              "frac": 92 * n / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else None},
                         "step_achieved": step_bytes / (el / args.steps) / 1e9,
                         "step_alg_bytes": step_bytes}}
+    # the same regime once the column collapses (the state a user spends most of a run in)
+    c3_motion = int(os.environ.get("SPH_BENCH_C3_MOTION_STEP", "1000"))
+    done = args.warmup + 5 + args.repeats * args.steps
+    if c3_motion > done:
+        eng.step_async(c3_motion - done); eng.synchronize()
+        reps = []
+        for _ in range(args.repeats):
+            eng.synchronize(); t0 = time.perf_counter()
+            eng.step_async(args.steps); eng.synchronize()
+            reps.append(time.perf_counter() - t0)
+        m_el = median(reps)
+        st2 = solver.stats()
+        out["in_motion"] = {"from_step": c3_motion, "ms_per_step": 1e3 * m_el / args.steps, "value": n * args.steps / m_el,
+                            "pair_interactions_per_s": st2["pair_interactions"] * args.steps / m_el}
     eng.close()
+    # SURVEY 8d C3 "with iteration counts as measured": the reference's own stop tests (DFSPH.py:139-159, :225-243), steps synchronous
+    # like the reference's (one flag read-back per batch of iterations), from rest and from the same in-motion state
+    try:
+        container, solver = P.build_product(cfg, fast_math=0 if args.strict_math else 1, deterministic=0 if args.no_deterministic else 1)
+        eng = container.engine
+        solver.prepare()
+        k_steps = min(args.steps, 20)
+
+        def measured():
+            iters = []
+            eng.synchronize(); t0 = time.perf_counter()
+            for _ in range(k_steps):
+                eng.step(1)
+                st = solver.stats()
+                iters.append((int(st["iter_divergence"]), int(st["iter_density"])))
+            eng.synchronize()
+            el = time.perf_counter() - t0
+            return {"ms_per_step": 1e3 * el / k_steps, "value": n * k_steps / el, "steps": k_steps,
+                    "iterations_per_step": {"divergence": sum(i[0] for i in iters) / k_steps, "density": sum(i[1] for i in iters) / k_steps},
+                    "max_iterations_in_a_step": {"divergence": max(i[0] for i in iters), "density": max(i[1] for i in iters)}}
+        eng.step(args.warmup)
+        m = {"from_rest": measured()}
+        done = args.warmup + k_steps
+        if c3_motion > done:
+            eng.step(c3_motion - done)
+            m["in_motion"] = dict(measured(), from_step=c3_motion)
+        out["measured"] = dict(m, note="the solvers' own convergence tests instead of 2 + 2 fixed iterations; iteration counts as measured")
+        eng.close()
+    except Exception as e:  # noqa: BLE001
+        out["measured"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -533,6 +584,9 @@ def run_rank(args, rank, world, local_rank):
             "device": eng.device_info()["name"],
         },
         "in_motion": in_motion,
+        "value_state": "from rest (steps %d.. of the initial lattice, %s neighbours per particle); `value_in_motion` is the same scene from step %s on"
+                       % (args.presteps + args.warmup + 5, ("%.0f" % (evals / max(n_total, 1) / 2.0)) if method == "wcsph" else "n/a", args.motion_step),
+        "value_in_motion": in_motion["value"] if in_motion else None,
         "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
@@ -570,6 +624,9 @@ def run_rank(args, rank, world, local_rank):
                       f"oracle/sph_ref.c (this repo's C restatement of the reference algorithm, OpenMP), not Taichi",
             "pair_interactions_per_s": cb["pairs_per_s"], "cpu": cb["model"], "hardware_threads": cb["ncpu"],
             "threads_sweep": {str(k): v for k, v in cb["sweep"].items()},
+            "speedup_over_1_thread": cb["speedup_over_1_thread"],
+            "thread_binding": "OMP_PROC_BIND=%s OMP_PLACES=%s, arrays first-touched page-interleaved over the threads" % (
+                os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
         }
     elif rank == 0:
         out["cpu_baseline"] = None

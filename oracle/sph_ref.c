@@ -80,7 +80,22 @@ struct SphRef {
     float cg_alpha, cg_beta, cg_error;
 };
 
-#define ALLOC(ptr, n) do { (ptr) = calloc((size_t)(n) > 0 ? (size_t)(n) : 1, sizeof(*(ptr))); } while (0)
+/* Zeroed arrays whose pages are first touched round-robin by the OpenMP threads (page-granular schedule(static, 1)): with bound threads
+   (OMP_PROC_BIND=spread) the pages end up interleaved over the NUMA nodes instead of all on the node of the thread that called calloc /
+   wrote the particles first -- on a two-socket box that single node was the bottleneck of every pass beyond ~16 threads. */
+static void *alloc_interleaved(size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    char *p = malloc(bytes);
+    if (!p) return NULL;
+    const long long pages = (long long)((bytes + 4095) / 4096);
+#pragma omp parallel for schedule(static, 1)
+    for (long long k = 0; k < pages; k++) {
+        const size_t o = (size_t)k * 4096;
+        memset(p + o, 0, bytes - o < 4096 ? bytes - o : 4096);
+    }
+    return p;
+}
+#define ALLOC(ptr, n) do { (ptr) = alloc_interleaved(((size_t)(n) > 0 ? (size_t)(n) : 1) * sizeof(*(ptr))); } while (0)
 
 SphRef *sphref_create(const SphRefParams *p) {
     SphRef *s = calloc(1, sizeof(SphRef));
@@ -233,22 +248,41 @@ static inline int flatten_grid_index(const SphRef *s, const int idx[3]) {
 
 /* base_container.py:496 */
 void sphref_init_grid(SphRef *s) {
-    memset(s->grid_num_particles, 0, sizeof(int) * (size_t)s->G);
-#pragma omp parallel for schedule(static)   /* per-particle, independent */
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < s->G; c++) s->grid_num_particles[c] = 0;
+#pragma omp parallel for schedule(static)   /* per-particle, independent; the histogram is an integer atomic add like :501 (order-free) */
     for (int p = 0; p < s->particle_num; p++) {
         int idx[3];
         pos_to_index(s, s->particle_positions[p], idx);
-        s->grid_ids[p] = flatten_grid_index(s, idx);
+        const int g = flatten_grid_index(s, idx);
+        s->grid_ids[p] = g;
+#pragma omp atomic
+        s->grid_num_particles[g] += 1;
     }
-    for (int p = 0; p < s->particle_num; p++) s->grid_num_particles[s->grid_ids[p]] += 1;   /* the histogram stays serial */
-    memcpy(s->grid_num_particles_temp, s->grid_num_particles, sizeof(int) * (size_t)s->G);
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < s->G; c++) s->grid_num_particles_temp[c] = s->grid_num_particles[c];
 }
 
 /* base_container.py:546 ti.algorithms.PrefixSumExecutor.run -- inclusive, in place
-   (semantics fixed by its use at :513-515 and :555-557). */
+   (semantics fixed by its use at :513-515 and :555-557).  Integer sums: blocked two-pass scan, any number of threads. */
 void sphref_prefix_sum(SphRef *s) {
-    int acc = 0;
-    for (int c = 0; c < s->G; c++) { acc += s->grid_num_particles[c]; s->grid_num_particles[c] = acc; }
+    enum { NB = 256 };
+    int tot[NB + 1];
+    const int G = s->G, bs = (G + NB - 1) / NB;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < NB; b++) {
+        int acc = 0;
+        const int lo = b * bs, hi = lo + bs < G ? lo + bs : G;
+        for (int c = lo; c < hi; c++) { acc += s->grid_num_particles[c]; s->grid_num_particles[c] = acc; }
+        tot[b + 1] = acc;
+    }
+    tot[0] = 0;
+    for (int b = 0; b < NB; b++) tot[b + 1] += tot[b];
+#pragma omp parallel for schedule(static)
+    for (int b = 1; b < NB; b++) {
+        const int lo = b * bs, hi = lo + bs < G ? lo + bs : G, add = tot[b];
+        for (int c = lo; c < hi; c++) s->grid_num_particles[c] += add;
+    }
 }
 
 /* base_container.py:506 -- serial execution order => stable counting sort */
