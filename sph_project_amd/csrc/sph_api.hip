@@ -53,7 +53,16 @@ struct SphHandle {
     SlabComm comm;
     long long comm_n_global = 0;   // particle_num of the whole scene (sum of the ranks' owned particles), see sph_prepare
     long long comm_nfluid_global = 0;   // fluid_particle_num of the whole scene (PCISPH's error mean divides by it)
+    // Slab sharding: the scene's slab axis (z by contract; SPH_SLAB_AXIS=x|y|z) is SWAPPED with x at this ABI boundary,
+    // because the library cuts its grid along x, the slowest axis of its cell order (layers = contiguous index ranges of the sorted
+    // arrays: boundary workgroups first, interior ones while the halo flies).  0: no swap.  Everything a caller hands over or reads
+    // back stays in the scene's frame: positions / velocities / every 3-vector field, gravity, domain, grid, rigid poses and
+    // wrenches are permuted here (P = P^-1, det P = -1: axial vectors -- torque, angular velocity -- also change sign).
+    int swap_axis = 0;
 };
+
+// component k of a scene-frame vector is component frame_ix(h, k) of the library-frame vector, and vice versa
+static inline int frame_ix(const SphHandle *h, int k) { return (h->swap_axis && k == 0) ? h->swap_axis : ((h->swap_axis && k == h->swap_axis) ? 0 : k); }
 
 static int fail(SphHandle *h, int code, const char *fmt, ...) {
     char buf[512];
@@ -100,8 +109,9 @@ static void fill_consts(SphHandle *h) {
     const SphParams &p = h->prm;
     Consts &c = h->st.c;
     memset(&c, 0, sizeof(c));
-    c.nx = p.grid_num[0]; c.ny = p.grid_num[1]; c.nz = c.nz_glob = p.grid_num[2];
-    c.cz_off = 0;
+    const int ix[3] = {frame_ix(h, 0), frame_ix(h, 1), frame_ix(h, 2)};
+    c.nx = c.nx_glob = p.grid_num[ix[0]]; c.ny = p.grid_num[ix[1]]; c.nz = p.grid_num[ix[2]];
+    c.cx_off = 0;
     c.G = c.nx * c.ny * c.nz;
     const double hd = p.support_radius;
     c.grid_size = (float)hd;
@@ -130,15 +140,15 @@ static void fill_consts(SphHandle *h) {
     c.rho0 = (float)p.density_0;
     c.inv_rho0 = 1.0f / c.rho0;
     c.g_upper = (float)p.g_upper;
-    c.gx = (float)p.gravity[0]; c.gy = (float)p.gravity[1]; c.gz = (float)p.gravity[2];
+    c.gx = (float)p.gravity[ix[0]]; c.gy = (float)p.gravity[ix[1]]; c.gz = (float)p.gravity[ix[2]];
     c.st = (float)p.surface_tension;
     c.cv = (float)(2 * (3 + 2) * p.viscosity);
     c.cvb = (float)(2 * (3 + 2) * p.viscosity_b);
     c.visc_eps = (float)(0.01 * hd * hd);
     c.pad = (float)p.padding;
-    c.hix = (float)(p.domain_size[0] - p.padding);
-    c.hiy = (float)(p.domain_size[1] - p.padding);
-    c.hiz = (float)(p.domain_size[2] - p.padding);
+    c.hix = (float)(p.domain_size[ix[0]] - p.padding);
+    c.hiy = (float)(p.domain_size[ix[1]] - p.padding);
+    c.hiz = (float)(p.domain_size[ix[2]] - p.padding);
     c.thr_kappa = (float)1e-5 * c.dt;
     c.V0 = (float)p.V0;
     c.force_global = p.force_global;
@@ -293,7 +303,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     memset(&h->last, 0, sizeof(h->last));
     s.has_dynamic_rigid = 0; s.has_rigid = 0;
     s.dyn = s.dyn_cur = nullptr; s.async_counts = 0; s.tables_pending = 0; memset(&s.push, 0, sizeof(s.push));
-    s.slab_active = 0; s.xcur = 0; s.halo_cap = 0; s.z_lo = 0; s.z_hi = s.c.nz_glob; s.has_down = s.has_up = 0;
+    s.slab_active = 0; s.xcur = 0; s.halo_cap = 0; s.z_lo = 0; s.z_hi = s.c.nx_glob; s.has_down = s.has_up = 0;
     s.xidx[0] = s.xidx[1] = nullptr; s.halo_counts = nullptr;
     s.visc_rho_raw = (p.method == SPH_METHOD_WCSPH);
     s.skip_viscosity = 0;
@@ -334,10 +344,11 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
     std::vector<float> hr(n), hpr(n);
     bool any_dyn_rigid = false;
     int nfl = 0;
+    const int ix0 = frame_ix(h, 0), ix1 = frame_ix(h, 1), ix2 = frame_ix(h, 2);   // scene frame -> library frame
     for (int k = 0; k < n; ++k) {
         // base_container.py:404 add_particle
-        hp[k] = make_float4(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2], V0);
-        hv[k] = make_float4(vel[3 * k], vel[3 * k + 1], vel[3 * k + 2], V0 * density[k]);
+        hp[k] = make_float4(pos[3 * k + ix0], pos[3 * k + ix1], pos[3 * k + ix2], V0);
+        hv[k] = make_float4(vel[3 * k + ix0], vel[3 * k + ix1], vel[3 * k + ix2], V0 * density[k]);
         hm[k] = META_PACK(object_id, material[k], is_dynamic[k] ? 1 : 0);
         if (h->prepared && material[k] == SPH_MAT_RIGID) { hm[k] |= META_FRESH_BIT; h->fresh_state = 1; }
         hid[k] = h->n + k;
@@ -405,8 +416,13 @@ extern "C" int sph_set_rigid_pose(SphHandle *h, int o, const float *com, const f
                                   const float *angvel, const float *com0) {
     if (!h || o < 0 || o >= SPH_MAX_OBJECTS || !com || !rot9 || !vel || !angvel) return fail(h, SPH_ERR_INVALID, "set_rigid_pose: bad argument");
     HIPCHK(h, hipSetDevice(h->device));
-    for (int a = 0; a < 3; ++a) { h->pose_h.com[o][a] = com[a]; h->pose_h.vel[o][a] = vel[a]; h->pose_h.angvel[o][a] = angvel[a]; if (com0) h->pose_h.com0[o][a] = com0[a]; }
-    for (int a = 0; a < 9; ++a) h->pose_h.rot[o][a] = rot9[a];
+    // scene frame -> library frame: polar vectors P v, the axial angular velocity det(P) P w = -P w, the rotation P R P
+    const float ws = h->swap_axis ? -1.0f : 1.0f;
+    for (int a = 0; a < 3; ++a) {
+        const int b = frame_ix(h, a);
+        h->pose_h.com[o][a] = com[b]; h->pose_h.vel[o][a] = vel[b]; h->pose_h.angvel[o][a] = ws * angvel[b]; if (com0) h->pose_h.com0[o][a] = com0[b];
+        for (int q = 0; q < 3; ++q) h->pose_h.rot[o][3 * a + q] = rot9[3 * b + frame_ix(h, q)];
+    }
     h->pose_dirty = true;
     return upload_pose(h);
 }
@@ -416,8 +432,13 @@ extern "C" int sph_get_rigid_wrench(SphHandle *h, float *force, float *torque, i
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(h->scal_h, h->st.scal, sizeof(DevScalars), hipMemcpyDeviceToHost, h->st.stream));
     HIPCHK(h, hipStreamSynchronize(h->st.stream));
-    memcpy(force, h->scal_h->wrench, sizeof(float) * SPH_NOBJ * 3);
-    memcpy(torque, h->scal_h->wrench + SPH_NOBJ * 3, sizeof(float) * SPH_NOBJ * 3);
+    // library frame -> scene frame: the force is polar (P f), the torque axial (-P t under the swap)
+    for (int o = 0; o < SPH_NOBJ; ++o)
+        for (int a = 0; a < 3; ++a) {
+            const int b = frame_ix(h, a);
+            force[3 * o + a] = h->scal_h->wrench[3 * o + b];
+            torque[3 * o + a] = (h->swap_axis ? -1.0f : 1.0f) * h->scal_h->wrench[SPH_NOBJ * 3 + 3 * o + b];
+        }
     if (h->st.slab_active && h->comm.nranks > 1) {
         // sharded scene: every rank holds the contributions of ITS fluid particles (SURVEY 8e "rigid coupling under sharding");
         // the body's wrench is their sum.  Collective: every rank calls this at the same point of the step (the host
@@ -812,7 +833,8 @@ extern "C" int sph_download(SphHandle *h, int field, void *dst, size_t bytes) {
         std::vector<float4> tmp(n);
         HIPCHK(h, hipMemcpy(tmp.data(), src, n * sizeof(float4), hipMemcpyDeviceToHost));
         float *d = (float *)dst;
-        for (size_t i = 0; i < n; ++i) { d[3 * i] = tmp[i].x; d[3 * i + 1] = tmp[i].y; d[3 * i + 2] = tmp[i].z; }
+        const int ix0 = frame_ix(h, 0), ix1 = frame_ix(h, 1), ix2 = frame_ix(h, 2);   // library frame -> scene frame
+        for (size_t i = 0; i < n; ++i) { const float v[3] = {tmp[i].x, tmp[i].y, tmp[i].z}; d[3 * i] = v[ix0]; d[3 * i + 1] = v[ix1]; d[3 * i + 2] = v[ix2]; }
         return SPH_OK;
     }
     if (field == SPH_F_REST_VOLUME || field == SPH_F_MASS) {
@@ -856,10 +878,15 @@ extern "C" int sph_download(SphHandle *h, int field, void *dst, size_t bytes) {
         std::vector<float4> tmp(n);
         HIPCHK(h, hipMemcpy(tmp.data(), s.posv.cur(), n * sizeof(float4), hipMemcpyDeviceToHost));
         int32_t *d = (int32_t *)dst;
+        // the REFERENCE's flat cell id: scene frame, whole grid (whatever this rank's slab or the library's axis order)
         const Consts &c = s.c;
+        const int *gn = h->prm.grid_num;
+        const int ix0 = frame_ix(h, 0), ix1 = frame_ix(h, 1), ix2 = frame_ix(h, 2);
         auto cc = [](float x, float gs, int nn) { int v = (int)(x / gs); v = v < 0 ? 0 : v; return v > nn - 1 ? nn - 1 : v; };
-        for (size_t i = 0; i < n; ++i)
-            d[i] = (cc(tmp[i].x, c.grid_size, c.nx) * c.ny + cc(tmp[i].y, c.grid_size, c.ny)) * c.nz + std::min(std::max(cc(tmp[i].z, c.grid_size, c.nz_glob) - c.cz_off, 0), c.nz - 1);
+        for (size_t i = 0; i < n; ++i) {
+            const float v[3] = {tmp[i].x, tmp[i].y, tmp[i].z};
+            d[i] = (cc(v[ix0], c.grid_size, gn[0]) * gn[1] + cc(v[ix1], c.grid_size, gn[1])) * gn[2] + cc(v[ix2], c.grid_size, gn[2]);
+        }
         return SPH_OK;
     }
     return fail(h, SPH_ERR_INVALID, "download: unknown field %d", field);
@@ -889,9 +916,10 @@ extern "C" int sph_upload(SphHandle *h, int field, const void *src, size_t bytes
         std::vector<float4> tmp(n);
         HIPCHK(h, hipMemcpy(tmp.data(), vdst, n * sizeof(float4), hipMemcpyDeviceToHost));
         const float *f = (const float *)src;
+        const int ix0 = frame_ix(h, 0), ix1 = frame_ix(h, 1), ix2 = frame_ix(h, 2);   // scene frame -> library frame
         for (size_t i = 0; i < n; ++i) {
             if (w_only) tmp[i].w = f[i];
-            else { tmp[i].x = f[3 * i]; tmp[i].y = f[3 * i + 1]; tmp[i].z = f[3 * i + 2]; }
+            else { tmp[i].x = f[3 * i + ix0]; tmp[i].y = f[3 * i + ix1]; tmp[i].z = f[3 * i + ix2]; }
         }
         HIPCHK(h, hipMemcpy(vdst, tmp.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         return SPH_OK;

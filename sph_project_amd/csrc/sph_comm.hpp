@@ -46,7 +46,7 @@ struct SlabComm {
     int slab_ready = 0;          // halo buffers allocated (sph_comm_set_slab)
     int rebalance_every = 0;     // re-plan the slab cuts from the z histogram every this many steps (0: never)
     int rebalance_moves = 0;     // cuts moved so far (this rank's lower + upper face)
-    int *hist_dev = nullptr;     // nz_glob + nranks ints: layer histogram | every rank's z_lo
+    int *hist_dev = nullptr;     // nx_glob + nranks ints: layer histogram | every rank's z_lo
     int *hist_host = nullptr;    // pinned mirror
     unsigned char id[128];
     // data plane

@@ -191,9 +191,22 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
     if (!h || !h->comm.kind) return fail(h, SPH_ERR_INVALID, "comm_set_slab: communicator not initialised");
     Consts &c = h->st.c;
     State &s = h->st;
-    if (z_lo < 0 || z_hi > c.nz_glob || z_hi - z_lo < 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: a slab needs >= 2 cell layers inside the grid");
     if (h->n > 0) return fail(h, SPH_ERR_INVALID, "comm_set_slab: set the slab before particles are appended");
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->comm.slab_ready) {
+        // The slab axis of the SCENE (z: SURVEY 8e, BASELINE configs[3]; SPH_SLAB_AXIS=x|y|z for scenes that are longer another way) becomes
+        // the library's x from here on -- see SphHandle::swap_axis.  Nothing has been appended yet; the constants are derived again.
+        const char *ax = getenv("SPH_SLAB_AXIS");
+        const int a = (ax && (ax[0] == 'x' || ax[0] == 'X')) ? 0 : ((ax && (ax[0] == 'y' || ax[0] == 'Y')) ? 1 : 2);
+        if (a != h->swap_axis) {
+            h->swap_axis = a;
+            const int fg = c.force_global;
+            fill_consts(h);
+            c.force_global = fg;
+            refresh_counts(h);
+        }
+    }
+    if (z_lo < 0 || z_hi > c.nx_glob || z_hi - z_lo < 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: a slab needs >= 2 cell layers inside the grid");
     s.has_down = h->comm.rank > 0; s.has_up = h->comm.rank < h->comm.nranks - 1;
     bool first = false;
     if (!h->comm.slab_ready) {
@@ -211,8 +224,8 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
         HIPCHK(h, hipMalloc((void **)&h->comm.bad_dev, sizeof(int)));
         HIPCHK(h, hipHostMalloc((void **)&h->comm.n_stage, 16 * sizeof(int), hipHostMallocDefault));
         s.xcur = 0;
-        HIPCHK(h, hipMalloc((void **)&h->comm.hist_dev, sizeof(int) * (size_t)(c.nz_glob + h->comm.nranks)));
-        HIPCHK(h, hipHostMalloc((void **)&h->comm.hist_host, sizeof(int) * (size_t)(c.nz_glob + h->comm.nranks), hipHostMallocDefault));
+        HIPCHK(h, hipMalloc((void **)&h->comm.hist_dev, sizeof(int) * (size_t)(c.nx_glob + h->comm.nranks)));
+        HIPCHK(h, hipHostMalloc((void **)&h->comm.hist_host, sizeof(int) * (size_t)(c.nx_glob + h->comm.nranks), hipHostMallocDefault));
         const char *rb = getenv("SPH_SLAB_REBALANCE");
         h->comm.rebalance_every = rb ? atoi(rb) : 64;
         h->comm.slab_ready = 1;
@@ -222,9 +235,9 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
     // the cell lists cover the own layers plus one ghost layer per interior side only: G, and with it the histogram, the
     // scan and the cell windows, shrink from the global grid to the slab (weak scaling would otherwise scan N times as
     // many cells on every rank)
-    c.cz_off = z_lo > 0 ? z_lo - 1 : 0;
-    const int top = z_hi < c.nz_glob ? z_hi + 1 : c.nz_glob;
-    c.nz = top - c.cz_off;
+    c.cx_off = z_lo > 0 ? z_lo - 1 : 0;
+    const int top = z_hi < c.nx_glob ? z_hi + 1 : c.nx_glob;
+    c.nx = top - c.cx_off;
     c.G = c.nx * c.ny * c.nz;
     if (first && h->comm.push_wanted) { int rc = push_setup(h); if (rc) return rc; }
     return SPH_OK;
@@ -610,7 +623,7 @@ static int slab_rebalance(SphHandle *h) {
     SlabComm &c = h->comm;
     Consts &k = s.c;
     if (c.nranks < 2) return SPH_OK;
-    const int nz = k.nz_glob, len = nz + c.nranks;
+    const int nz = k.nx_glob, len = nz + c.nranks;   // layers along the slab axis
     ProfScope p(h, SPH_K_HALO);
     h->L->layer_hist(s, c.hist_dev);
     HIPCHK(h, hipMemsetAsync(c.hist_dev + nz, 0, sizeof(int) * c.nranks, s.stream));
@@ -647,9 +660,9 @@ static int slab_rebalance(SphHandle *h) {
     const int z_lo = next[c.rank], z_hi = next[c.rank + 1];
     c.rebalance_moves += (z_lo != s.z_lo) + (z_hi != s.z_hi);
     s.z_lo = z_lo; s.z_hi = z_hi;
-    k.cz_off = z_lo > 0 ? z_lo - 1 : 0;
-    const int top = z_hi < k.nz_glob ? z_hi + 1 : k.nz_glob;
-    k.nz = top - k.cz_off;
+    k.cx_off = z_lo > 0 ? z_lo - 1 : 0;
+    const int top = z_hi < k.nx_glob ? z_hi + 1 : k.nx_glob;
+    k.nx = top - k.cx_off;
     k.G = k.nx * k.ny * k.nz;
     return SPH_OK;
 }

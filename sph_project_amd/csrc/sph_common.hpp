@@ -29,8 +29,11 @@
 #define META_SET_MAT(m, mat) (((m) & ~(0x3 << 8)) | (((mat) & 0x3) << 8))
 
 struct Consts {
-    int nx, ny, nz, G;      // grid the cell lists are built on (slab sharding: nz = own layers + ghost layers, see cz_off)
-    int nz_glob, cz_off;    // global number of z layers; global layer of local layer 0
+    int nx, ny, nz, G;      // grid the cell lists are built on (slab sharding: nx = own layers + ghost layers, see cx_off)
+    int nx_glob, cx_off;    // slab sharding cuts the grid along x, the SLOWEST axis of the cell order (lin = (cx ny + cy) nz + cz): a
+                            // rank's ghost / boundary / interior layers are contiguous index ranges of the sorted arrays.  nx_glob =
+                            // layers of the whole scene, cx_off = global layer of local layer 0.  (The scene's slab axis is mapped onto
+                            // this x at the C-ABI boundary: sph_api.hip, SphHandle::swap_axis.)
     float grid_size;        // f32(dh): cell size
     float h, h2, inv_h;     // support radius, squared, reciprocal (fast build)
     float kW, kG;           // cubic spline constants (base_solver.py:57, :81)

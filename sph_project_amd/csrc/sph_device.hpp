@@ -54,12 +54,12 @@ __device__ __forceinline__ int cell_coord(float x, float gs, int n) {
     return c;
 }
 
-// z axis: a slab-sharded rank builds its cell lists on its own layers only (local layer = global layer - cz_off); a
-// particle outside them (it is about to be dropped) is clamped onto the nearest local layer.
-__device__ __forceinline__ int cell_coord_z(const Consts &c, float z) {
-    int cz = cell_coord(z, c.grid_size, c.nz_glob) - c.cz_off;
-    cz = cz < 0 ? 0 : cz;
-    return cz > c.nz - 1 ? c.nz - 1 : cz;
+// x axis: a slab-sharded rank builds its cell lists on its own layers only (local layer = global layer - cx_off); a
+// particle outside them (it is about to be dropped) is clamped onto the nearest local layer.  Unsharded: cx_off = 0, nx = nx_glob.
+__device__ __forceinline__ int cell_coord_x(const Consts &c, float x) {
+    int cx = cell_coord(x, c.grid_size, c.nx_glob) - c.cx_off;
+    cx = cx < 0 ? 0 : cx;
+    return cx > c.nx - 1 ? c.nx - 1 : cx;
 }
 
 // Per-pair geometry shared by kernel_W / kernel_gradient.  Strict build: rn = sqrt(r2), q = rn / h (IEEE).
@@ -181,9 +181,9 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
     int lin = -1 - lane;  // distinct dummy key for lanes past the end
     if (valid) {
         const float4 p = posv[i];
-        const int cx = cell_coord(p.x, c.grid_size, c.nx);
+        const int cx = cell_coord_x(c, p.x);
         const int cy = cell_coord(p.y, c.grid_size, c.ny);
-        const int cz = cell_coord_z(c, p.z);
+        const int cz = cell_coord(p.z, c.grid_size, c.nz);
         lin = (cx * c.ny + cy) * c.nz + cz;
         if (meta_dead && META_DEAD(meta_dead[i])) lin = c.G;   // slab sharding: graveyard cell behind the grid
         cellid[i] = lin;
@@ -719,12 +719,13 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
             if (kind >= 1 && kind <= 8) tabs.tab[kind - 1][x & 0x0fffffff] = i;
         }
         const float4 p = posv[i];
-        const int cx = cell_coord(p.x, c.grid_size, c.nx);
-        const int k = (int)((p.x / c.grid_size - (float)cx) * 62.0f);
+        const int cxg = cell_coord(p.x, c.grid_size, c.nx_glob);   // (the key is the position inside the cell: global layer)
+        const int k = (int)((p.x / c.grid_size - (float)cxg) * 62.0f);
+        const int cx = cell_coord_x(c, p.x);
         key = k < 0 ? 0 : (k > 62 ? 62 : k);
         if (tid == 0 || tid == nvalid - 1) {
             const int cy = cell_coord(p.y, c.grid_size, c.ny);
-            const int cz = cell_coord_z(c, p.z);
+            const int cz = cell_coord(p.z, c.grid_size, c.nz);
             const int lin = (cx * c.ny + cy) * c.nz + cz;
             if (tid == 0) s_c[0] = lin;
             if (tid == nvalid - 1) s_c[1] = lin;
@@ -1003,9 +1004,9 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     int e0, e1;
     unsigned dom = 0u;
     {
-        const int cx = cell_coord(pi.x, c.grid_size, c.nx);
+        const int cx = cell_coord_x(c, pi.x);
         const int cy = cell_coord(pi.y, c.grid_size, c.ny);
-        const int cz = cell_coord_z(c, pi.z);
+        const int cz = cell_coord(pi.z, c.grid_size, c.nz);
         const int lin = (cx * c.ny + cy) * c.nz + cz;
         const int z0 = cz > 0 ? cz - 1 : 0;
         const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
@@ -1109,8 +1110,8 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     } else {   // (a workgroup spanning more cells than the window cache holds: sparse spray)
                         float px = pi.x, py = pi.y, pz = pi.z;
                         asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));   // keeps the recomputation IN this branch (it is loop-invariant: hoisted, it would hold four registers for every workgroup)
-                        const int xx = cell_coord(px, c.grid_size, c.nx) + g - 1, yy = cell_coord(py, c.grid_size, c.ny) + q - 1;
-                        const int cz = cell_coord_z(c, pz);
+                        const int xx = cell_coord_x(c, px) + g - 1, yy = cell_coord(py, c.grid_size, c.ny) + q - 1;
+                        const int cz = cell_coord(pz, c.grid_size, c.nz);
                         const int z0 = cz > 0 ? cz - 1 : 0;
                         const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
                         const int lin0 = (xx * c.ny + yy) * c.nz + z0;

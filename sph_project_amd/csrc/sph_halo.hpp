@@ -1,10 +1,14 @@
-// sph_halo.hpp -- z-slab sharding, device side (included inside the per-build namespace).
+// sph_halo.hpp -- slab sharding, device side (included inside the per-build namespace).
 //
-// Rank r owns the global cell layers cz in [z_lo, z_hi) (>= 2 layers) and keeps one ghost layer per interior
+// The slab axis is the library's x, the SLOWEST axis of the cell order (the scene's slab axis -- z by contract, SURVEY 8e -- is
+// swapped onto it at the C-ABI boundary): layers are contiguous index ranges of the sorted arrays, which is what lets boundary
+// workgroups run first and interior ones while the halo is in flight.  `z_lo` / `z_hi` keep their names from the API
+// (sph_comm_set_slab): they are LAYER numbers along the slab axis.
+// Rank r owns the global cell layers [z_lo, z_hi) (>= 2 layers) and keeps one ghost layer per interior
 // side.  Once per step, right before the sort, ONE message per neighbour carries both kinds of
 // records (48 B each: posv, velm, meta|pid|color|rho; 64 B with the rest position when the scene has a dynamic rigid body):
 //   * migrants: particles that left the slab -> ownership moves (ghost flag 0);
-//   * boundary copies: owned particles in cz == z_lo / z_hi-1 -> ghosts of the neighbour (ghost flag 1).
+//   * boundary copies: owned particles in layer z_lo / z_hi-1 -> ghosts of the neighbour (ghost flag 1).
 // A migrant that lands in the neighbour's boundary layer (it moved < 1 layer) is needed back as a ghost; both
 // sides can tell that from the record itself, so the sender keeps it as a local ghost ("echo ghost", indexed by
 // its position k in the sender's message) and the receiver tags it "echo send k": no second round.
@@ -98,7 +102,7 @@ k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z
             dead = 1;
         } else {
             p = a.posv[i];
-            const int cz = cell_coord(p.z, c.grid_size, c.nz_glob);   // global layer: compared with the slab bounds
+            const int cz = cell_coord(p.x, c.grid_size, c.nx_glob);   // global layer: compared with the slab bounds
             if (cz < z_lo && has_down) {           // left through the lower face: ownership moves down
                 side = 0; mrec = META_SET_GHOST(m, 0);
                 if (cz == z_lo - 1) mnew = META_SET_GHOST(m, 1); else dead = 1;   // kept as "echo ghost" / gone
@@ -119,7 +123,7 @@ k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z
             if (dead) lin = c.G;
             else {
                 const float4 q = a.posv[i];
-                lin = (cell_coord(q.x, c.grid_size, c.nx) * c.ny + cell_coord(q.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, q.z);
+                lin = (cell_coord_x(c, q.x) * c.ny + cell_coord(q.y, c.grid_size, c.ny)) * c.nz + cell_coord(q.z, c.grid_size, c.nz);
             }
             hash.cellid[i] = lin;
         }
@@ -260,13 +264,13 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
         int xi;
         if (META_GHOST(m)) xi = HALO_PACK(HALO_GHOST + side, k);
         else {  // a migrant, now owned here; echo it back if it sits in my boundary layer facing the sender
-            const int cz = cell_coord(p.z, c.grid_size, c.nz_glob);
+            const int cz = cell_coord(p.x, c.grid_size, c.nx_glob);
             const int edge = side == 0 ? z_lo : z_hi - 1;
             xi = cz == edge ? HALO_PACK(HALO_ECHO_SEND + side, k) : 0;
         }
         xidx[d] = xi;
         if (hash.cellid) {   // the arrival's share of this step's k_hash_count
-            const int lin = (cell_coord(p.x, c.grid_size, c.nx) * c.ny + cell_coord(p.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, p.z);
+            const int lin = (cell_coord_x(c, p.x) * c.ny + cell_coord(p.y, c.grid_size, c.ny)) * c.nz + cell_coord(p.z, c.grid_size, c.nz);
             hash.cellid[d] = lin;
             hash.rank[d] = atomicAdd(&hash.cell_count[lin], 1);
         }
@@ -295,7 +299,7 @@ k_halo_unpack(const Consts c, int count, int offset, int side, int z_lo, int z_h
     int xi;
     if (META_GHOST(m)) xi = HALO_PACK(HALO_GHOST + side, k);
     else {  // a migrant, now owned here; echo it back if it sits in my boundary layer facing the sender
-        const int cz = cell_coord(p.z, c.grid_size, c.nz_glob);
+        const int cz = cell_coord(p.x, c.grid_size, c.nx_glob);
         const int edge = side == 0 ? z_lo : z_hi - 1;
         xi = cz == edge ? HALO_PACK(HALO_ECHO_SEND + side, k) : 0;
     }
@@ -498,7 +502,7 @@ k_layer_hist(const Consts c, int n, const float4 *posv, const int *meta, int *hi
     if (i >= n) return;
     const int m = meta[i];
     if (META_GHOST(m) || META_DEAD(m)) return;
-    atomicAdd(&hist[cell_coord(posv[i].z, c.grid_size, c.nz_glob)], 1);
+    atomicAdd(&hist[cell_coord(posv[i].x, c.grid_size, c.nx_glob)], 1);
 }
 
 // number of ghost copies among the first n particles (sph_comm_get_slab): one atomic per wave

@@ -168,7 +168,7 @@ static void l_loop_criterion(State &s, int slot) {
 }
 
 static void l_layer_hist(State &s, int *hist) {
-    hipMemsetAsync(hist, 0, sizeof(int) * (size_t)s.c.nz_glob, s.stream);
+    hipMemsetAsync(hist, 0, sizeof(int) * (size_t)s.c.nx_glob, s.stream);
     if (s.c.n > 0) hipLaunchKernelGGL(k_layer_hist, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.c.n, s.posv.cur(), s.meta.cur(), hist);
 }
 
