@@ -36,6 +36,7 @@ struct SphHandle {
     int n_nonfluid = 0;
     bool any_rigid_object = false;   // a non-fluid object was registered (slab sharding: its particles may live on another rank)
     int64_t steps = 0;
+    int steps_to_follow = 0;       // sph_step_async(n): steps of this call still to come after the running one
     double total_time = 0.0;
     bool prepared = false;
     bool pose_dirty = false;
@@ -58,11 +59,28 @@ struct SphHandle {
     // arrays: boundary workgroups first, interior ones while the halo flies).  0: no swap.  Everything a caller hands over or reads
     // back stays in the scene's frame: positions / velocities / every 3-vector field, gravity, domain, grid, rigid poses and
     // wrenches are permuted here (P = P^-1, det P = -1: axial vectors -- torque, angular velocity -- also change sign).
-    int swap_axis = 0;
+    int swap_axis = 0;             // != 0: the frames differ (kept as a flag; the permutation itself follows)
+    int perm[3] = {0, 1, 2};       // library axis k  = scene axis perm[k]
+    int inv[3] = {0, 1, 2};        // scene axis k    = library axis inv[k]
+    float axial = 1.0f;            // parity of the permutation: sign of axial vectors (torque, angular velocity) across the boundary
 };
 
-// component k of a scene-frame vector is component frame_ix(h, k) of the library-frame vector, and vice versa
-static inline int frame_ix(const SphHandle *h, int k) { return (h->swap_axis && k == 0) ? h->swap_axis : ((h->swap_axis && k == h->swap_axis) ? 0 : k); }
+// "zxy" = library (x, y, z) <- scene (z, x, y)
+static bool set_axis_order(SphHandle *h, const char *order) {
+    int p[3], seen = 0;
+    for (int k = 0; k < 3; ++k) {
+        const char ch = order ? order[k] : 0;
+        p[k] = (ch == 'x' || ch == 'X') ? 0 : (ch == 'y' || ch == 'Y') ? 1 : (ch == 'z' || ch == 'Z') ? 2 : -1;
+        if (p[k] < 0) return false;
+        seen |= 1 << p[k];
+    }
+    if (seen != 7 || order[3]) return false;
+    for (int k = 0; k < 3; ++k) { h->perm[k] = p[k]; h->inv[p[k]] = k; }
+    const bool even = (p[0] == 0 && p[1] == 1) || (p[0] == 1 && p[1] == 2) || (p[0] == 2 && p[1] == 0);
+    h->axial = even ? 1.0f : -1.0f;
+    h->swap_axis = !(p[0] == 0 && p[1] == 1 && p[2] == 2);
+    return true;
+}
 
 static int fail(SphHandle *h, int code, const char *fmt, ...) {
     char buf[512];
@@ -109,7 +127,7 @@ static void fill_consts(SphHandle *h) {
     const SphParams &p = h->prm;
     Consts &c = h->st.c;
     memset(&c, 0, sizeof(c));
-    const int ix[3] = {frame_ix(h, 0), frame_ix(h, 1), frame_ix(h, 2)};
+    const int *ix = h->perm;
     c.nx = c.nx_glob = p.grid_num[ix[0]]; c.ny = p.grid_num[ix[1]]; c.nz = p.grid_num[ix[2]];
     c.cx_off = 0;
     c.G = c.nx * c.ny * c.nz;
@@ -242,6 +260,9 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     memset(&s.c, 0, sizeof(s.c));
     s.stream = nullptr;
     HIP_CREATE(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (const char *ord = getenv("SPH_AXIS_ORDER")) {   // which scene axes the library's (x, y, z) are, e.g. "zxy" (A/B of the cell order; sph_comm_set_slab picks one for sharded runs)
+        if (!set_axis_order(h, ord)) { fail(nullptr, SPH_ERR_INVALID, "sph_create: SPH_AXIS_ORDER must be a permutation of xyz"); sph_destroy(h); return SPH_ERR_INVALID; }
+    }
     fill_consts(h);
     const size_t cap = (size_t)p.particle_max_num;
     s.cap = p.particle_max_num;
@@ -303,6 +324,8 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     memset(&h->last, 0, sizeof(h->last));
     s.has_dynamic_rigid = 0; s.has_rigid = 0;
     s.dyn = s.dyn_cur = nullptr; s.async_counts = 0; s.tables_pending = 0; memset(&s.push, 0, sizeof(s.push));
+    s.tile_list[0] = s.tile_list[1] = nullptr; s.tile_cnt = nullptr; s.tile_sel = 0; s.tile_plan_n = -1;
+    s.tile_bound_b = 0; s.defer_flip = 0; s.classify_part = 0; s.preclassified = 0;
     s.slab_active = 0; s.xcur = 0; s.halo_cap = 0; s.z_lo = 0; s.z_hi = s.c.nx_glob; s.has_down = s.has_up = 0;
     s.xidx[0] = s.xidx[1] = nullptr; s.halo_counts = nullptr;
     s.visc_rho_raw = (p.method == SPH_METHOD_WCSPH);
@@ -344,7 +367,7 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
     std::vector<float> hr(n), hpr(n);
     bool any_dyn_rigid = false;
     int nfl = 0;
-    const int ix0 = frame_ix(h, 0), ix1 = frame_ix(h, 1), ix2 = frame_ix(h, 2);   // scene frame -> library frame
+    const int ix0 = h->perm[0], ix1 = h->perm[1], ix2 = h->perm[2];   // scene frame -> library frame
     for (int k = 0; k < n; ++k) {
         // base_container.py:404 add_particle
         hp[k] = make_float4(pos[3 * k + ix0], pos[3 * k + ix1], pos[3 * k + ix2], V0);
@@ -416,12 +439,11 @@ extern "C" int sph_set_rigid_pose(SphHandle *h, int o, const float *com, const f
                                   const float *angvel, const float *com0) {
     if (!h || o < 0 || o >= SPH_MAX_OBJECTS || !com || !rot9 || !vel || !angvel) return fail(h, SPH_ERR_INVALID, "set_rigid_pose: bad argument");
     HIPCHK(h, hipSetDevice(h->device));
-    // scene frame -> library frame: polar vectors P v, the axial angular velocity det(P) P w = -P w, the rotation P R P
-    const float ws = h->swap_axis ? -1.0f : 1.0f;
+    // scene frame -> library frame: polar vectors P v, the axial angular velocity det(P) P w, the rotation P R P^T
     for (int a = 0; a < 3; ++a) {
-        const int b = frame_ix(h, a);
-        h->pose_h.com[o][a] = com[b]; h->pose_h.vel[o][a] = vel[b]; h->pose_h.angvel[o][a] = ws * angvel[b]; if (com0) h->pose_h.com0[o][a] = com0[b];
-        for (int q = 0; q < 3; ++q) h->pose_h.rot[o][3 * a + q] = rot9[3 * b + frame_ix(h, q)];
+        const int b = h->perm[a];
+        h->pose_h.com[o][a] = com[b]; h->pose_h.vel[o][a] = vel[b]; h->pose_h.angvel[o][a] = h->axial * angvel[b]; if (com0) h->pose_h.com0[o][a] = com0[b];
+        for (int q = 0; q < 3; ++q) h->pose_h.rot[o][3 * a + q] = rot9[3 * b + h->perm[q]];
     }
     h->pose_dirty = true;
     return upload_pose(h);
@@ -432,12 +454,12 @@ extern "C" int sph_get_rigid_wrench(SphHandle *h, float *force, float *torque, i
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(h->scal_h, h->st.scal, sizeof(DevScalars), hipMemcpyDeviceToHost, h->st.stream));
     HIPCHK(h, hipStreamSynchronize(h->st.stream));
-    // library frame -> scene frame: the force is polar (P f), the torque axial (-P t under the swap)
+    // library frame -> scene frame: the force is polar (P^T f), the torque axial (det(P) P^T t)
     for (int o = 0; o < SPH_NOBJ; ++o)
         for (int a = 0; a < 3; ++a) {
-            const int b = frame_ix(h, a);
+            const int b = h->inv[a];
             force[3 * o + a] = h->scal_h->wrench[3 * o + b];
-            torque[3 * o + a] = (h->swap_axis ? -1.0f : 1.0f) * h->scal_h->wrench[SPH_NOBJ * 3 + 3 * o + b];
+            torque[3 * o + a] = h->axial * h->scal_h->wrench[SPH_NOBJ * 3 + 3 * o + b];
         }
     if (h->st.slab_active && h->comm.nranks > 1) {
         // sharded scene: every rank holds the contributions of ITS fluid particles (SURVEY 8e "rigid coupling under sharding");
@@ -727,7 +749,12 @@ extern "C" int sph_step_async(SphHandle *h, int nsteps) {
         return fail(h, SPH_ERR_UNSUPPORTED, "sph_step_async needs wcsph or fixed_iterations > 0");
     HIPCHK(h, hipSetDevice(h->device));
     refresh_counts(h);
-    for (int k = 0; k < nsteps; ++k) { int rc = step_once(h, false); if (rc) return rc; }
+    for (int k = 0; k < nsteps; ++k) {
+        h->steps_to_follow = nsteps - 1 - k;   // (a sharded WCSPH step may start the next step's halo message behind its own force pass)
+        int rc = step_once(h, false);
+        h->steps_to_follow = 0;
+        if (rc) return rc;
+    }
     return check_async(h);
 }
 
@@ -833,7 +860,7 @@ extern "C" int sph_download(SphHandle *h, int field, void *dst, size_t bytes) {
         std::vector<float4> tmp(n);
         HIPCHK(h, hipMemcpy(tmp.data(), src, n * sizeof(float4), hipMemcpyDeviceToHost));
         float *d = (float *)dst;
-        const int ix0 = frame_ix(h, 0), ix1 = frame_ix(h, 1), ix2 = frame_ix(h, 2);   // library frame -> scene frame
+        const int ix0 = h->inv[0], ix1 = h->inv[1], ix2 = h->inv[2];   // library frame -> scene frame
         for (size_t i = 0; i < n; ++i) { const float v[3] = {tmp[i].x, tmp[i].y, tmp[i].z}; d[3 * i] = v[ix0]; d[3 * i + 1] = v[ix1]; d[3 * i + 2] = v[ix2]; }
         return SPH_OK;
     }
@@ -881,7 +908,7 @@ extern "C" int sph_download(SphHandle *h, int field, void *dst, size_t bytes) {
         // the REFERENCE's flat cell id: scene frame, whole grid (whatever this rank's slab or the library's axis order)
         const Consts &c = s.c;
         const int *gn = h->prm.grid_num;
-        const int ix0 = frame_ix(h, 0), ix1 = frame_ix(h, 1), ix2 = frame_ix(h, 2);
+        const int ix0 = h->inv[0], ix1 = h->inv[1], ix2 = h->inv[2];
         auto cc = [](float x, float gs, int nn) { int v = (int)(x / gs); v = v < 0 ? 0 : v; return v > nn - 1 ? nn - 1 : v; };
         for (size_t i = 0; i < n; ++i) {
             const float v[3] = {tmp[i].x, tmp[i].y, tmp[i].z};
@@ -916,7 +943,7 @@ extern "C" int sph_upload(SphHandle *h, int field, const void *src, size_t bytes
         std::vector<float4> tmp(n);
         HIPCHK(h, hipMemcpy(tmp.data(), vdst, n * sizeof(float4), hipMemcpyDeviceToHost));
         const float *f = (const float *)src;
-        const int ix0 = frame_ix(h, 0), ix1 = frame_ix(h, 1), ix2 = frame_ix(h, 2);   // scene frame -> library frame
+        const int ix0 = h->perm[0], ix1 = h->perm[1], ix2 = h->perm[2];   // scene frame -> library frame
         for (size_t i = 0; i < n; ++i) {
             if (w_only) tmp[i].w = f[i];
             else { tmp[i].x = f[3 * i + ix0]; tmp[i].y = f[3 * i + ix1]; tmp[i].z = f[3 * i + ix2]; }

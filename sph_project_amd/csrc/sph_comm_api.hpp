@@ -194,17 +194,18 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
     if (h->n > 0) return fail(h, SPH_ERR_INVALID, "comm_set_slab: set the slab before particles are appended");
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->comm.slab_ready) {
-        // The slab axis of the SCENE (z: SURVEY 8e, BASELINE configs[3]; SPH_SLAB_AXIS=x|y|z for scenes that are longer another way) becomes
+        // The slab axis of the SCENE (z: SURVEY 8e, BASELINE configs[3]; the layers sph_comm_set_slab counts are its cell layers) becomes
         // the library's x from here on -- see SphHandle::swap_axis.  Nothing has been appended yet; the constants are derived again.
-        const char *ax = getenv("SPH_SLAB_AXIS");
-        const int a = (ax && (ax[0] == 'x' || ax[0] == 'X')) ? 0 : ((ax && (ax[0] == 'y' || ax[0] == 'Y')) ? 1 : 2);
-        if (a != h->swap_axis) {
-            h->swap_axis = a;
-            const int fg = c.force_global;
-            fill_consts(h);
-            c.force_global = fg;
-            refresh_counts(h);
-        }
+        const int a = 2;
+        // library (x, y, z) <- scene (slab axis, then the other two in cyclic order): a proper rotation, and for z-slabs the library's
+        // FASTEST axis becomes the scene's y -- the vertical, along which a column of fluid is contiguous; SPH_AXIS_ORDER overrides
+        // (its first letter must then be the slab axis)
+        static const char *const cyc[3] = {"xyz", "yzx", "zxy"};
+        const char *ord = getenv("SPH_AXIS_ORDER");
+        if (!set_axis_order(h, ord ? ord : cyc[a]) || h->perm[0] != a)
+            return fail(h, SPH_ERR_INVALID, "comm_set_slab: SPH_AXIS_ORDER must be a permutation of xyz that starts with the slab axis z");
+        fill_consts(h);
+        refresh_counts(h);
     }
     if (z_lo < 0 || z_hi > c.nx_glob || z_hi - z_lo < 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: a slab needs >= 2 cell layers inside the grid");
     s.has_down = h->comm.rank > 0; s.has_up = h->comm.rank < h->comm.nranks - 1;
@@ -219,6 +220,10 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
         }
         for (int k = 0; k < 8; ++k) { int rc = dalloc(h, &s.halo_tab[k], cap); if (rc) return rc; }
         { int rc = dalloc(h, &s.halo_counts, 8); if (rc) return rc; }
+        if (!getenv("SPH_NO_SLAB_OVERLAP")) {   // boundary / interior tile lists (State::tile_list)
+            for (int k = 0; k < 2; ++k) { int rc = dalloc(h, &s.tile_list[k], ((size_t)s.cap + 255) / 256 + 1); if (rc) return rc; }
+            int rc = dalloc(h, &s.tile_cnt, 2); if (rc) return rc;
+        }
         { int rc = dalloc(h, &s.dyn, 2); if (rc) return rc; }
         s.dyn_cur = s.dyn;
         HIPCHK(h, hipMalloc((void **)&h->comm.bad_dev, sizeof(int)));
@@ -508,7 +513,7 @@ static int push_setup(SphHandle *h) {
         if (e != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "hipIpcGetMemHandle: %s", hipGetErrorString(e)); (void)hipGetLastError(); }
     }
     if (hipHostMalloc((void **)&s.push.mirror, sizeof(SlabDyn), hipHostMallocDefault) != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "pinned mirror"); (void)hipGetLastError(); }
-    else memset(s.push.mirror, 0, sizeof(SlabDyn));
+    else { memset(s.push.mirror, 0, sizeof(SlabDyn)); s.push.mirror->n_btiles = -1; }
     // handles to the neighbours (even a rank that failed so far takes part: the exchange is collective)
     struct Hello { unsigned magic; int ok; int rank; int inbox_kind; char busid[32]; hipIpcMemHandle_t handle; } hello_out, hello_in[2];
     static_assert(sizeof(Hello) <= 256, "hello message");
@@ -697,7 +702,9 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
         int rc = slab_settle(h); if (rc) return rc;
         s.async_counts = 0; s.c.n_dev = nullptr;
         { ProfScope p(h, SPH_K_HALO);
+          s.classify_part = s.preclassified ? 2 : 0; s.preclassified = 0;
           h->L->halo_classify_pack(s, h->n);
+          s.classify_part = 0;
           h->L->halo_unpack2(s, h->n, 0, 0, c.est_recv + c.est_recv / 4 + 4096); }
         int dev_status = 0;   // every workgroup ORs its verdict into the device word; the mirror carries workgroup 0's only
         HIPCHK(h, hipMemcpyAsync(&dev_status, &s.dyn_cur->status, sizeof(int), hipMemcpyDeviceToHost, s.stream));
@@ -752,7 +759,11 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
     s.async_counts = 1;
     s.c.n = grid_n; s.c.n_dev = &s.dyn_cur->n_live;
     { ProfScope p(h, SPH_K_HALO);
+      // (preclassified: the boundary tiles were classified -- and their records sent -- behind the last step's force pass; the interior
+      //  tiles complete the message: normally nothing but their share of the hash)
+      s.classify_part = s.preclassified ? 2 : 0; s.preclassified = 0;
       h->L->halo_classify_pack(s, grid_n);
+      s.classify_part = 0;
       h->L->halo_unpack2(s, -1, bound_app, bound_live, c.est_recv + c.est_recv / 4 + 4096); }   // (moves dyn_cur to this message's bank)
     h->n = bound_app; refresh_counts(h); s.c.n_dev = &s.dyn_cur->n_app;
     ph_sort_hashed(h);
@@ -860,12 +871,17 @@ static int slab_neighbor_search(SphHandle *h, bool allow_async = false) {
     return SPH_OK;
 }
 
+// grid hint of the field-message kernels (grid-stride: a hint, not a bound)
+static int slab_field_hint(SphHandle *h) {
+    const SlabComm &c = h->comm;
+    return h->n_exact ? c.n_send[0] + c.n_recv[0] + c.n_send[1] + c.n_recv[1] : 2 * c.est_recv + c.est_recv / 2 + 4096;
+}
+
 // field messages over the push transport: pack straight into the neighbours' inboxes (+ message number), wait, scatter
 static int slab_exchange_push(SphHandle *h, int kind, float *f0, float4 *v) {
     State &s = h->st;
-    SlabComm &c = h->comm;
     ProfScope p(h, SPH_K_HALO);
-    const int hint = h->n_exact ? c.n_send[0] + c.n_recv[0] + c.n_send[1] + c.n_recv[1] : 2 * c.est_recv + c.est_recv / 2 + 4096;
+    const int hint = slab_field_hint(h);
     h->L->halo_push_fields(s, kind, f0, v, hint);
     h->L->halo_pull_fields(s, kind, f0, v, hint);
     return SPH_OK;

@@ -71,6 +71,7 @@ struct SlabDyn {
     int longest;     // longest of the four messages (slot tables are reset up to here)
     int status;      // sticky: SLAB_ST_*
     unsigned seq;    // number of the step message these counts belong to
+    int n_btiles;    // pinned mirror only: boundary tiles of the last sort (k_block_prep), sizes the boundary launches of the next steps
     unsigned wseq;   // pinned mirror only: 2 seq + 1 while the settle kernel writes the fields, 2 seq + 2 when they are complete (seqlock)
 };
 struct HaloCtl {            // push transport: header block of one side of a rank's inbox, 256 bytes, written by that neighbour
@@ -176,6 +177,19 @@ struct State {
         long long timeout_ticks;       // bounded waits of the device (100 MHz wall clock)
         SlabDyn *mirror;               // pinned host copy of `dyn`, written by the wait kernel
     } push;
+    // slab sharding, compute / halo overlap: the layers of a slab are contiguous index ranges of the sorted arrays (x is the slowest axis of
+    // the cell order), so the 256-particle tiles fall into a BOUNDARY set (anything within two own layers of a face, plus the ghost layers)
+    // and an INTERIOR set; k_block_prep lists both once per sort.  A pass launched with tile_sel = 1 / 2 walks one set only: boundary
+    // tiles first, their values go out, interior tiles run while the message is in flight.
+    int *tile_list[2];   // [0] boundary tiles, [1] interior tiles (XCD-remapped order), device
+    int *tile_cnt;       // their lengths (2 ints, device)
+    int tile_sel;        // 0: every tile (default); 1: boundary set; 2: interior set -- read by launch_pass
+    int tile_plan_n;     // particle count (launch bound) the lists were built for, -1: none
+    int tile_bound_b;    // workgroups a boundary launch gets: last known number of boundary tiles + margin (checked on the device: SLAB_ST_BOUND)
+    int defer_flip;      // wcsph_forces: launch only, the buffers flip after the second (interior) launch
+    int classify_part;   // halo_classify_pack: 0 = every particle; 1 = boundary tiles, on the buffers the force pass is writing (begins the
+                         // message); 2 = interior tiles (completes the message part 1 began)
+    int preclassified;   // part 1 of the next step's classify has run (behind the boundary tiles of this step's force pass)
     int halo_cap;        // particles per message buffer
     int halo_longest;    // longest halo message of the running step, in particles (sent or received)
     int slab_active, z_lo, z_hi, has_down, has_up;

@@ -691,6 +691,10 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
 #define NBR_BLOCK 256
 
 struct BlockPrepTables { int *tab[8]; };
+// slab sharding: the boundary / interior tile lists of the compute / halo overlap (State::tile_list).  lo_layers / hi_layers = local
+// layers at the low / high end of the slab that belong to the boundary set (ghost layer + two own layers; 0 where the slab has no
+// neighbour on that side).
+struct TilePlanOut { int *list_b, *list_i, *cnt; int lo_layers, hi_layers; int bound_b; int *status; volatile int *mirror_nb; };
 // Lane permutation of a workgroup (256 consecutive sorted particles): particles stably sorted by their x position
 // inside the cell.  The x-offset groups (-1, 0, +1) of the neighbour pass hold very different numbers of accepted
 // neighbours for particles in the low-x and the high-x part of a cell; putting like with like makes the 64 lanes
@@ -699,13 +703,33 @@ struct BlockPrepTables { int *tab[8]; };
 __global__ void __launch_bounds__(256)
 k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restrict__ meta,
              const int *__restrict__ cell_start, int *__restrict__ blk_hdr, unsigned char *__restrict__ perm,
-             int *__restrict__ blk_flag, const int *__restrict__ xidx, BlockPrepTables tabs) {
+             int *__restrict__ blk_flag, const int *__restrict__ xidx, BlockPrepTables tabs, TilePlanOut plan) {
     __shared__ int s_cnt[4][64];
     __shared__ int s_c[2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i0 = blockIdx.x * 256;
     const int i = i0 + tid;
     const int n = live_n(c);
+    if (plan.list_b && tid == 64 && i0 < n) {
+        // which set does this tile belong to?  Interior = entirely inside the particle range [r1, r2) of the layers that are neither
+        // ghost layers nor within two layers of a face; everything else (and every tile of a slab too thin to have such layers) = boundary.
+        const int layer = c.ny * c.nz;
+        const int r1 = plan.lo_layers > 0 ? cell_start[(plan.lo_layers < c.nx ? plan.lo_layers : c.nx) * layer] : 0;
+        const int r2 = plan.hi_layers > 0 ? cell_start[(c.nx - plan.hi_layers > 0 ? c.nx - plan.hi_layers : 0) * layer] : n;
+        const int nt = (n + 255) >> 8;
+        int t1 = (r1 + 255) >> 8, t2 = r2 >> 8;          // interior tiles: [t1, t2)
+        if (t2 > nt) t2 = nt;
+        if (t2 < t1) t2 = t1 = nt;                         // none
+        const int t = (int)blockIdx.x, ni = t2 - t1;
+        if (t < t1) plan.list_b[t] = t;
+        else if (t >= t2) plan.list_b[t1 + (t - t2)] = t;
+        else plan.list_i[t - t1] = t1 + xcd_remap(t - t1, ni);   // slot k holds the k-th tile of an XCD-aware order (bijective)
+        if (t == 0) {
+            plan.cnt[0] = nt - ni; plan.cnt[1] = ni;
+            if (nt - ni > plan.bound_b && plan.status) atomicOr(plan.status, SLAB_ST_BOUND);   // boundary launches of this sort epoch would miss tiles
+            if (plan.mirror_nb) *plan.mirror_nb = nt - ni;
+        }
+    }
     if (i0 >= n) {   // launch bound of an asynchronous slab step: no such tile
         if (blk_flag && tid == 0) blk_flag[blockIdx.x] = 0;
         return;

@@ -90,9 +90,12 @@ __device__ __forceinline__ bool halo_poll(const unsigned *word, unsigned seq, lo
 struct HaloHash { int *cellid, *rank, *cell_count; };
 __global__ void __launch_bounds__(256)
 k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z_lo, int z_hi, int has_down, int has_up, HaloArrays a,
-                float4 *send_down, float4 *send_up, int cap, int *counts, HaloHash hash) {
+                float4 *send_down, float4 *send_up, int cap, int *counts, HaloHash hash, const int *__restrict__ tile_list,
+                const int *__restrict__ tile_count) {
     const int n = n_dev ? *n_dev : n_host;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // tile_list: one set of the slab's tiles only (State::tile_list of the LAST sort: the particles still sit where that sort put them)
+    if (tile_list && (int)blockIdx.x >= *tile_count) return;
+    const int i = (tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x) * 256 + threadIdx.x;
     int side = -1, dead = 0, xi = 0, mnew = 0, mrec = 0;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) {

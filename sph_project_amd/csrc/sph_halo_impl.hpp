@@ -9,17 +9,23 @@ static inline char *inbox_fld(const State &s, char *inbox, int side, unsigned se
 // in place: marks the particles this rank drops, tags the ones a neighbour needs and writes the two messages -- into the
 // local send buffers, or (push transport) straight into the step-message regions of the neighbours' inboxes
 static void l_halo_classify_pack(State &s, int n) {
-    HaloArrays a{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(), s.xidx[s.xcur], s.orig.cur()};
+    // part 1 (State::classify_part) runs between the boundary and the interior launch of the force pass: the new positions and
+    // velocities of the boundary tiles are in the buffers that pass is writing
+    const int part = s.push.on ? s.classify_part : 0;
+    HaloArrays a{part == 1 ? s.posv.alt() : s.posv.cur(), part == 1 ? s.velm.alt() : s.velm.cur(), s.meta.cur(), s.pid.cur(), s.color.cur(),
+                 s.rho.cur(), s.xidx[s.xcur], s.orig.cur()};
     float4 *dst[2] = {s.sendbuf[0], s.sendbuf[1]};
     int *counts = s.halo_counts;
     const int *n_dev = nullptr;
     HaloHash hash{nullptr, nullptr, nullptr};
     if (s.push.on) {
         // this kernel and k_halo_unpack2 are the step's k_hash_count as well (ph_sort_hashed follows instead of ph_neighbor_search)
-        if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 2), s.stream);
-        s.cell_count_clean = 0;
+        if (part != 2) {
+            if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 2), s.stream);
+            s.cell_count_clean = 0;
+        }
         hash = HaloHash{s.cellid, s.rank, s.cell_count};
-        const unsigned seq = ++s.push.rec_seq;
+        const unsigned seq = part == 2 ? s.push.rec_seq : ++s.push.rec_seq;   // part 2 completes the message part 1 began
         for (int side = 0; side < 2; ++side)
             if (s.push.peer[side]) dst[side] = (float4 *)inbox_rec(s, s.push.peer[side], 1 - side, seq);   // I am the neighbour's OTHER side
         counts = s.halo_counts + 4 * (seq & 1u);   // zeroed by the previous step's k_halo_unpack2
@@ -29,8 +35,10 @@ static void l_halo_classify_pack(State &s, int n) {
         hipMemsetAsync(s.halo_counts, 0, 4 * sizeof(int), s.stream);
         if (n <= 0) return;
     }
-    hipLaunchKernelGGL(k_halo_classify, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, n, n_dev, s.z_lo, s.z_hi, s.has_down, s.has_up, a,
-                       dst[0], dst[1], s.push.on ? s.push.rec_cap : s.halo_cap, counts, hash);
+    const int *tl = part ? s.tile_list[part - 1] : nullptr, *tc = part ? s.tile_cnt + (part - 1) : nullptr;
+    const int grid = part == 1 ? (s.tile_bound_b > 0 ? s.tile_bound_b : 1) : cdiv(n, 256);
+    hipLaunchKernelGGL(k_halo_classify, dim3(grid), dim3(256), 0, s.stream, s.c, n, n_dev, s.z_lo, s.z_hi, s.has_down, s.has_up, a,
+                       dst[0], dst[1], s.push.on ? s.push.rec_cap : s.halo_cap, counts, hash, tl, tc);
 }
 
 static int halo_grid(int count_hint) {   // grid-stride kernels: enough workgroups for the hint, at least one, never a huge launch

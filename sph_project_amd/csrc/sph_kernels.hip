@@ -50,8 +50,21 @@ void l_block_prep(State &s) {
     for (int k = 0; k < 8; ++k) tabs.tab[k] = s.halo_tab[k];
     const int *xi = (s.slab_active && s.tables_pending) ? s.xidx[s.xcur] : nullptr;   // push transport: slot tables built here (l_halo_build_tables)
     s.tables_pending = 0;
+    TilePlanOut plan{nullptr, nullptr, nullptr, 0, 0};
+    s.tile_plan_n = -1;
+    if (s.slab_active && s.tile_list[0]) {   // boundary / interior tile lists of this sort (compute / halo overlap)
+        // boundary launches get last sort's number of boundary tiles + a quarter + 64 workgroups (an empty workgroup still costs its LDS /
+        // register allocation: a launch of every tile that mostly exits was measured at +20 us per step)
+        const int nt = cdiv(n, 256);
+        int known = s.push.mirror ? ((volatile SlabDyn *)s.push.mirror)->n_btiles : -1;
+        if (known < 0) known = nt;   // no sort with a plan has finished on the device yet (the mirror starts at -1): every tile
+        s.tile_bound_b = std::min(nt, known + known / 4 + 64);
+        plan = TilePlanOut{s.tile_list[0], s.tile_list[1], s.tile_cnt, s.has_down ? 3 : 0, s.has_up ? 3 : 0, s.tile_bound_b,
+                           s.dyn_cur ? &s.dyn_cur->status : nullptr, s.push.mirror ? &((volatile SlabDyn *)s.push.mirror)->n_btiles : nullptr};
+        s.tile_plan_n = n;
+    }
     hipLaunchKernelGGL(k_block_prep, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.meta.cur(), s.cell_start,
-                       s.blk_hdr, s.lane_perm, lst ? s.blk_flag : nullptr, xi, tabs);
+                       s.blk_hdr, s.lane_perm, lst ? s.blk_flag : nullptr, xi, tabs, plan);
     if (lst) hipLaunchKernelGGL(k_compact_blocks, dim3(1), dim3(256), 0, s.stream, s.blk_flag, cdiv(n, 256), s.blk_list, s.blk_count);   // (tiles past the live count carry flag 0)
     s.list_n = lst ? n : -1;
     s.perm_n = n;
@@ -106,6 +119,11 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     // workgroups without fluid are not launched for functors that have nothing to do there
     const bool use_list = PassFluidOnly<P>::value && !s.c.all_fluid && s.list_n == n && s.c.force_global == 0;
     const int *bl = use_list ? s.blk_list : nullptr, *bc = use_list ? s.blk_count : nullptr;
+    int nb_launch = nb;
+    if (s.tile_sel && s.tile_plan_n == n && !use_list) {   // one set of the slab's tiles only (compute / halo overlap); the grid is a bound
+        bl = s.tile_list[s.tile_sel - 1]; bc = s.tile_cnt + (s.tile_sel - 1);
+        if (s.tile_sel == 1) nb_launch = s.tile_bound_b > 0 ? s.tile_bound_b : 1;
+    }
     if (P::HAS_REDUCE) s.last_pass_listed = use_list ? 1 : 0;   // whose partial sums l_reduce_sum will finish
     unsigned long long *tl = (s.c.force_global == 20 && (size_t)nb * 16 * 8 <= (size_t)s.cap * 4) ? (unsigned long long *)s.tmp_idx : nullptr;
     if (tl) hipMemsetAsync(tl, 0, (size_t)nb * 16 * 8, s.stream);
@@ -116,7 +134,7 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     // debug ("time against resident workgroups"): SPH_DEBUG_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup lower the
     // number of workgroups a CU can hold without touching the code
     static const int extra_lds = getenv("SPH_DEBUG_EXTRA_LDS") ? atoi(getenv("SPH_DEBUG_EXTRA_LDS")) : 0;
-#define SPH_LAUNCH_NBR(M) hipLaunchKernelGGL((k_nbr_pass<P, M>), dim3(nb, gy), dim3(P::BLOCK), extra_lds, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc)
+#define SPH_LAUNCH_NBR(M) hipLaunchKernelGGL((k_nbr_pass<P, M>), dim3(nb_launch, gy), dim3(P::BLOCK), extra_lds, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc)
     if (mask_mode == 1) {
         if constexpr ((MODES & 0b010) != 0) { SPH_LAUNCH_NBR(1); s.masks_valid = 1; }
     } else if (mask_mode == 2) {
@@ -217,6 +235,7 @@ void l_wcsph_forces(State &s) {
         WcsphForcePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0};
         launch_pass(s, p, 2);
     }
+    if (s.defer_flip) return;   // boundary tiles only (tile_sel 1): the interior launch follows, then the buffers flip
     s.velm.flip();
     s.posv.flip();
     s.masks_valid = 0;  // positions moved
