@@ -63,7 +63,18 @@ struct SphHandle {
     int perm[3] = {0, 1, 2};       // library axis k  = scene axis perm[k]
     int inv[3] = {0, 1, 2};        // scene axis k    = library axis inv[k]
     float axial = 1.0f;            // parity of the permutation: sign of axial vectors (torque, angular velocity) across the boundary
+    int slab_axis = 2;             // library axis the slabs are cut along (Consts::slab_axis): 2 = z (default), 0 = x (SPH_SLAB_LAYOUT=slow)
 };
+
+// layers of the whole scene along the slab axis / setting the local window [lo_ghost, top) of a rank
+static inline int slab_layers_glob(const Consts &c) { return c.slab_axis == 0 ? c.nx_glob : c.nz_glob; }
+static inline void slab_set_window(Consts &c, int z_lo, int z_hi) {
+    const int glob = slab_layers_glob(c);
+    const int off = z_lo > 0 ? z_lo - 1 : 0;              // one ghost layer per interior side
+    const int top = z_hi < glob ? z_hi + 1 : glob;
+    if (c.slab_axis == 0) { c.cx_off = off; c.nx = top - off; } else { c.cz_off = off; c.nz = top - off; }
+    c.G = c.nx * c.ny * c.nz;
+}
 
 // "zxy" = library (x, y, z) <- scene (z, x, y)
 static bool set_axis_order(SphHandle *h, const char *order) {
@@ -128,8 +139,9 @@ static void fill_consts(SphHandle *h) {
     Consts &c = h->st.c;
     memset(&c, 0, sizeof(c));
     const int *ix = h->perm;
-    c.nx = c.nx_glob = p.grid_num[ix[0]]; c.ny = p.grid_num[ix[1]]; c.nz = p.grid_num[ix[2]];
-    c.cx_off = 0;
+    c.nx = c.nx_glob = p.grid_num[ix[0]]; c.ny = p.grid_num[ix[1]]; c.nz = c.nz_glob = p.grid_num[ix[2]];
+    c.cx_off = c.cz_off = 0;
+    c.slab_axis = h->slab_axis;
     c.G = c.nx * c.ny * c.nz;
     const double hd = p.support_radius;
     c.grid_size = (float)hd;
@@ -158,6 +170,7 @@ static void fill_consts(SphHandle *h) {
     c.rho0 = (float)p.density_0;
     c.inv_rho0 = 1.0f / c.rho0;
     c.g_upper = (float)p.g_upper;
+    c.up_axis = h->inv[1];
     c.gx = (float)p.gravity[ix[0]]; c.gy = (float)p.gravity[ix[1]]; c.gz = (float)p.gravity[ix[2]];
     c.st = (float)p.surface_tension;
     c.cv = (float)(2 * (3 + 2) * p.viscosity);
@@ -324,9 +337,9 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     memset(&h->last, 0, sizeof(h->last));
     s.has_dynamic_rigid = 0; s.has_rigid = 0;
     s.dyn = s.dyn_cur = nullptr; s.async_counts = 0; s.tables_pending = 0; memset(&s.push, 0, sizeof(s.push));
-    s.tile_list[0] = s.tile_list[1] = nullptr; s.tile_cnt = nullptr; s.tile_sel = 0; s.tile_plan_n = -1;
-    s.tile_bound_b = 0; s.defer_flip = 0; s.classify_part = 0; s.preclassified = 0;
-    s.slab_active = 0; s.xcur = 0; s.halo_cap = 0; s.z_lo = 0; s.z_hi = s.c.nx_glob; s.has_down = s.has_up = 0;
+    s.tile_list[0] = s.tile_list[1] = nullptr; s.tile_cnt = nullptr; s.tile_class = nullptr; s.tile_sel = 0; s.tile_plan_n = -1;
+    s.tile_bound_b = 0; memset(&s.presend, 0, sizeof(s.presend)); memset(&s.fieldsend, 0, sizeof(s.fieldsend)); s.preclassified = 0;
+    s.slab_active = 0; s.xcur = 0; s.halo_cap = 0; s.z_lo = 0; s.z_hi = slab_layers_glob(s.c); s.has_down = s.has_up = 0;
     s.xidx[0] = s.xidx[1] = nullptr; s.halo_counts = nullptr;
     s.visc_rho_raw = (p.method == SPH_METHOD_WCSPH);
     s.skip_viscosity = 0;

@@ -194,20 +194,25 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
     if (h->n > 0) return fail(h, SPH_ERR_INVALID, "comm_set_slab: set the slab before particles are appended");
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->comm.slab_ready) {
-        // The slab axis of the SCENE (z: SURVEY 8e, BASELINE configs[3]; the layers sph_comm_set_slab counts are its cell layers) becomes
-        // the library's x from here on -- see SphHandle::swap_axis.  Nothing has been appended yet; the constants are derived again.
-        const int a = 2;
-        // library (x, y, z) <- scene (slab axis, then the other two in cyclic order): a proper rotation, and for z-slabs the library's
-        // FASTEST axis becomes the scene's y -- the vertical, along which a column of fluid is contiguous; SPH_AXIS_ORDER overrides
-        // (its first letter must then be the slab axis)
-        static const char *const cyc[3] = {"xyz", "yzx", "zxy"};
+        // Which library axis the slabs are cut along (Consts::slab_axis, sph_common.hpp).  Default: z, the scene's own z and the fastest
+        // axis of the cell order -- no permutation.  SPH_SLAB_LAYOUT=slow: the scene's z becomes the library's x, the slowest axis
+        // (library axes = scene z, x, y; SPH_AXIS_ORDER may name another order that starts with z), which is what the boundary-first /
+        // interior-later launches of the compute / halo overlap need.  Nothing has been appended yet; the constants are derived again.
+        const char *lay = getenv("SPH_SLAB_LAYOUT");
+        const bool slow = lay && (lay[0] == 's' || lay[0] == 'S');
         const char *ord = getenv("SPH_AXIS_ORDER");
-        if (!set_axis_order(h, ord ? ord : cyc[a]) || h->perm[0] != a)
-            return fail(h, SPH_ERR_INVALID, "comm_set_slab: SPH_AXIS_ORDER must be a permutation of xyz that starts with the slab axis z");
+        if (slow) {
+            if (!set_axis_order(h, ord ? ord : "zxy") || h->perm[0] != 2)
+                return fail(h, SPH_ERR_INVALID, "comm_set_slab: with SPH_SLAB_LAYOUT=slow, SPH_AXIS_ORDER must be a permutation of xyz that starts with z");
+            h->slab_axis = 0;
+        } else {
+            if (h->perm[2] != 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: SPH_AXIS_ORDER must end with z unless SPH_SLAB_LAYOUT=slow");
+            h->slab_axis = 2;
+        }
         fill_consts(h);
         refresh_counts(h);
     }
-    if (z_lo < 0 || z_hi > c.nx_glob || z_hi - z_lo < 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: a slab needs >= 2 cell layers inside the grid");
+    if (z_lo < 0 || z_hi > slab_layers_glob(c) || z_hi - z_lo < 2) return fail(h, SPH_ERR_INVALID, "comm_set_slab: a slab needs >= 2 cell layers inside the grid");
     s.has_down = h->comm.rank > 0; s.has_up = h->comm.rank < h->comm.nranks - 1;
     bool first = false;
     if (!h->comm.slab_ready) {
@@ -220,17 +225,18 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
         }
         for (int k = 0; k < 8; ++k) { int rc = dalloc(h, &s.halo_tab[k], cap); if (rc) return rc; }
         { int rc = dalloc(h, &s.halo_counts, 8); if (rc) return rc; }
-        if (!getenv("SPH_NO_SLAB_OVERLAP")) {   // boundary / interior tile lists (State::tile_list)
+        if (h->slab_axis == 0 && !getenv("SPH_NO_SLAB_OVERLAP")) {   // boundary / interior tile lists (State::tile_list): slowest-axis slabs only
             for (int k = 0; k < 2; ++k) { int rc = dalloc(h, &s.tile_list[k], ((size_t)s.cap + 255) / 256 + 1); if (rc) return rc; }
             int rc = dalloc(h, &s.tile_cnt, 2); if (rc) return rc;
+            rc = dalloc(h, &s.tile_class, ((size_t)s.cap + 255) / 256 + 1); if (rc) return rc;
         }
         { int rc = dalloc(h, &s.dyn, 2); if (rc) return rc; }
         s.dyn_cur = s.dyn;
         HIPCHK(h, hipMalloc((void **)&h->comm.bad_dev, sizeof(int)));
         HIPCHK(h, hipHostMalloc((void **)&h->comm.n_stage, 16 * sizeof(int), hipHostMallocDefault));
         s.xcur = 0;
-        HIPCHK(h, hipMalloc((void **)&h->comm.hist_dev, sizeof(int) * (size_t)(c.nx_glob + h->comm.nranks)));
-        HIPCHK(h, hipHostMalloc((void **)&h->comm.hist_host, sizeof(int) * (size_t)(c.nx_glob + h->comm.nranks), hipHostMallocDefault));
+        HIPCHK(h, hipMalloc((void **)&h->comm.hist_dev, sizeof(int) * (size_t)(slab_layers_glob(c) + h->comm.nranks)));
+        HIPCHK(h, hipHostMalloc((void **)&h->comm.hist_host, sizeof(int) * (size_t)(slab_layers_glob(c) + h->comm.nranks), hipHostMallocDefault));
         const char *rb = getenv("SPH_SLAB_REBALANCE");
         h->comm.rebalance_every = rb ? atoi(rb) : 64;
         h->comm.slab_ready = 1;
@@ -240,10 +246,7 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
     // the cell lists cover the own layers plus one ghost layer per interior side only: G, and with it the histogram, the
     // scan and the cell windows, shrink from the global grid to the slab (weak scaling would otherwise scan N times as
     // many cells on every rank)
-    c.cx_off = z_lo > 0 ? z_lo - 1 : 0;
-    const int top = z_hi < c.nx_glob ? z_hi + 1 : c.nx_glob;
-    c.nx = top - c.cx_off;
-    c.G = c.nx * c.ny * c.nz;
+    slab_set_window(c, z_lo, z_hi);
     if (first && h->comm.push_wanted) { int rc = push_setup(h); if (rc) return rc; }
     return SPH_OK;
 }
@@ -628,7 +631,7 @@ static int slab_rebalance(SphHandle *h) {
     SlabComm &c = h->comm;
     Consts &k = s.c;
     if (c.nranks < 2) return SPH_OK;
-    const int nz = k.nx_glob, len = nz + c.nranks;   // layers along the slab axis
+    const int nz = slab_layers_glob(k), len = nz + c.nranks;   // layers along the slab axis
     ProfScope p(h, SPH_K_HALO);
     h->L->layer_hist(s, c.hist_dev);
     HIPCHK(h, hipMemsetAsync(c.hist_dev + nz, 0, sizeof(int) * c.nranks, s.stream));
@@ -665,10 +668,7 @@ static int slab_rebalance(SphHandle *h) {
     const int z_lo = next[c.rank], z_hi = next[c.rank + 1];
     c.rebalance_moves += (z_lo != s.z_lo) + (z_hi != s.z_hi);
     s.z_lo = z_lo; s.z_hi = z_hi;
-    k.cx_off = z_lo > 0 ? z_lo - 1 : 0;
-    const int top = z_hi < k.nx_glob ? z_hi + 1 : k.nx_glob;
-    k.nx = top - k.cx_off;
-    k.G = k.nx * k.ny * k.nz;
+    slab_set_window(k, z_lo, z_hi);
     return SPH_OK;
 }
 
@@ -702,9 +702,7 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
         int rc = slab_settle(h); if (rc) return rc;
         s.async_counts = 0; s.c.n_dev = nullptr;
         { ProfScope p(h, SPH_K_HALO);
-          s.classify_part = s.preclassified ? 2 : 0; s.preclassified = 0;
-          h->L->halo_classify_pack(s, h->n);
-          s.classify_part = 0;
+          if (s.preclassified) { s.preclassified = 0; h->L->hash_count(s); } else h->L->halo_classify_pack(s, h->n);
           h->L->halo_unpack2(s, h->n, 0, 0, c.est_recv + c.est_recv / 4 + 4096); }
         int dev_status = 0;   // every workgroup ORs its verdict into the device word; the mirror carries workgroup 0's only
         HIPCHK(h, hipMemcpyAsync(&dev_status, &s.dyn_cur->status, sizeof(int), hipMemcpyDeviceToHost, s.stream));
@@ -759,11 +757,8 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
     s.async_counts = 1;
     s.c.n = grid_n; s.c.n_dev = &s.dyn_cur->n_live;
     { ProfScope p(h, SPH_K_HALO);
-      // (preclassified: the boundary tiles were classified -- and their records sent -- behind the last step's force pass; the interior
-      //  tiles complete the message: normally nothing but their share of the hash)
-      s.classify_part = s.preclassified ? 2 : 0; s.preclassified = 0;
-      h->L->halo_classify_pack(s, grid_n);
-      s.classify_part = 0;
+      // (preclassified: the last step's force pass classified the particles and sent this message's records itself; the hash is left)
+      if (s.preclassified) { s.preclassified = 0; h->L->hash_count(s); } else h->L->halo_classify_pack(s, grid_n);
       h->L->halo_unpack2(s, -1, bound_app, bound_live, c.est_recv + c.est_recv / 4 + 4096); }   // (moves dyn_cur to this message's bank)
     h->n = bound_app; refresh_counts(h); s.c.n_dev = &s.dyn_cur->n_app;
     ph_sort_hashed(h);

@@ -30,16 +30,22 @@
 
 struct Consts {
     int nx, ny, nz, G;      // grid the cell lists are built on (slab sharding: nx = own layers + ghost layers, see cx_off)
-    int nx_glob, cx_off;    // slab sharding cuts the grid along x, the SLOWEST axis of the cell order (lin = (cx ny + cy) nz + cz): a
-                            // rank's ghost / boundary / interior layers are contiguous index ranges of the sorted arrays.  nx_glob =
-                            // layers of the whole scene, cx_off = global layer of local layer 0.  (The scene's slab axis is mapped onto
-                            // this x at the C-ABI boundary: sph_api.hip, SphHandle::swap_axis.)
+    // Slab sharding cuts the grid along ONE library axis (slab_axis) and builds the cell lists on the own layers + ghost layers only:
+    //   slab_axis 2 (default): z, the FASTEST axis of the cell order lin = (cx ny + cy) nz + cz.  The three runs of an x-offset group of a
+    //     thin slab overlap and are staged once (nbr_plan "chain"): at 12-24 layers per rank a step is 20-50 % cheaper than with
+    //   slab_axis 0: x, the SLOWEST axis (the scene's z is mapped onto it at the C-ABI boundary, sph_api.hip set_axis_order): a rank's
+    //     ghost / boundary / interior layers are contiguous index ranges, so boundary tiles can run first and interior ones while the halo
+    //     flies -- built and measured in round 4 (profiles/r04_slab_layouts.txt): the split costs a workgroup lifetime per pass and the
+    //     thin-slab staging advantage is lost; kept behind SPH_SLAB_LAYOUT=slow.
+    // n?_glob = layers of the whole scene along the axis, c?_off = global layer of local layer 0 (0 for the axis that is not cut).
+    int nx_glob, cx_off, nz_glob, cz_off, slab_axis;
     float grid_size;        // f32(dh): cell size
     float h, h2, inv_h;     // support radius, squared, reciprocal (fast build)
     float kW, kG;           // cubic spline constants (base_solver.py:57, :81)
     float W0, Wd;           // kernel_W(0), kernel_W(particle diameter)
     float diameter2;
     float dt, inv_dt, rho0, inv_rho0, g_upper;
+    int up_axis;            // library axis that holds the scene's y (gravitationUpper is a height: base_solver.py:18-23); 1 unless the axes are permuted
     float gx, gy, gz;
     float st;               // surface tension coefficient (0.01)
     float cv, cvb, visc_eps;// 2*(dim+2)*viscosity, ..*viscosity_b, 0.01*dh^2
@@ -103,6 +109,21 @@ struct RigidPose {  // rigid_body_* fields of the container (base_container.py:1
     float com[SPH_NOBJ][3], com0[SPH_NOBJ][3], rot[SPH_NOBJ][9], vel[SPH_NOBJ][3], angvel[SPH_NOBJ][3];
     int   is_dynamic[SPH_NOBJ], material[SPH_NOBJ];
 };
+
+// slab sharding: what a pass needs to classify its own particles and store their records into the neighbours' inboxes (sph_halo_defs.hpp)
+struct HaloSend {
+    int on;                       // 0: the pass leaves the classification to k_halo_classify
+    int z_lo, z_hi, has_down, has_up, cap, rs;
+    float4 *dst[2];               // step-message regions of the neighbours' inboxes for the NEXT message
+    int *counts;                  // its count bank: [0..1] records per side, [2] particles that die
+    int *meta_w, *xidx;           // the particle's meta word (rewritten) and exchange tag
+    const int *pid; const unsigned *color; const float4 *orig;
+};
+
+// ... and what the WCSPH density pass needs to store (rho_raw, rho, p, p / rho^2) of its boundary particles straight into the field
+// message of the neighbours' inboxes (the message k_halo_pack2<2> would gather afterwards): out[side] = that message's region, xidx = the
+// exchange tags of this sort, dyn = this step's counts (the echo part of a message starts behind its n_send records)
+struct HaloFieldSend { int on; float4 *out[2]; const int *xidx; const SlabDyn *dyn; };
 
 template <class T> struct DBuf {
     T *b[2] = {nullptr, nullptr};
@@ -183,13 +204,14 @@ struct State {
     // tiles first, their values go out, interior tiles run while the message is in flight.
     int *tile_list[2];   // [0] boundary tiles, [1] interior tiles (XCD-remapped order), device
     int *tile_cnt;       // their lengths (2 ints, device)
+    unsigned char *tile_class;   // per tile: 1 = boundary set.  The INTERIOR launch is an ordinary launch of every tile (no list: a list costs each
+                                 // workgroup one more dependent load in front of its header) whose boundary tiles leave at once.
     int tile_sel;        // 0: every tile (default); 1: boundary set; 2: interior set -- read by launch_pass
     int tile_plan_n;     // particle count (launch bound) the lists were built for, -1: none
     int tile_bound_b;    // workgroups a boundary launch gets: last known number of boundary tiles + margin (checked on the device: SLAB_ST_BOUND)
-    int defer_flip;      // wcsph_forces: launch only, the buffers flip after the second (interior) launch
-    int classify_part;   // halo_classify_pack: 0 = every particle; 1 = boundary tiles, on the buffers the force pass is writing (begins the
-                         // message); 2 = interior tiles (completes the message part 1 began)
-    int preclassified;   // part 1 of the next step's classify has run (behind the boundary tiles of this step's force pass)
+    HaloSend presend;    // on != 0: the next wcsph_forces launch classifies its particles and sends the next step message itself
+    HaloFieldSend fieldsend;   // on != 0: the next WCSPH density launch stores its boundary values into the field message itself
+    int preclassified;   // ... and has done so: the next step's exchange starts with the hash alone
     int halo_cap;        // particles per message buffer
     int halo_longest;    // longest halo message of the running step, in particles (sent or received)
     int slab_active, z_lo, z_hi, has_down, has_up;
@@ -259,6 +281,8 @@ struct Launch {
     void (*halo_push_fields)(State &, int kind, float *f0, float4 *v, int count_hint);   // pack a field message per neighbour
     void (*halo_pull_fields)(State &, int kind, float *f0, float4 *v, int count_hint);   // announce, wait, scatter the neighbours' field messages
     void (*halo_selftest)(State &, int n, int tag, int tag_down, int tag_up, int *bad_dev);
+    void (*halo_fieldsend_begin)(State &);   // begin a field message of kind 2: the density pass launched next fills it (State::fieldsend)
+    void (*halo_presend_begin)(State &);   // begin the next step message: the force pass launched next fills it (State::presend)
     // implicit viscosity (CG)
     void (*cg_prepare)(State &);
     void (*cg_ap)(State &);

@@ -45,6 +45,9 @@ __device__ __forceinline__ float fsqrt(float a) {
 #endif
 }
 
+// the scene's y of a library-frame position (emitter threshold g_upper)
+__device__ __forceinline__ float up_coord(const Consts &c, const float4 &p) { return c.up_axis == 1 ? p.y : (c.up_axis == 0 ? p.x : p.z); }
+
 // base_container.py:468 pos_to_index, one axis (IEEE division in both builds: cell assignment
 // must agree with the hash kernel), clamped into the grid.
 __device__ __forceinline__ int cell_coord(float x, float gs, int n) {
@@ -54,12 +57,22 @@ __device__ __forceinline__ int cell_coord(float x, float gs, int n) {
     return c;
 }
 
-// x axis: a slab-sharded rank builds its cell lists on its own layers only (local layer = global layer - cx_off); a
-// particle outside them (it is about to be dropped) is clamped onto the nearest local layer.  Unsharded: cx_off = 0, nx = nx_glob.
+// The slab axis (x or z, Consts::slab_axis): a slab-sharded rank builds its cell lists on its own layers only (local layer = global
+// layer - offset); a particle outside them (it is about to be dropped) is clamped onto the nearest local layer.  Unsharded, and for the
+// axis that is not cut: offset 0, n = n_glob.
 __device__ __forceinline__ int cell_coord_x(const Consts &c, float x) {
     int cx = cell_coord(x, c.grid_size, c.nx_glob) - c.cx_off;
     cx = cx < 0 ? 0 : cx;
     return cx > c.nx - 1 ? c.nx - 1 : cx;
+}
+__device__ __forceinline__ int cell_coord_z(const Consts &c, float z) {
+    int cz = cell_coord(z, c.grid_size, c.nz_glob) - c.cz_off;
+    cz = cz < 0 ? 0 : cz;
+    return cz > c.nz - 1 ? c.nz - 1 : cz;
+}
+// global cell layer of a position along the slab axis (compared with the slab bounds z_lo / z_hi)
+__device__ __forceinline__ int slab_layer(const Consts &c, const float4 &p) {
+    return c.slab_axis == 0 ? cell_coord(p.x, c.grid_size, c.nx_glob) : cell_coord(p.z, c.grid_size, c.nz_glob);
 }
 
 // Per-pair geometry shared by kernel_W / kernel_gradient.  Strict build: rn = sqrt(r2), q = rn / h (IEEE).
@@ -183,7 +196,7 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
         const float4 p = posv[i];
         const int cx = cell_coord_x(c, p.x);
         const int cy = cell_coord(p.y, c.grid_size, c.ny);
-        const int cz = cell_coord(p.z, c.grid_size, c.nz);
+        const int cz = cell_coord_z(c, p.z);
         lin = (cx * c.ny + cy) * c.nz + cz;
         if (meta_dead && META_DEAD(meta_dead[i])) lin = c.G;   // slab sharding: graveyard cell behind the grid
         cellid[i] = lin;
@@ -694,7 +707,7 @@ struct BlockPrepTables { int *tab[8]; };
 // slab sharding: the boundary / interior tile lists of the compute / halo overlap (State::tile_list).  lo_layers / hi_layers = local
 // layers at the low / high end of the slab that belong to the boundary set (ghost layer + two own layers; 0 where the slab has no
 // neighbour on that side).
-struct TilePlanOut { int *list_b, *list_i, *cnt; int lo_layers, hi_layers; int bound_b; int *status; volatile int *mirror_nb; };
+struct TilePlanOut { int *list_b, *list_i, *cnt; unsigned char *cls; int lo_layers, hi_layers; int bound_b; int *status; volatile int *mirror_nb; };
 // Lane permutation of a workgroup (256 consecutive sorted particles): particles stably sorted by their x position
 // inside the cell.  The x-offset groups (-1, 0, +1) of the neighbour pass hold very different numbers of accepted
 // neighbours for particles in the low-x and the high-x part of a cell; putting like with like makes the 64 lanes
@@ -724,6 +737,7 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
         if (t < t1) plan.list_b[t] = t;
         else if (t >= t2) plan.list_b[t1 + (t - t2)] = t;
         else plan.list_i[t - t1] = t1 + xcd_remap(t - t1, ni);   // slot k holds the k-th tile of an XCD-aware order (bijective)
+        plan.cls[t] = (t < t1 || t >= t2) ? 1 : 0;
         if (t == 0) {
             plan.cnt[0] = nt - ni; plan.cnt[1] = ni;
             if (nt - ni > plan.bound_b && plan.status) atomicOr(plan.status, SLAB_ST_BOUND);   // boundary launches of this sort epoch would miss tiles
@@ -749,7 +763,7 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
         key = k < 0 ? 0 : (k > 62 ? 62 : k);
         if (tid == 0 || tid == nvalid - 1) {
             const int cy = cell_coord(p.y, c.grid_size, c.ny);
-            const int cz = cell_coord(p.z, c.grid_size, c.nz);
+            const int cz = cell_coord_z(c, p.z);
             const int lin = (cx * c.ny + cy) * c.nz + cz;
             if (tid == 0) s_c[0] = lin;
             if (tid == nvalid - 1) s_c[1] = lin;
@@ -918,7 +932,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
            int nblocks, unsigned *__restrict__ nbr_mask, unsigned *__restrict__ nbr_mask_hi, int mask_stride,
            const int *__restrict__ blk_hdr, const unsigned char *__restrict__ lane_perm,
            unsigned long long *__restrict__ timeline, const int *__restrict__ stop_flag,
-           const int *__restrict__ blk_list, const int *__restrict__ blk_count) {
+           const int *__restrict__ blk_list, const int *__restrict__ blk_count, const unsigned char *__restrict__ tile_skip) {
     if (stop_flag && *stop_flag) return;   // iteration launched past the convergence of a device-controlled loop
     if (blk_list && (int)blockIdx.x >= *blk_count) {   // only the workgroups that hold fluid were listed
         // (a functor whose prologue keeps a solver loop's books gets it run by workgroup (0, 0) even when the list is EMPTY --
@@ -948,6 +962,9 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     if constexpr (PassPrologue<P>::value) { if (!p.prologue(scal)) return; }   // workgroup-uniform
     const int b = blk_list ? blk_list[blockIdx.x] : xcd_remap(blockIdx.x, nblocks);
     const int i0 = b * BLOCK;
+    // slab sharding, interior launch of a pass that ran its boundary tiles first: those leave (the flag is requested here and looked at
+    // behind the prologue's loads, so it adds no round trip of its own)
+    const int skip_tile = tile_skip ? (int)tile_skip[b] : 0;
     const int n_live = live_n(c);
     if (i0 >= n_live) {   // launch bound of an asynchronous slab step: no such tile (its header was never written)
         if constexpr (P::HAS_REDUCE) { if (tid == 0 && !(PassSplit<P>::value && gridDim.y == 3)) p.red_out[b] = 0.0f; }
@@ -1030,7 +1047,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     {
         const int cx = cell_coord_x(c, pi.x);
         const int cy = cell_coord(pi.y, c.grid_size, c.ny);
-        const int cz = cell_coord(pi.z, c.grid_size, c.nz);
+        const int cz = cell_coord_z(c, pi.z);
         const int lin = (cx * c.ny + cy) * c.nz + cz;
         const int z0 = cz > 0 ? cz - 1 : 0;
         const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
@@ -1042,6 +1059,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             if (xx >= 0 && xx < c.nx && yy >= 0 && yy < c.ny) dom |= 1u << k;
         }
     }
+    if (skip_tile) return;   // (uniform)
     if (__syncthreads_or(active ? 1 : 0)) {  // workgroup-uniform; also publishes s_cs
         NBR_STAMP(1);
         unsigned npairs = 0;
@@ -1135,7 +1153,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                         float px = pi.x, py = pi.y, pz = pi.z;
                         asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));   // keeps the recomputation IN this branch (it is loop-invariant: hoisted, it would hold four registers for every workgroup)
                         const int xx = cell_coord_x(c, px) + g - 1, yy = cell_coord(py, c.grid_size, c.ny) + q - 1;
-                        const int cz = cell_coord(pz, c.grid_size, c.nz);
+                        const int cz = cell_coord_z(c, pz);
                         const int z0 = cz > 0 ? cz - 1 : 0;
                         const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
                         const int lin0 = (xx * c.ny + yy) * c.nz + z0;

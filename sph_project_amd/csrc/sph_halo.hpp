@@ -1,9 +1,8 @@
 // sph_halo.hpp -- slab sharding, device side (included inside the per-build namespace).
 //
-// The slab axis is the library's x, the SLOWEST axis of the cell order (the scene's slab axis -- z by contract, SURVEY 8e -- is
-// swapped onto it at the C-ABI boundary): layers are contiguous index ranges of the sorted arrays, which is what lets boundary
-// workgroups run first and interior ones while the halo is in flight.  `z_lo` / `z_hi` keep their names from the API
-// (sph_comm_set_slab): they are LAYER numbers along the slab axis.
+// The slab axis is one of the library's axes (Consts::slab_axis: z, the fastest axis of the cell order, by default; x, the slowest,
+// with SPH_SLAB_LAYOUT=slow -- sph_common.hpp).  `z_lo` / `z_hi` keep their names from the API (sph_comm_set_slab: cell layers of the
+// SCENE's z): here they are layer numbers along the slab axis.
 // Rank r owns the global cell layers [z_lo, z_hi) (>= 2 layers) and keeps one ghost layer per interior
 // side.  Once per step, right before the sort, ONE message per neighbour carries both kinds of
 // records (48 B each: posv, velm, meta|pid|color|rho; 64 B with the rest position when the scene has a dynamic rigid body):
@@ -17,38 +16,7 @@
 // message sizes both sides already know.
 #pragma once
 
-#define HALO_SEND 1        // + side: owned boundary particle exported as ghost, k = index in my message
-#define HALO_GHOST 3       // + side: ghost received, k = index in the neighbour's message
-#define HALO_ECHO_SEND 5   // + side: migrant received into my boundary layer, k = index in the neighbour's message
-#define HALO_ECHO_GHOST 7  // + side: my migrant kept as ghost, k = index in my message
-#define HALO_PACK(kind, idx) (((kind) << 28) | (idx))
-#define HALO_KIND(x) ((int)(((unsigned)(x)) >> 28))
-#define HALO_IDX(x) ((x) & 0x0fffffff)
-#define META_SET_GHOST(m, g) (((m) & ~(1 << 11)) | ((g) << 11))
-
-struct HaloArrays {
-    const float4 *posv, *velm; int *meta; const int *pid; const unsigned *color; const float *rho; int *xidx;
-    const float4 *orig;   // rigid_particle_original_positions, or null: then records are 3 float4 (rs = 3), else 4
-};
-
-__device__ __forceinline__ void halo_write_record(float4 *buf, int rs, int k, const float4 &p, const float4 &v, int meta,
-                                                  int pid, unsigned color, float rho) {
-    buf[rs * k] = p;
-    buf[rs * k + 1] = v;
-    buf[rs * k + 2] = make_float4(__int_as_float(meta), __int_as_float(pid), __uint_as_float(color), rho);
-}
-
-// one atomic per wave and counter: base index of this lane among the lanes with `want`
-__device__ __forceinline__ int halo_wave_slot(bool want, int *counter) {
-    const unsigned long long m = __ballot(want);
-    if (!m) return 0;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(m));
-    base = __shfl(base, leader, 64);
-    return base + __popcll(m & ((1ull << lane) - 1ull));
-}
+// (record kinds, HaloArrays, halo_write_record, halo_wave_slot and the classification rule itself: sph_halo_defs.hpp)
 
 // ---- push transport (sph_comm.hpp): a rank's INBOX is one device allocation that its two neighbours map through hipIpc and
 // write into directly -- no send buffer, no copy engine, no host.  Per side (= which neighbour writes): a control block, two
@@ -90,31 +58,16 @@ __device__ __forceinline__ bool halo_poll(const unsigned *word, unsigned seq, lo
 struct HaloHash { int *cellid, *rank, *cell_count; };
 __global__ void __launch_bounds__(256)
 k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z_lo, int z_hi, int has_down, int has_up, HaloArrays a,
-                float4 *send_down, float4 *send_up, int cap, int *counts, HaloHash hash, const int *__restrict__ tile_list,
-                const int *__restrict__ tile_count) {
+                float4 *send_down, float4 *send_up, int cap, int *counts, HaloHash hash) {
     const int n = n_dev ? *n_dev : n_host;
-    // tile_list: one set of the slab's tiles only (State::tile_list of the LAST sort: the particles still sit where that sort put them)
-    if (tile_list && (int)blockIdx.x >= *tile_count) return;
-    const int i = (tile_list ? tile_list[blockIdx.x] : (int)blockIdx.x) * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     int side = -1, dead = 0, xi = 0, mnew = 0, mrec = 0;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) {
         const int m = a.meta[i];
-        mnew = m;
-        if (META_GHOST(m) || META_DEAD(m)) {   // last step's ghosts are re-sent by their owners
-            dead = 1;
-        } else {
-            p = a.posv[i];
-            const int cz = cell_coord(p.x, c.grid_size, c.nx_glob);   // global layer: compared with the slab bounds
-            if (cz < z_lo && has_down) {           // left through the lower face: ownership moves down
-                side = 0; mrec = META_SET_GHOST(m, 0);
-                if (cz == z_lo - 1) mnew = META_SET_GHOST(m, 1); else dead = 1;   // kept as "echo ghost" / gone
-            } else if (cz >= z_hi && has_up) {
-                side = 1; mrec = META_SET_GHOST(m, 0);
-                if (cz == z_hi) mnew = META_SET_GHOST(m, 1); else dead = 1;
-            } else if (cz == z_lo && has_down) { side = 0; mrec = META_SET_GHOST(m, 1); }
-            else if (cz == z_hi - 1 && has_up) { side = 1; mrec = META_SET_GHOST(m, 1); }
-        }
+        if (!(META_GHOST(m) || META_DEAD(m))) p = a.posv[i];
+        const HaloVerdict vd = halo_classify_one(m, slab_layer(c, p), z_lo, z_hi, has_down, has_up);   // (sph_halo_defs.hpp)
+        side = vd.side; dead = vd.dead; mnew = vd.mnew; mrec = vd.mrec;
     }
     const int k0 = halo_wave_slot(side == 0, &counts[0]);
     const int k1 = halo_wave_slot(side == 1, &counts[1]);
@@ -126,7 +79,7 @@ k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z
             if (dead) lin = c.G;
             else {
                 const float4 q = a.posv[i];
-                lin = (cell_coord_x(c, q.x) * c.ny + cell_coord(q.y, c.grid_size, c.ny)) * c.nz + cell_coord(q.z, c.grid_size, c.nz);
+                lin = (cell_coord_x(c, q.x) * c.ny + cell_coord(q.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, q.z);
             }
             hash.cellid[i] = lin;
         }
@@ -267,13 +220,13 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
         int xi;
         if (META_GHOST(m)) xi = HALO_PACK(HALO_GHOST + side, k);
         else {  // a migrant, now owned here; echo it back if it sits in my boundary layer facing the sender
-            const int cz = cell_coord(p.x, c.grid_size, c.nx_glob);
+            const int cz = slab_layer(c, p);
             const int edge = side == 0 ? z_lo : z_hi - 1;
             xi = cz == edge ? HALO_PACK(HALO_ECHO_SEND + side, k) : 0;
         }
         xidx[d] = xi;
         if (hash.cellid) {   // the arrival's share of this step's k_hash_count
-            const int lin = (cell_coord_x(c, p.x) * c.ny + cell_coord(p.y, c.grid_size, c.ny)) * c.nz + cell_coord(p.z, c.grid_size, c.nz);
+            const int lin = (cell_coord_x(c, p.x) * c.ny + cell_coord(p.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, p.z);
             hash.cellid[d] = lin;
             hash.rank[d] = atomicAdd(&hash.cell_count[lin], 1);
         }
@@ -302,7 +255,7 @@ k_halo_unpack(const Consts c, int count, int offset, int side, int z_lo, int z_h
     int xi;
     if (META_GHOST(m)) xi = HALO_PACK(HALO_GHOST + side, k);
     else {  // a migrant, now owned here; echo it back if it sits in my boundary layer facing the sender
-        const int cz = cell_coord(p.x, c.grid_size, c.nx_glob);
+        const int cz = slab_layer(c, p);
         const int edge = side == 0 ? z_lo : z_hi - 1;
         xi = cz == edge ? HALO_PACK(HALO_ECHO_SEND + side, k) : 0;
     }
@@ -505,7 +458,7 @@ k_layer_hist(const Consts c, int n, const float4 *posv, const int *meta, int *hi
     if (i >= n) return;
     const int m = meta[i];
     if (META_GHOST(m) || META_DEAD(m)) return;
-    atomicAdd(&hist[cell_coord(posv[i].x, c.grid_size, c.nx_glob)], 1);
+    atomicAdd(&hist[slab_layer(c, posv[i])], 1);
 }
 
 // number of ghost copies among the first n particles (sph_comm_get_slab): one atomic per wave

@@ -9,23 +9,17 @@ static inline char *inbox_fld(const State &s, char *inbox, int side, unsigned se
 // in place: marks the particles this rank drops, tags the ones a neighbour needs and writes the two messages -- into the
 // local send buffers, or (push transport) straight into the step-message regions of the neighbours' inboxes
 static void l_halo_classify_pack(State &s, int n) {
-    // part 1 (State::classify_part) runs between the boundary and the interior launch of the force pass: the new positions and
-    // velocities of the boundary tiles are in the buffers that pass is writing
-    const int part = s.push.on ? s.classify_part : 0;
-    HaloArrays a{part == 1 ? s.posv.alt() : s.posv.cur(), part == 1 ? s.velm.alt() : s.velm.cur(), s.meta.cur(), s.pid.cur(), s.color.cur(),
-                 s.rho.cur(), s.xidx[s.xcur], s.orig.cur()};
+    HaloArrays a{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(), s.xidx[s.xcur], s.orig.cur()};
     float4 *dst[2] = {s.sendbuf[0], s.sendbuf[1]};
     int *counts = s.halo_counts;
     const int *n_dev = nullptr;
     HaloHash hash{nullptr, nullptr, nullptr};
     if (s.push.on) {
         // this kernel and k_halo_unpack2 are the step's k_hash_count as well (ph_sort_hashed follows instead of ph_neighbor_search)
-        if (part != 2) {
-            if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 2), s.stream);
-            s.cell_count_clean = 0;
-        }
+        if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 2), s.stream);
+        s.cell_count_clean = 0;
         hash = HaloHash{s.cellid, s.rank, s.cell_count};
-        const unsigned seq = part == 2 ? s.push.rec_seq : ++s.push.rec_seq;   // part 2 completes the message part 1 began
+        const unsigned seq = ++s.push.rec_seq;
         for (int side = 0; side < 2; ++side)
             if (s.push.peer[side]) dst[side] = (float4 *)inbox_rec(s, s.push.peer[side], 1 - side, seq);   // I am the neighbour's OTHER side
         counts = s.halo_counts + 4 * (seq & 1u);   // zeroed by the previous step's k_halo_unpack2
@@ -35,10 +29,23 @@ static void l_halo_classify_pack(State &s, int n) {
         hipMemsetAsync(s.halo_counts, 0, 4 * sizeof(int), s.stream);
         if (n <= 0) return;
     }
-    const int *tl = part ? s.tile_list[part - 1] : nullptr, *tc = part ? s.tile_cnt + (part - 1) : nullptr;
-    const int grid = part == 1 ? (s.tile_bound_b > 0 ? s.tile_bound_b : 1) : cdiv(n, 256);
-    hipLaunchKernelGGL(k_halo_classify, dim3(grid), dim3(256), 0, s.stream, s.c, n, n_dev, s.z_lo, s.z_hi, s.has_down, s.has_up, a,
-                       dst[0], dst[1], s.push.on ? s.push.rec_cap : s.halo_cap, counts, hash, tl, tc);
+    hipLaunchKernelGGL(k_halo_classify, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, n, n_dev, s.z_lo, s.z_hi, s.has_down, s.has_up, a,
+                       dst[0], dst[1], s.push.on ? s.push.rec_cap : s.halo_cap, counts, hash);
+}
+
+// Push transport, fused form of the above (HaloSend, sph_halo_defs.hpp): the NEXT step's message is begun here -- its number, its regions
+// in the neighbours' inboxes, its count bank -- and the force pass about to be launched fills it; the next step's exchange then starts
+// with the hash (l_hash_count) instead of k_halo_classify.
+static void l_halo_presend_begin(State &s) {
+    const unsigned seq = ++s.push.rec_seq;
+    HaloSend &hs = s.presend;
+    hs.on = 1; hs.z_lo = s.z_lo; hs.z_hi = s.z_hi; hs.has_down = s.has_down; hs.has_up = s.has_up;
+    hs.cap = s.push.rec_cap; hs.rs = s.orig.cur() ? 4 : 3;
+    for (int side = 0; side < 2; ++side)
+        hs.dst[side] = s.push.peer[side] ? (float4 *)inbox_rec(s, s.push.peer[side], 1 - side, seq) : s.sendbuf[side];
+    hs.counts = s.halo_counts + 4 * (seq & 1u);   // zeroed by this step's k_halo_unpack2
+    hs.meta_w = s.meta.cur(); hs.xidx = s.xidx[s.xcur];
+    hs.pid = s.pid.cur(); hs.color = s.color.cur(); hs.orig = s.orig.cur();
 }
 
 static int halo_grid(int count_hint) {   // grid-stride kernels: enough workgroups for the hint, at least one, never a huge launch
@@ -103,6 +110,14 @@ static void l_halo_pull_fields(State &s, int kind, float *f0, float4 *v, int cou
     if (kind == 0) hipLaunchKernelGGL(k_halo_unpack2f<0>, g, b, 0, s.stream, a);
     else if (kind == 1) hipLaunchKernelGGL(k_halo_unpack2f<1>, g, b, 0, s.stream, a);
     else hipLaunchKernelGGL(k_halo_unpack2f<2>, g, b, 0, s.stream, a);
+}
+// fused form of l_halo_push_fields(kind 2) (HaloFieldSend, sph_common.hpp): the message is begun here, the WCSPH density pass launched
+// next stores the values where it computes them; l_halo_pull_fields follows as usual
+static void l_halo_fieldsend_begin(State &s) {
+    const unsigned seq = ++s.push.fld_seq;
+    HaloFieldSend &fs = s.fieldsend;
+    fs.on = 1; fs.xidx = s.xidx[s.xcur]; fs.dyn = s.dyn_cur;
+    for (int side = 0; side < 2; ++side) fs.out[side] = s.push.peer[side] ? (float4 *)inbox_fld(s, s.push.peer[side], 1 - side, seq) : nullptr;
 }
 // self-test: my pattern into both neighbours' field regions (as one field message), the handshake, then check theirs
 static void l_halo_selftest(State &s, int n, int tag, int tag_down, int tag_up, int *bad_dev) {
@@ -176,7 +191,7 @@ static void l_loop_criterion(State &s, int slot) {
 }
 
 static void l_layer_hist(State &s, int *hist) {
-    hipMemsetAsync(hist, 0, sizeof(int) * (size_t)s.c.nx_glob, s.stream);
+    hipMemsetAsync(hist, 0, sizeof(int) * (size_t)(s.c.slab_axis == 0 ? s.c.nx_glob : s.c.nz_glob), s.stream);
     if (s.c.n > 0) hipLaunchKernelGGL(k_layer_hist, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.c.n, s.posv.cur(), s.meta.cur(), hist);
 }
 

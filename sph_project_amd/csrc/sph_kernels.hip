@@ -15,6 +15,8 @@
 #include <vector>
 #include <cstdio>
 namespace SPH_NS {
+#include "sph_device.hpp"
+#include "sph_halo_defs.hpp"
 #include "sph_passes.hpp"
 #include "sph_solvers.hpp"
 #include "sph_cg.hpp"
@@ -50,7 +52,7 @@ void l_block_prep(State &s) {
     for (int k = 0; k < 8; ++k) tabs.tab[k] = s.halo_tab[k];
     const int *xi = (s.slab_active && s.tables_pending) ? s.xidx[s.xcur] : nullptr;   // push transport: slot tables built here (l_halo_build_tables)
     s.tables_pending = 0;
-    TilePlanOut plan{nullptr, nullptr, nullptr, 0, 0};
+    TilePlanOut plan{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
     s.tile_plan_n = -1;
     if (s.slab_active && s.tile_list[0]) {   // boundary / interior tile lists of this sort (compute / halo overlap)
         // boundary launches get last sort's number of boundary tiles + a quarter + 64 workgroups (an empty workgroup still costs its LDS /
@@ -59,7 +61,7 @@ void l_block_prep(State &s) {
         int known = s.push.mirror ? ((volatile SlabDyn *)s.push.mirror)->n_btiles : -1;
         if (known < 0) known = nt;   // no sort with a plan has finished on the device yet (the mirror starts at -1): every tile
         s.tile_bound_b = std::min(nt, known + known / 4 + 64);
-        plan = TilePlanOut{s.tile_list[0], s.tile_list[1], s.tile_cnt, s.has_down ? 3 : 0, s.has_up ? 3 : 0, s.tile_bound_b,
+        plan = TilePlanOut{s.tile_list[0], s.tile_list[1], s.tile_cnt, s.tile_class, s.has_down ? 3 : 0, s.has_up ? 3 : 0, s.tile_bound_b,
                            s.dyn_cur ? &s.dyn_cur->status : nullptr, s.push.mirror ? &((volatile SlabDyn *)s.push.mirror)->n_btiles : nullptr};
         s.tile_plan_n = n;
     }
@@ -120,9 +122,10 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     const bool use_list = PassFluidOnly<P>::value && !s.c.all_fluid && s.list_n == n && s.c.force_global == 0;
     const int *bl = use_list ? s.blk_list : nullptr, *bc = use_list ? s.blk_count : nullptr;
     int nb_launch = nb;
-    if (s.tile_sel && s.tile_plan_n == n && !use_list) {   // one set of the slab's tiles only (compute / halo overlap); the grid is a bound
-        bl = s.tile_list[s.tile_sel - 1]; bc = s.tile_cnt + (s.tile_sel - 1);
-        if (s.tile_sel == 1) nb_launch = s.tile_bound_b > 0 ? s.tile_bound_b : 1;
+    const unsigned char *skip = nullptr;
+    if (s.tile_sel && s.tile_plan_n == n && !use_list) {   // one set of the slab's tiles only (compute / halo overlap)
+        if (s.tile_sel == 1) { bl = s.tile_list[0]; bc = s.tile_cnt; nb_launch = s.tile_bound_b > 0 ? s.tile_bound_b : 1; }   // the listed boundary tiles; the grid is a bound
+        else skip = s.tile_class;   // every tile, the boundary ones leave
     }
     if (P::HAS_REDUCE) s.last_pass_listed = use_list ? 1 : 0;   // whose partial sums l_reduce_sum will finish
     unsigned long long *tl = (s.c.force_global == 20 && (size_t)nb * 16 * 8 <= (size_t)s.cap * 4) ? (unsigned long long *)s.tmp_idx : nullptr;
@@ -134,7 +137,7 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     // debug ("time against resident workgroups"): SPH_DEBUG_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup lower the
     // number of workgroups a CU can hold without touching the code
     static const int extra_lds = getenv("SPH_DEBUG_EXTRA_LDS") ? atoi(getenv("SPH_DEBUG_EXTRA_LDS")) : 0;
-#define SPH_LAUNCH_NBR(M) hipLaunchKernelGGL((k_nbr_pass<P, M>), dim3(nb_launch, gy), dim3(P::BLOCK), extra_lds, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc)
+#define SPH_LAUNCH_NBR(M) hipLaunchKernelGGL((k_nbr_pass<P, M>), dim3(nb_launch, gy), dim3(P::BLOCK), extra_lds, s.stream, s.c, s.cell_start, p, s.scal, nb, s.nbr_mask, s.nbr_mask_hi, s.cap, s.blk_hdr, perm, tl, s.loop_flag, bl, bc, skip)
     if (mask_mode == 1) {
         if constexpr ((MODES & 0b010) != 0) { SPH_LAUNCH_NBR(1); s.masks_valid = 1; }
     } else if (mask_mode == 2) {
@@ -169,12 +172,15 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
 }
 
 void l_density(State &s, int eos) {
+    HaloFieldSend fs = s.fieldsend;
+    if (!eos) fs.on = 0;
+    s.fieldsend.on = 0;
     if (s.c.all_fluid) {
-        if (eos) { DensityPass<true, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p, 1); }
-        else { DensityPass<true, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p, 1); }
+        if (eos) { DensityPass<true, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs}; launch_pass(s, p, 1); }
+        else { DensityPass<true, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs}; launch_pass(s, p, 1); }
     } else {
-        if (eos) { DensityPass<false, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p, 1); }
-        else { DensityPass<false, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm}; launch_pass(s, p, 1); }
+        if (eos) { DensityPass<false, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs}; launch_pass(s, p, 1); }
+        else { DensityPass<false, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs}; launch_pass(s, p, 1); }
     }
 }
 
@@ -200,13 +206,13 @@ k_emitter_advance(const Consts c, float4 *posv, const float4 *velm, int *meta, c
     const int m = meta[i];
     if (META_MAT(m) == 1) return;
     float4 p = posv[i];
-    if (p.y > c.g_upper) {
+    if (up_coord(c, p) > c.g_upper) {
         const int obj = META_OBJ(m);
         if (obj >= 0 && pose->material[obj] == 1) {
             const float4 v = velm[i];
             p.x += c.dt * v.x; p.y += c.dt * v.y; p.z += c.dt * v.z;
             posv[i] = p;
-            if (p.y <= c.g_upper) meta[i] = META_SET_MAT(m, 1);
+            if (up_coord(c, p) <= c.g_upper) meta[i] = META_SET_MAT(m, 1);
         }
     }
 }
@@ -229,13 +235,13 @@ void l_pressure_integrate(State &s) {
 // WCSPH.py:30-36, 45 as one pass (see WcsphForcePass); same buffer choreography as the two passes it replaces
 void l_wcsph_forces(State &s) {
     if (s.c.all_fluid) {
-        WcsphForcePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0};
+        WcsphForcePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend};
         launch_pass(s, p, 2);
     } else {
-        WcsphForcePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0};
+        WcsphForcePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend};
         launch_pass(s, p, 2);
     }
-    if (s.defer_flip) return;   // boundary tiles only (tile_sel 1): the interior launch follows, then the buffers flip
+    if (s.presend.on) { s.presend.on = 0; s.preclassified = 1; }
     s.velm.flip();
     s.posv.flip();
     s.masks_valid = 0;  // positions moved
@@ -285,7 +291,7 @@ __global__ void __launch_bounds__(256) k_prepare_emitter(const Consts c, const f
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= live_n(c)) return;
     const int m = meta[i];
-    if (META_MAT(m) == 1 && posv[i].y > c.g_upper) meta[i] = META_SET_MAT(m, 2);
+    if (META_MAT(m) == 1 && up_coord(c, posv[i]) > c.g_upper) meta[i] = META_SET_MAT(m, 2);
 }
 
 void l_prepare_emitter(State &s) {
@@ -306,7 +312,7 @@ k_post_insert(const Consts c, int first, float4 *posv, float4 *velm, const int *
     float4 p = posv[i], v = velm[i];
     if (META_MAT(m) == 1) {
         if (META_DYN(m)) { enforce_boundary(c, p.x, p.y, p.z, v.x, v.y, v.z); posv[i] = p; velm[i] = v; }
-    } else if (stale_volume && META_MAT(m) == 2 && p.y <= c.g_upper) {
+    } else if (stale_volume && META_MAT(m) == 2 && up_coord(c, p) <= c.g_upper) {
         const float V = 1.0f / c.W0;
         p.w = V; v.w = c.rho0 * V;
         posv[i] = p; velm[i] = v;
@@ -356,7 +362,7 @@ const Launch *SPH_LAUNCH_FN() {
         L.halo_pack_vel = l_halo_pack_vel; L.halo_unpack_vel = l_halo_unpack_vel;
         L.loop_criterion = l_loop_criterion;
         L.halo_unpack2 = l_halo_unpack2; L.halo_push_fields = l_halo_push_fields;
-        L.halo_pull_fields = l_halo_pull_fields; L.halo_selftest = l_halo_selftest;
+        L.halo_pull_fields = l_halo_pull_fields; L.halo_selftest = l_halo_selftest; L.halo_presend_begin = l_halo_presend_begin; L.halo_fieldsend_begin = l_halo_fieldsend_begin;
         L.layer_hist = l_layer_hist;
         L.count_ghosts = l_count_ghosts;
         init = true;

@@ -28,6 +28,7 @@ struct DensityPass {
     struct Own { float sum; };
     const float4 *posv; const int *meta;
     float *rho_raw, *rho, *prs, *ptm;
+    HaloFieldSend fs;   // slab sharding (EOS form only): boundary values go straight into the neighbours' field message; fs.on = 0 otherwise
 
     __device__ float4 loadA(int j) const { return posv[j]; }
     __device__ BT loadB(int) const { return 0; }
@@ -56,7 +57,16 @@ struct DensityPass {
             float pr = 50000.0f * (powf(rc / c.rho0, 7.0f) - 1.0f);
 #endif
             prs[i] = pr;
-            ptm[i] = pr / (rc * rc);
+            const float pt = pr / (rc * rc);
+            ptm[i] = pt;
+            if (fs.on) {   // (uniform) layout of a field message: [ my n_send records | the records I received from that side ], k_halo_pack2
+                const int x = fs.xidx[i], kind = HALO_KIND(x), k = HALO_IDX(x);
+                if (kind == HALO_SEND || kind == HALO_SEND + 1) { if (fs.out[kind - HALO_SEND]) fs.out[kind - HALO_SEND][k] = make_float4(den, rc, pr, pt); }
+                else if (kind == HALO_ECHO_SEND || kind == HALO_ECHO_SEND + 1) {
+                    const int side = kind - HALO_ECHO_SEND;
+                    if (fs.out[side]) fs.out[side][fs.dyn->n_send[side] + k] = make_float4(den, rc, pr, pt);
+                }
+            }
         } else {
             rho[i] = den;
         }
@@ -286,6 +296,7 @@ struct WcsphForcePass {
     };
     const float4 *posv, *velm; const int *meta; const float *rho_raw, *ptm, *prs, *rho;
     float4 *vel_out, *acc, *posv_out; DevScalars *scal; const RigidPose *pose; float rho0;
+    HaloSend hs;   // slab sharding: classify + send the next step message from here (sph_halo_defs.hpp); hs.on = 0 otherwise
 
     __device__ float4 loadA(int j) const { return posv[j]; }
     __device__ float4 stage(const Consts &, int j, BT &bj, CT &cj) const {
@@ -379,6 +390,7 @@ struct WcsphForcePass {
             vel_out[i] = make_float4(vx, vy, vz, o.m);
             acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             posv_out[i] = pi;
+            if (hs.on) halo_presend(c, hs, i, pi, make_float4(vx, vy, vz, o.m), rho[i]);
             return 0.0f;
         }
         // pressure update, advection, boundary (:136, :643, :652, :575)
@@ -388,12 +400,15 @@ struct WcsphForcePass {
         enforce_boundary(c, x, y, z, vx, vy, vz);
         posv_out[i] = make_float4(x, y, z, pi.w);
         vel_out[i] = make_float4(vx, vy, vz, o.m);
+        if (hs.on) halo_presend(c, hs, i, make_float4(x, y, z, pi.w), make_float4(vx, vy, vz, o.m), rho[i]);
         return 0.0f;
     }
-    __device__ void passive(const Consts &, int i, const float4 &pi) const {
-        vel_out[i] = velm[i];
+    __device__ void passive(const Consts &c, int i, const float4 &pi) const {
+        const float4 v = velm[i];
+        vel_out[i] = v;
         acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         posv_out[i] = pi;
+        if (hs.on) halo_presend(c, hs, i, pi, v, rho[i]);   // (last step's ghosts die here; a static particle in a boundary layer is copied)
     }
 };
 
@@ -421,7 +436,7 @@ struct RigidVolumePass {
     __device__ float4 stage(const Consts &, int j, BT &) const { return stage_impl(j); }
     __device__ bool begin(const Consts &c, int i, const float4 &pi, Own &o) const {
         const int m = meta[i];
-        if (META_MAT(m) != 2 || META_GHOST(m) || META_FRESH(m) || !(pi.y <= c.g_upper)) return false;
+        if (META_MAT(m) != 2 || META_GHOST(m) || META_FRESH(m) || !(up_coord(c, pi) <= c.g_upper)) return false;
         o.obj = META_OBJ(m);
         o.sum = c.W0;
         return true;

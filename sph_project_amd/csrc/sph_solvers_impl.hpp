@@ -13,11 +13,11 @@ k_advect_boundary(const Consts c, float4 *posv, float4 *velm, int *meta, const R
         p.x += c.dt * v.x; p.y += c.dt * v.y; p.z += c.dt * v.z;
         if (META_DYN(m)) enforce_boundary(c, p.x, p.y, p.z, v.x, v.y, v.z);
         posv[i] = p; velm[i] = v;
-    } else if (p.y > c.g_upper) {  // emitter branch :660-666
+    } else if (up_coord(c, p) > c.g_upper) {  // emitter branch :660-666
         const int obj = META_OBJ(m);
         if (obj >= 0 && pose->material[obj] == 1) {
             p.x += c.dt * v.x; p.y += c.dt * v.y; p.z += c.dt * v.z;
-            if (p.y <= c.g_upper) {
+            if (up_coord(c, p) <= c.g_upper) {
                 meta[i] = META_SET_MAT(m, 1);
                 if (META_DYN(m)) enforce_boundary(c, p.x, p.y, p.z, v.x, v.y, v.z);
                 velm[i] = v;

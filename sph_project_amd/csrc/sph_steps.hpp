@@ -71,7 +71,7 @@ static int wcsph_step(SphHandle *h) {
     // Sharded over the push transport, fluid only: the density pass runs the slab's BOUNDARY tiles first, their rho / p go out to the
     // neighbours, and the INTERIOR tiles (everything more than two layers from a face) run while that message is in flight; only
     // then does the stream wait for the neighbours' (SURVEY 8e "compute interior cells while halos are in flight").
-    const bool overlap = s.slab_active && s.push.on && s.tile_list[0] && s.c.all_fluid && s.tile_plan_n == s.c.n;
+    const bool overlap = s.slab_active && s.push.on && s.tile_list[0] && s.c.all_fluid && s.tile_plan_n == s.c.n && (s.has_down || s.has_up);
     if (overlap) {
         const int hint = slab_field_hint(h);
         s.tile_sel = 1;
@@ -81,29 +81,27 @@ static int wcsph_step(SphHandle *h) {
         { ProfScope p(h, SPH_K_DENSITY); h->L->density(s, 1); }
         s.tile_sel = 0;
         { ProfScope p(h, SPH_K_HALO); h->L->halo_pull_fields(s, 2, nullptr, nullptr, hint); }
+    } else if (s.slab_active && s.push.on && !getenv("SPH_NO_SLAB_FUSED_FIELDS")) {
+        // ghost rho, p: the density pass stores the values of its boundary particles straight into the neighbours' field message
+        // (HaloFieldSend) -- no gather kernel, and the message travels while the pass is still running; then the usual wait + scatter
+        const int hint = slab_field_hint(h);
+        h->L->halo_fieldsend_begin(s);
+        { ProfScope p(h, SPH_K_DENSITY); h->L->density(s, 1); }               // :29 + :33 (EOS fused)
+        { ProfScope p(h, SPH_K_HALO); h->L->halo_pull_fields(s, 2, nullptr, nullptr, hint); }
     } else {
         { ProfScope p(h, SPH_K_DENSITY); h->L->density(s, 1); }               // :29 + :33 (EOS fused)
         if (s.slab_active) { int rc = slab_exchange_fields(h); if (rc) return rc; }   // ghost rho, p
     }
     if (!h->prm.viscosity_implicit && !getenv("SPH_NO_FUSED_FORCES")) {
-        // Another step of this call follows (sph_step_async(n)) and nothing on the host happens in between: the force pass runs the
-        // boundary tiles first, the NEXT step's classify takes those tiles at once -- their migrants and boundary copies travel to the
-        // neighbours while the interior tiles are still being computed -- and the next step only completes the message.  Not before a
-        // step that re-plans the cuts (the layers change hands there).
+        // Another step of this call follows (sph_step_async(n)) and nothing on the host happens in between: the force pass classifies its
+        // own particles and stores the NEXT step's message into the neighbours' inboxes as its workgroups finish (HaloSend,
+        // sph_halo_defs.hpp) -- the records travel while the pass is still running, and the next step starts with the hash alone.  Not
+        // with an emitter or rigid bodies (they move particles after this pass) and not before a step that re-plans the cuts.
         const SlabComm &cm = h->comm;
         const bool rebalance_next = cm.rebalance_every > 0 && (h->steps + 1) % cm.rebalance_every == 0 && !h->any_rigid_object;
-        const bool pre = overlap && s.async_counts && h->steps_to_follow > 0 && !rebalance_next && s.tile_plan_n == s.c.n && !getenv("SPH_NO_SLAB_PRESEND");
-        if (pre) {
-            s.tile_sel = 1; s.defer_flip = 1;
-            { ProfScope p(h, SPH_K_WCSPH_FORCES); h->L->wcsph_forces(s); }
-            s.classify_part = 1;
-            { ProfScope p(h, SPH_K_HALO); h->L->halo_classify_pack(s, s.c.n); }
-            s.classify_part = 0; s.preclassified = 1;
-            s.tile_sel = 2; s.defer_flip = 0;
-            { ProfScope p(h, SPH_K_WCSPH_FORCES); h->L->wcsph_forces(s); }
-            s.tile_sel = 0;
-            return SPH_OK;
-        }
+        if (s.slab_active && s.push.on && h->steps_to_follow > 0 && !rebalance_next && !s.has_emitter && !h->any_rigid_object &&
+            !h->sort_dirty && !getenv("SPH_NO_SLAB_PRESEND"))
+            h->L->halo_presend_begin(s);
         ProfScope p(h, SPH_K_WCSPH_FORCES); h->L->wcsph_forces(s);            // :30-31 + :34-36, :45 in one neighbour walk
         return SPH_OK;
     }
