@@ -471,8 +471,8 @@ extern "C" int sph_get_rigid_wrench(SphHandle *h, float *force, float *torque, i
     for (int o = 0; o < SPH_NOBJ; ++o)
         for (int a = 0; a < 3; ++a) {
             const int b = h->inv[a];
-            force[3 * o + a] = h->scal_h->wrench[3 * o + b];
-            torque[3 * o + a] = h->axial * h->scal_h->wrench[SPH_NOBJ * 3 + 3 * o + b];
+            force[3 * o + a] = (float)((double)h->scal_h->wrench[3 * o + b] / SPH_WRENCH_SCALE);
+            torque[3 * o + a] = h->axial * (float)((double)h->scal_h->wrench[SPH_NOBJ * 3 + 3 * o + b] / SPH_WRENCH_SCALE);
         }
     if (h->st.slab_active && h->comm.nranks > 1) {
         // sharded scene: every rank holds the contributions of ITS fluid particles (SURVEY 8e "rigid coupling under sharding");
@@ -484,7 +484,7 @@ extern "C" int sph_get_rigid_wrench(SphHandle *h, float *force, float *torque, i
         for (int k = 0; k < SPH_NOBJ * 3; ++k) { force[k] = (float)w[k]; torque[k] = (float)w[SPH_NOBJ * 3 + k]; }
     }
     if (reset)
-        HIPCHK(h, hipMemsetAsync((char *)h->st.scal + offsetof(DevScalars, wrench), 0, sizeof(float) * 2 * SPH_NOBJ * 3, h->st.stream));
+        HIPCHK(h, hipMemsetAsync((char *)h->st.scal + offsetof(DevScalars, wrench), 0, sizeof(long long) * 2 * SPH_NOBJ * 3, h->st.stream));
     return SPH_OK;
 }
 

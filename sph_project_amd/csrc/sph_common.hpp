@@ -100,7 +100,11 @@ struct DevScalars {
     unsigned long long pairs[2][SPH_STAT_SLOTS];     // accepted pairs of a step weighted by the reference passes a walk stands for (sum over slots)
     unsigned long long evals[2][SPH_STAT_SLOTS];     // accepted pairs as evaluated (one per neighbour walk); separate 64-bit words: no carry between the two tallies
     unsigned long long fallback[2][SPH_STAT_SLOTS];  // neighbour runs that did not fit the LDS tile
-    float wrench[2 * SPH_NOBJ * 3];  // rigid_body_forces, rigid_body_torques
+    // rigid_body_forces, rigid_body_torques (base_container.py:161-162) as 64-bit FIXED POINT, 2^-32 N (N m) per unit: integer atomics
+    // commute, so the accumulated wrench is bit-reproducible from run to run whatever order the workgroups finish in (the reference's f32
+    // atomics -- and this code until round 3 -- are not); range +-2.1e9, resolution 2.3e-10.  Written by add_wrench (sph_passes.hpp).
+    long long wrench[2 * SPH_NOBJ * 3];
+#define SPH_WRENCH_SCALE 4294967296.0
     float red[8];                    // reduction results (errors, CG dots)
     int   flags[4];
 };

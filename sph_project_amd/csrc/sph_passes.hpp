@@ -4,12 +4,39 @@
 #pragma once
 #include "sph_device.hpp"
 
+// Force / torque of one fluid -- dynamic-rigid pair onto the body's accumulators (base_solver.py:174-187, :272-278; DFSPH.py:173-203).
+// Called from inside the pair loop by whichever lanes of the wave met such a neighbour in this trip.  Until round 3: six f32 atomicAdd per
+// pair and lane onto the SAME six words -- the pattern that once pinned a pass at 280 us (lessons) and made the wrench depend on
+// the order the workgroups finished in.  Now: the lanes that are here together and push on the same body (the usual case: one body nearby)
+// add their six components up in a fixed tree over the lanes -- the lanes that are NOT here are masked out, their registers hold stale
+// values -- and one lane converts the sums to 64-bit fixed point (DevScalars::wrench) and issues the six atomics: 64 x fewer atomics, and
+// integer addition commutes, so the result does not depend on any order.  Lanes that disagree about the body each add their own.
 __device__ __forceinline__ void add_wrench(DevScalars *scal, int obj, float fx, float fy, float fz,
                                            float tx, float ty, float tz) {
-    float *f = scal->wrench + obj * 3;
-    float *t = scal->wrench + SPH_NOBJ * 3 + obj * 3;
-    atomicAdd(f + 0, fx); atomicAdd(f + 1, fy); atomicAdd(f + 2, fz);
-    atomicAdd(t + 0, tx); atomicAdd(t + 1, ty); atomicAdd(t + 2, tz);
+    const unsigned long long act = __ballot(1);   // the lanes executing this call
+    const int lane = threadIdx.x & 63;
+    const int first = __ffsll((long long)act) - 1;
+    const bool same = __ballot(obj == __shfl(obj, first, 64)) == act;
+    float v[6] = {fx, fy, fz, tx, ty, tz};
+    if (same) {
+        // sum over the lanes that are here, ascending (a wave-uniform loop over the set bits: v_readlane + add per lane and component --
+        // a shuffle tree would need the absent lanes to forward partial sums)
+        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (unsigned long long m = act; m; m &= m - 1ull) {
+            const int src = __ffsll((long long)m) - 1;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) s[q] += __shfl(v[q], src, 64);
+        }
+        if (lane != first) return;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] = s[q];
+    }
+    long long *f = scal->wrench + obj * 3, *t = scal->wrench + SPH_NOBJ * 3 + obj * 3;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        atomicAdd((unsigned long long *)(f + q), (unsigned long long)__double2ll_rn((double)v[q] * SPH_WRENCH_SCALE));
+        atomicAdd((unsigned long long *)(t + q), (unsigned long long)__double2ll_rn((double)v[3 + q] * SPH_WRENCH_SCALE));
+    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -129,3 +129,73 @@ def test_mesh_rigid_and_fluid_bodies_from_obj(gpu, tmp_path):
     fluid = np.setdiff1d(np.arange(len(x)), rigid_ids)
     assert x[fluid, 1].min() > 0.2 - 0.5 * 0.02                            # nothing leaked through the slab top (y = 0.2)
     assert x[fluid, 1].mean() < x0[fluid, 1].mean()                        # and the block has come down onto it
+
+
+def _engine_with_plate(cfg, plate, dynamic):
+    """Fluid of `cfg` + a plate of rigid particles (object 1) under it, appended by hand like test_dynamic_rigid_wrench_and_pose."""
+    c = H.SimConfig(config=cfg)
+    geo, sol = scene.derive_geometry(c), scene.derive_solver_constants(c)
+    container, solver = H.build_product(cfg, jitter=0.002, seed=5)
+    e = container.engine
+    n_f, n_r = e.particle_num, plate.shape[0]
+    pd = scene.params_dict(geo, sol, "wcsph", n_f + n_r)
+    p = L.SphParams()
+    for k in ("particle_radius", "support_radius", "V0", "padding", "g_upper", "viscosity", "viscosity_b", "density_0",
+              "surface_tension", "dt", "particle_max_num", "viscosity_implicit"):
+        setattr(p, k, pd[k])
+    p.domain_size[:] = pd["domain_size"]; p.grid_num[:] = pd["grid_num"]; p.gravity[:] = pd["gravity"]
+    p.method = L.METHOD["wcsph"]; p.device = -1; p.deterministic = 1; p.fast_math = 1
+    eng = L.Engine(p)
+    fpos, fvel = e.download(L.F_POSITION), e.download(L.F_VELOCITY)
+    eng.set_object(0, 1, 0)
+    eng.append_particles(0, fpos, fvel, np.full(n_f, 1000.0, np.float32), np.zeros(n_f, np.float32), np.ones(n_f, np.int32),
+                         np.ones(n_f, np.int32), np.zeros((n_f, 3), np.int32))
+    eng.set_object(1, 2, 1 if dynamic else 0)
+    eng.append_particles(1, plate, np.zeros((n_r, 3), np.float32), np.full(n_r, 2200.0, np.float32), np.zeros(n_r, np.float32),
+                         np.full(n_r, 2, np.int32), np.full(n_r, 1 if dynamic else 0, np.int32), np.zeros((n_r, 3), np.int32))
+    com = plate.mean(0)
+    eng.set_rigid_pose(1, com, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32), com0=com)
+    eng.prepare()
+    container.engine.close()
+    return eng, n_f
+
+
+def test_wrench_is_bit_reproducible_and_cheap(gpu):
+    """the wrench onto a dynamic body used to be six f32 atomicAdd per fluid-rigid pair onto the same six words -- order-
+    dependent and serialised.  add_wrench (csrc/sph_passes.hpp) now sums over the lanes of a wave in a fixed order and accumulates in
+    64-bit fixed point: (1) two runs of the same scene give the SAME bits, step after step; (2) a scene with > 100 k fluid -- dynamic-rigid
+    pairs per step costs no more than the same scene with the plate declared static (no wrench at all) + 15 %."""
+    import time
+    cfg = H.dam_break_scene(domain_end=(1.6, 0.8, 1.6), start=(0.1, 0.1, 0.1), end=(1.36, 0.3, 1.36), translation=(0, 0, 0),
+                            particleSpacing=0.019, viscosity_b=0.4, velocity=(0.0, -0.2, 0.0))
+    ax = 0.08 + 0.02 * np.arange(66)
+    plate = np.ascontiguousarray(np.stack(np.meshgrid(ax, [0.06, 0.08], ax, indexing="ij"), -1).reshape(-1, 3), dtype=np.float32)   # right under the block
+    runs = []
+    for rep in range(2):
+        eng, n_f = _engine_with_plate(cfg, plate, dynamic=True)
+        hist = []
+        for _ in range(6):
+            eng.step(1)
+            f, t = eng.get_rigid_wrench(reset=False)
+            hist.append(np.concatenate([f[1], t[1]]).copy())
+        runs.append((eng, np.array(hist)))
+    assert np.abs(runs[0][1]).max() > 0
+    assert np.array_equal(runs[0][1].view(np.uint32), runs[1][1].view(np.uint32)), (runs[0][1], runs[1][1])
+    eng_dyn = runs[0][0]
+    runs[1][0].close()
+    eng_sta, _ = _engine_with_plate(cfg, plate, dynamic=False)
+
+    def ms_per_step(e, k=60):
+        e.step_async(10); e.synchronize()
+        t0 = time.perf_counter(); e.step_async(k); e.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / k
+    t_sta = min(ms_per_step(eng_sta) for _ in range(2))
+    t_dyn = min(ms_per_step(eng_dyn) for _ in range(2))
+    # pairs with the plate: fluid particles within the support of a plate particle
+    pos, mat = eng_dyn.download(L.F_POSITION), eng_dyn.download(L.F_MATERIAL)
+    near = int(((mat == 1) & (pos[:, 1] < 0.08 + 0.04)).sum())
+    print("wrench: %d fluid particles (%d within the plate's support, ~%d fluid-rigid pairs per pass), %.4f ms/step dynamic vs %.4f static plate" % (
+        n_f, near, near * 12, t_dyn, t_sta))
+    assert near * 12 > 100000
+    assert t_dyn <= 1.15 * t_sta + 0.01, (t_dyn, t_sta)
+    eng_dyn.close(); eng_sta.close()
