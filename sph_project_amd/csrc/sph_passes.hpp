@@ -6,37 +6,39 @@
 
 // Force / torque of one fluid -- dynamic-rigid pair onto the body's accumulators (base_solver.py:174-187, :272-278; DFSPH.py:173-203).
 // Called from inside the pair loop by whichever lanes of the wave met such a neighbour in this trip.  Until round 3: six f32 atomicAdd per
-// pair and lane onto the SAME six words -- the pattern that once pinned a pass at 280 us (lessons) and made the wrench depend on
-// the order the workgroups finished in.  Now: the lanes that are here together and push on the same body (the usual case: one body nearby)
-// add their six components up in a fixed tree over the lanes -- the lanes that are NOT here are masked out, their registers hold stale
-// values -- and one lane converts the sums to 64-bit fixed point (DevScalars::wrench) and issues the six atomics: 64 x fewer atomics, and
-// integer addition commutes, so the result does not depend on any order.  Lanes that disagree about the body each add their own.
-__device__ __forceinline__ void add_wrench(DevScalars *scal, int obj, float fx, float fy, float fz,
-                                           float tx, float ty, float tz) {
-    const unsigned long long act = __ballot(1);   // the lanes executing this call
-    const int lane = threadIdx.x & 63;
-    const int first = __ffsll((long long)act) - 1;
-    const bool same = __ballot(obj == __shfl(obj, first, 64)) == act;
-    float v[6] = {fx, fy, fz, tx, ty, tz};
-    if (same) {
-        // sum over the lanes that are here, ascending (a wave-uniform loop over the set bits: v_readlane + add per lane and component --
-        // a shuffle tree would need the absent lanes to forward partial sums)
-        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (unsigned long long m = act; m; m &= m - 1ull) {
-            const int src = __ffsll((long long)m) - 1;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) s[q] += __shfl(v[q], src, 64);
-        }
-        if (lane != first) return;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) v[q] = s[q];
-    }
-    long long *f = scal->wrench + obj * 3, *t = scal->wrench + SPH_NOBJ * 3 + obj * 3;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        atomicAdd((unsigned long long *)(f + q), (unsigned long long)__double2ll_rn((double)v[q] * SPH_WRENCH_SCALE));
-        atomicAdd((unsigned long long *)(t + q), (unsigned long long)__double2ll_rn((double)v[3 + q] * SPH_WRENCH_SCALE));
-    }
+// pair and lane onto the SAME six words of global memory.  Same-address atomics are served one at a time (~0.1 us each): a plate under a
+// 50 k-particle block, 10^5 fluid-rigid pairs per pass, took a 0.09 ms step to 0.8 ms and more -- and the f32 sums depended on the order
+// the workgroups finished in.  Now every WAVE owns a row of six floats per body in LDS (4 waves x 20 bodies x 24 B = 1.9 KB):
+//   * a pair is six ds_add_f32 onto the wave's own row -- nothing else in the pair loop (summing over the lanes in registers first, or
+//     flushing from inside the loop, cost the rigid-aware passes 10-50 spilled VGPRs);
+//   * behind the pair loops (wrench_flush_all) the four rows of a body are added up in a fixed order and go out as six 64-bit
+//     FIXED-POINT atomics per body and workgroup (DevScalars::wrench).  Integer addition commutes, and the lanes of ONE ds_add_f32 are
+//     served in an order that depends on the instruction's lanes and addresses, not on timing: the wrench is bit-reproducible from run
+//     to run (tests/test_hip_rigid.py::test_wrench_is_bit_reproducible_and_cheap).
+typedef float WrenchRows[4][SPH_NOBJ][6];
+__device__ __forceinline__ WrenchRows &wrench_rows() {
+    __shared__ WrenchRows s_rows;   // (one instance per kernel: every caller gets the same array)
+    return s_rows;
+}
+// start of a workgroup (every thread, before the first barrier) / behind the pair loops (every thread, behind a barrier)
+__device__ __forceinline__ void wrench_init_all() {
+    float *r = &wrench_rows()[0][0][0];
+    for (int k = threadIdx.x; k < 4 * SPH_NOBJ * 6; k += 256) r[k] = 0.0f;
+}
+__device__ __forceinline__ void wrench_flush_all(DevScalars *scal) {
+    const int k = threadIdx.x;   // (body, component)
+    if (k >= SPH_NOBJ * 6) return;
+    const WrenchRows &w = wrench_rows();
+    const int obj = k / 6, q = k % 6;
+    const float v = ((w[0][obj][q] + w[1][obj][q]) + w[2][obj][q]) + w[3][obj][q];
+    if (v != 0.0f)
+        atomicAdd((unsigned long long *)(scal->wrench + (q < 3 ? 0 : SPH_NOBJ * 3) + obj * 3 + q % 3),
+                  (unsigned long long)__double2ll_rn((double)v * SPH_WRENCH_SCALE));
+}
+__device__ __forceinline__ void add_wrench(DevScalars *, int obj, float fx, float fy, float fz, float tx, float ty, float tz) {
+    float *r = wrench_rows()[threadIdx.x >> 6][obj];
+    atomicAdd(r + 0, fx); atomicAdd(r + 1, fy); atomicAdd(r + 2, fz);
+    atomicAdd(r + 3, tx); atomicAdd(r + 4, ty); atomicAdd(r + 5, tz);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -108,6 +110,7 @@ struct DensityPass {
 // Bytes / particle: R posv 16 + velm 16 + rho_raw 4 -> W velm 16.
 template <bool AF>
 struct NonPressurePass {
+    static constexpr bool HAS_WRENCH = !AF;   // pair() may call add_wrench: k_nbr_pass opens / flushes the per-wave rows
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
@@ -224,6 +227,7 @@ __device__ __forceinline__ void enforce_boundary(const Consts &c, float &x, floa
 // Bytes / particle: R posv 16 + velm 16 + ptm 4 -> W acc 16 + posv 16 + velm 16.
 template <bool AF>
 struct PressurePass {
+    static constexpr bool HAS_WRENCH = !AF;
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true;
@@ -305,6 +309,7 @@ struct PressurePass {
 // Bytes / particle: R posv 16 + velm 16 + rho_raw 4 + ptm 4 (+ own prs, rho 8) -> W acc 16 + posv 16 + velm 16.
 template <bool AF>
 struct WcsphForcePass {
+    static constexpr bool HAS_WRENCH = !AF;
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, HAS_C = true, COUNT_PAIRS = true;

@@ -181,6 +181,7 @@ struct DfsphRhoAdvPass {
 // Bytes / particle: R posv 16 + kappa 4 + rho 4 + velm 16 -> W velm 16.
 template <bool AF, int MODE>
 struct DfsphCorrectPass {
+    static constexpr bool HAS_WRENCH = !AF;           // pair() may call add_wrench (sph_passes.hpp)
     static constexpr bool FLUID_BLOCKS_ONLY = true;   // active for fluid only, passive() empty
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
