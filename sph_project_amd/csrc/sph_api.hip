@@ -297,7 +297,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.nbr_mask = nullptr; s.masks_valid = 0;
     s.nbr_mask_hi = nullptr;
     if (!getenv("SPH_NO_MASK_REUSE")) { CHK_CREATE(dalloc(h, &s.nbr_mask, cap * 9 + 256)); CHK_CREATE(dalloc(h, &s.nbr_mask_hi, cap * 9 + 256)); }   // + 256: the lanes past the last particle of the last tile read (and drop) a word too
-    s.lane_perm = nullptr; s.perm_n = -1; s.perm_lanes = 0;
+    s.lane_perm = nullptr; s.perm_n = -1;
     s.loop_flag = nullptr; s.loop_slot = 0; s.loop_kind = 0; s.loop_denom = 1.0f; s.loop_thr = 0.0;
     CHK_CREATE(dalloc(h, &s.blk_hdr, (cap + 255) / 256 * 20));
     s.blk_flag = s.blk_list = s.blk_count = nullptr; s.list_n = -1; s.last_pass_listed = 0;

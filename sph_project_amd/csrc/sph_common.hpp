@@ -234,7 +234,6 @@ struct State {
     int last_pass_listed;      // the last pass with a reduction ran the listed workgroups only: so must the sum of its partials
     int *blk_hdr;              // [ceil(cap / 256)][BLK_HDR_INTS]: cell span and candidate-run windows of every workgroup
     int perm_n;                // particle count blk_hdr / lane_perm were built for (-1: none)
-    int perm_lanes;            // lane_perm belongs to the current headers (0: they came out of the scatter, which builds none)
     int has_emitter;     // gravitationUpper set (base_solver.py:18-23)
     int visc_rho_raw;    // viscosity reads rho_raw (WCSPH: density before the EOS clamp)
     int skip_viscosity;  // implicit viscosity: explicit term not part of the fused pass

@@ -183,30 +183,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ------------------------------------------------------------------ grid build
-// base_container.py:546 PrefixSumExecutor.run -- here an exclusive scan into cell_start[0..G]: the hash kernels add every particle to
-// the sum of its 2048-cell scan tile as well (round 4: what a launch of its own, k_scan_reduce, used to add up from the histogram), and
-// ONE launch rescans the tiles (k_scan_final: each adds up the tile sums before it).
-#define SCAN_TPB 256
-#define SCAN_IPT 8
-#define SCAN_TILE (SCAN_TPB * SCAN_IPT)
-#define SCAN_TILE_SHIFT 11
-// one atomic per run of lanes whose cells lie in the same scan tile (the input is the last step's sorted order: one or two runs per wave)
-__device__ __forceinline__ void hash_tile_sums(int lin, bool valid, int *__restrict__ tile_sum) {
-    const int lane = threadIdx.x & 63;
-    const int tl = valid ? (lin >> SCAN_TILE_SHIFT) : -1 - lane;
-    const int prev = __shfl_up(tl, 1, 64);
-    const bool head = lane == 0 || tl != prev;
-    const unsigned long long hm = __ballot(head);
-    const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
-    const int len = above ? __ffsll(above) : 64 - lane;
-    if (head && valid) atomicAdd(&tile_sum[tl], len);
-}
-
 // base_container.py:496 init_grid: cell id + histogram.  The atomic's return value is the
 // particle's arrival rank inside its cell, which replaces the second atomic pass of :515.
 __global__ void __launch_bounds__(256)
 k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ cellid,
-             int *__restrict__ rank, int *__restrict__ cell_count, const int *__restrict__ meta_dead, int *__restrict__ tile_sum) {
+             int *__restrict__ rank, int *__restrict__ cell_count, const int *__restrict__ meta_dead) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = i < live_n(c);
@@ -233,9 +214,13 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
     if (head && valid) base = atomicAdd(&cell_count[lin], len);
     base = __shfl(base, hl, 64);
     if (valid) rank[i] = base + (lane - hl);
-    hash_tile_sums(lin, valid, tile_sum);
 }
 
+// base_container.py:546 PrefixSumExecutor.run -- here an exclusive scan into cell_start[0..G],
+// two launches: tile sums, then tile rescans (each adds up the tile sums before it).
+#define SCAN_TPB 256
+#define SCAN_IPT 8
+#define SCAN_TILE (SCAN_TPB * SCAN_IPT)
 
 __device__ __forceinline__ int block_excl_scan_256(int v, int *s_w, int &total) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -263,6 +248,19 @@ __device__ __forceinline__ int4 scan_load4(const int *__restrict__ in, int idx, 
     if (idx + 3 < n) v = *reinterpret_cast<const int4 *>(in + idx);
     else { if (idx < n) v.x = in[idx]; if (idx + 1 < n) v.y = in[idx + 1]; if (idx + 2 < n) v.z = in[idx + 2]; }
     return v;
+}
+
+__global__ void __launch_bounds__(SCAN_TPB)
+k_scan_reduce(const int *__restrict__ in, int n, int *__restrict__ partial) {
+    __shared__ int s_w[SCAN_TPB / 64];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+    const int4 a = scan_load4(in, base, n), b = scan_load4(in, base + SCAN_TILE / 2, n);
+    int s = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
 __global__ void __launch_bounds__(SCAN_TPB)
@@ -315,12 +313,8 @@ k_scatter_index(int n, const int *__restrict__ cellid, const int *__restrict__ r
     tmp_idx[cell_start[cellid[i]] + rank[i]] = i;
 }
 
-// Per-workgroup header of the neighbour passes (written by k_block_prep or, for fluid-only unsharded scenes, by k_scatter):
-#define BLK_HDR_INTS 20   // [0] first cell, [1] last cell, [2..10] run start, [11..19] run END (length = end - start, <= 0: no such run)
 struct SortArrays {
     int G;   // number of grid cells (cell id G = graveyard of the slab sharding)
-    int *blk_hdr;   // non-null: the scatter also writes the per-workgroup headers of the neighbour passes (see k_scatter)
-    int ny_nz, nz;  // cell strides of the x and y offsets
     const float4 *posv_in, *velm_in, *orig_in;
     const int *meta_in, *pid_in;
     const unsigned *color_in;
@@ -337,11 +331,8 @@ struct SortArrays {
 template <bool STABLE>
 __global__ void __launch_bounds__(256)
 k_scatter(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
-          const int *__restrict__ cell_start, const int *__restrict__ tmp_idx, SortArrays a, const int *__restrict__ n_dev,
-          int *__restrict__ tile_sum, int n_tiles) {
+          const int *__restrict__ cell_start, const int *__restrict__ tmp_idx, SortArrays a, const int *__restrict__ n_dev) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    // the scan is done with the tile sums of this sort: cleared here for the next hash (every launch that hashes is followed by this one)
-    for (int k = i; k < n_tiles; k += (int)gridDim.x * 256) tile_sum[k] = 0;
     if (n_dev) n = *n_dev;
     if (i >= n) return;
     int cell = cellid[i];
@@ -355,25 +346,6 @@ k_scatter(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
         r = rank[i];
     }
     int d = s + r;
-    if (a.blk_hdr) {
-        // Per-workgroup header of the neighbour passes (what k_block_prep computes from the sorted arrays in a launch of its own): the
-        // thread that places the FIRST particle of a 256-particle tile knows the tile's first cell and with it where its nine candidate
-        // runs start; the one that places the LAST particle (of the tile, or of all) knows the last cell and where they end.  Fluid-only,
-        // unsharded scenes run without the lane permutation (time-neutral at rest, +1 % in motion: profiles/r04_sort_fusion.txt), so this
-        // replaces the whole launch.  An invalid window gets start 2^30 - 1 (length = end - start < 0: no run) or end 0.
-        const bool first = (d & 255) == 0, last = (d & 255) == 255 || d == n - 1;
-        if (first || last) {
-            int *h = a.blk_hdr + (size_t)(d >> 8) * BLK_HDR_INTS;
-            h[first ? 0 : 1] = cell;
-            if (first && last) h[1] = cell;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int shift = (k / 3 - 1) * a.ny_nz + (k % 3 - 1) * a.nz;
-                if (first) { const int lo = cell + shift - 1; h[2 + k] = lo > a.G - 1 ? 0x3fffffff : cell_start[lo < 0 ? 0 : lo]; }
-                if (last) { const int hi = cell + shift + 1; h[11 + k] = hi < 0 ? 0 : cell_start[(hi > a.G - 1 ? a.G - 1 : hi) + 1]; }
-            }
-        }
-    }
     a.posv_out[d] = a.posv_in[i];
     a.velm_out[d] = a.velm_in[i];
     a.meta_out[d] = a.meta_in[i];
@@ -475,7 +447,7 @@ template <class P> constexpr bool pass_mask_pipe() { return PassMaskPipe<P>::val
 // flushes them behind its pair loops (sph_passes.hpp)
 template <class P, class = void> struct PassWrench { static constexpr bool value = false; };
 template <class P> struct PassWrench<P, decltype((void)P::HAS_WRENCH)> { static constexpr bool value = P::HAS_WRENCH; };
-__device__ __forceinline__ void wrench_init_all();
+__device__ __forceinline__ void wrench_init_all(const RigidPose *pose);
 __device__ __forceinline__ void wrench_flush_all(DevScalars *scal);
 template <class P, class = void> struct PassPrologue { static constexpr bool value = false; };
 template <class P> struct PassPrologue<P, decltype((void)P::HAS_PROLOGUE)> { static constexpr bool value = P::HAS_PROLOGUE; };
@@ -732,6 +704,7 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
 
 // Per-workgroup data prepared once per sort (k_block_prep), read by every neighbour pass of the sort epoch:
 // header = cells of the first / last particle + the 9 candidate-run windows (start, length); lane permutation.
+#define BLK_HDR_INTS 20   // [0] first cell, [1] last cell, [2..10] run start, [11..19] run length
 #define NBR_CS_SPAN 124   // cell_start window cached in LDS per run: cells [first-1, last+1] (+ end) of the workgroup
 #define NBR_CS_PITCH (NBR_CS_SPAN + 4)
 #define NBR_BLOCK 256
@@ -832,7 +805,7 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
         int *h = blk_hdr + (size_t)blockIdx.x * BLK_HDR_INTS;
         if (tid == 0) { h[0] = cfirst; h[1] = clast; }
         h[2 + tid] = rs;
-        h[11 + tid] = re;
+        h[11 + tid] = re - rs;
     }
     __syncthreads();
     if (perm) {
@@ -908,7 +881,7 @@ __device__ __forceinline__ void nbr_plan(const int *__restrict__ hdr, int g, int
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         rs_[q] = hdr[2 + g * 3 + q];
-        ln_[q] = hdr[11 + g * 3 + q] > rs_[q] ? hdr[11 + g * 3 + q] - rs_[q] : 0;
+        ln_[q] = hdr[11 + g * 3 + q] > 0 ? hdr[11 + g * 3 + q] : 0;
     }
     // Thin grids (nz <= the workgroup's cell span + 2: small scenes, and the slabs of a sharded scene -- C4 on 8 ranks has 12
     // layers per rank): the three runs of a group are windows of one and the same stretch of the sorted arrays, nz cells apart,
@@ -992,7 +965,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
 
     const int tid = threadIdx.x;
     NBR_STAMP(0);
-    if constexpr (PassWrench<P>::value) wrench_init_all();   // (published by the prologue's barrier)
+    if constexpr (PassWrench<P>::value) wrench_init_all(p.pose);   // (published by the prologue's barrier)
     if constexpr (PassPrologue<P>::value) { if (!p.prologue(scal)) return; }   // workgroup-uniform
     const int b = blk_list ? blk_list[blockIdx.x] : xcd_remap(blockIdx.x, nblocks);
     const int i0 = b * BLOCK;
@@ -1015,7 +988,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     const int span = clast - cfirst;
     bool cs_lds = span >= 0 && span <= NBR_CS_SPAN;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) cs_lds = cs_lds && hdr[11 + k] - hdr[2 + k] < 65536;   // windows are cached as 16-bit offsets
+    for (int k = 0; k < 9; ++k) cs_lds = cs_lds && hdr[11 + k] < 65536;   // windows are cached as 16-bit offsets
     // In flight together, behind the one dependent load above (the lane permutation): own particle and what begin() reads of it,
     // the first staging round, the cell_start windows.  Straight-line code on a clamped index: a load inside a divergent `if (valid)`
     // gets an `s_waitcnt vmcnt(0)` at the end of its block (the merge of its result), which used to serialise the prologue into
@@ -1331,7 +1304,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             qa = qb;
             if (qa >= RPG) { qa = 0; ++g; }
         }
-        if constexpr (PassWrench<P>::value) { __syncthreads(); wrench_flush_all(scal); }   // every wave its own row: 6 atomics per wave that touched a body
+        if constexpr (PassWrench<P>::value) { __syncthreads(); wrench_flush_all(scal); }   // six atomics per body and workgroup that touched it
         if (P::COUNT_PAIRS) {
             float fp = wave_sum((float)npairs);  // <= 64 * few hundred: exact in f32
             if ((tid & 63) == 0 && fp > 0.0f) {

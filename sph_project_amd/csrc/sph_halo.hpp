@@ -55,7 +55,7 @@ __device__ __forceinline__ bool halo_poll(const unsigned *word, unsigned seq, lo
 // hash != null (push transport): the kernel is also this step's k_hash_count for the particles that are here already (cell id,
 // histogram, arrival rank; the dead ones into the graveyard cell G) -- both read the same positions, and the arrivals are hashed
 // by k_halo_unpack2 when they land.
-struct HaloHash { int *cellid, *rank, *cell_count, *tile_sum; };
+struct HaloHash { int *cellid, *rank, *cell_count; };
 __global__ void __launch_bounds__(256)
 k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z_lo, int z_hi, int has_down, int has_up, HaloArrays a,
                 float4 *send_down, float4 *send_up, int cap, int *counts, HaloHash hash) {
@@ -94,7 +94,6 @@ k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z
         if (head && i < n) base = atomicAdd(&hash.cell_count[lin], len);
         base = __shfl(base, hl, 64);
         if (i < n) hash.rank[i] = base + (lane - hl);
-        hash_tile_sums(lin, i < n, hash.tile_sum);
     }
     if (i >= n) return;
     if (side >= 0) {
@@ -207,36 +206,30 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
     const int r0 = s_v[0], r1 = s_v[1], n_old = s_v[2];
     const int rs = orig ? 4 : 3;
     const int stride = (int)(gridDim.x * 256);
-    for (int q0 = blockIdx.x * 256; q0 < r0 + r1; q0 += stride) {   // (workgroup-uniform trips: the tile sums below are wave-aggregated)
-        const int q = q0 + threadIdx.x;
-        const bool valid = q < r0 + r1;
-        int lin = 0;
-        if (valid) {
-            const int side = q < r0 ? 0 : 1;
-            const int k = side ? q - r0 : q;
-            const float4 *recv = w.recv[side];
-            const float4 p = recv[rs * k];
-            const float4 v4 = recv[rs * k + 2];
-            const int m = __float_as_int(v4.x);
-            const int d = n_old + q;
-            posv[d] = p; velm[d] = recv[rs * k + 1];
-            if (orig) orig[d] = recv[rs * k + 3];
-            meta[d] = m; pid[d] = __float_as_int(v4.y); color[d] = __float_as_uint(v4.z); rho[d] = v4.w;
-            int xi;
-            if (META_GHOST(m)) xi = HALO_PACK(HALO_GHOST + side, k);
-            else {  // a migrant, now owned here; echo it back if it sits in my boundary layer facing the sender
-                const int cz = slab_layer(c, p);
-                const int edge = side == 0 ? z_lo : z_hi - 1;
-                xi = cz == edge ? HALO_PACK(HALO_ECHO_SEND + side, k) : 0;
-            }
-            xidx[d] = xi;
-            if (hash.cellid) {   // the arrival's share of this step's k_hash_count
-                lin = (cell_coord_x(c, p.x) * c.ny + cell_coord(p.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, p.z);
-                hash.cellid[d] = lin;
-                hash.rank[d] = atomicAdd(&hash.cell_count[lin], 1);
-            }
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < r0 + r1; q += stride) {
+        const int side = q < r0 ? 0 : 1;
+        const int k = side ? q - r0 : q;
+        const float4 *recv = w.recv[side];
+        const float4 p = recv[rs * k];
+        const float4 v4 = recv[rs * k + 2];
+        const int m = __float_as_int(v4.x);
+        const int d = n_old + q;
+        posv[d] = p; velm[d] = recv[rs * k + 1];
+        if (orig) orig[d] = recv[rs * k + 3];
+        meta[d] = m; pid[d] = __float_as_int(v4.y); color[d] = __float_as_uint(v4.z); rho[d] = v4.w;
+        int xi;
+        if (META_GHOST(m)) xi = HALO_PACK(HALO_GHOST + side, k);
+        else {  // a migrant, now owned here; echo it back if it sits in my boundary layer facing the sender
+            const int cz = slab_layer(c, p);
+            const int edge = side == 0 ? z_lo : z_hi - 1;
+            xi = cz == edge ? HALO_PACK(HALO_ECHO_SEND + side, k) : 0;
         }
-        if (hash.cellid) hash_tile_sums(lin, valid, hash.tile_sum);   // (records arrive in the sender's sorted order: one or two scan tiles per wave)
+        xidx[d] = xi;
+        if (hash.cellid) {   // the arrival's share of this step's k_hash_count
+            const int lin = (cell_coord_x(c, p.x) * c.ny + cell_coord(p.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, p.z);
+            hash.cellid[d] = lin;
+            hash.rank[d] = atomicAdd(&hash.cell_count[lin], 1);
+        }
     }
     const int longest = s_v[3];
     for (int k = blockIdx.x * 256 + threadIdx.x; k < longest; k += stride) {

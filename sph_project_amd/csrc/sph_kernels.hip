@@ -26,21 +26,18 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 void l_hash_count(State &s) {
     const int n = s.c.n;
-    if (!s.cell_count_clean) {   // (a hash that was never followed by its scan + scatter: both accumulators start over)
-        hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 2), s.stream);
-        hipMemsetAsync(s.scan_partial, 0, sizeof(int) * (size_t)s.scan_blocks, s.stream);
-    }
+    if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 2), s.stream);
     s.cell_count_clean = 0;
     if (n == 0) return;
     hipLaunchKernelGGL(k_hash_count, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.cellid,
-                       s.rank, s.cell_count, s.slab_active ? s.meta.cur() : nullptr, s.scan_partial);
+                       s.rank, s.cell_count, s.slab_active ? s.meta.cur() : nullptr);
 }
 
 void l_scan(State &s) {
     const int G = s.c.G + (s.slab_active ? 1 : 0);   // + graveyard cell
     int nb = cdiv(G, SCAN_TILE);                      // <= s.scan_blocks (sized for the global grid)
     if (nb < SPH_STAT_SLOTS / SCAN_TPB) nb = SPH_STAT_SLOTS / SCAN_TPB;   // k_scan_final also clears the statistics slots
-    // (tile sums: accumulated by the hash kernels -- k_hash_count, k_halo_classify, k_halo_unpack2 -- and cleared again by k_scatter)
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial,
                        s.cell_start, s.c.n, s.scal, 1 - s.c.stat_bank, s.c.n_dev);
     s.cell_count_clean = 1;
@@ -73,7 +70,6 @@ void l_block_prep(State &s) {
     if (lst) hipLaunchKernelGGL(k_compact_blocks, dim3(1), dim3(256), 0, s.stream, s.blk_flag, cdiv(n, 256), s.blk_list, s.blk_count);   // (tiles past the live count carry flag 0)
     s.list_n = lst ? n : -1;
     s.perm_n = n;
-    s.perm_lanes = s.lane_perm ? 1 : 0;
 }
 
 void l_scatter_impl(State &s, bool stable) {
@@ -81,11 +77,6 @@ void l_scatter_impl(State &s, bool stable) {
     if (n == 0) return;
     SortArrays a;
     a.G = s.c.G;
-    // fluid-only, unsharded: the headers of the neighbour passes come out of the scatter itself and the passes run without the lane
-    // permutation -- no k_block_prep launch (SPH_KEEP_BLOCK_PREP=1: the round-3 pipeline, for A/B)
-    static const bool keep_prep = getenv("SPH_KEEP_BLOCK_PREP") != nullptr;
-    const bool fused_hdr = s.c.all_fluid && !s.slab_active && !keep_prep;
-    a.blk_hdr = fused_hdr ? s.blk_hdr : nullptr; a.ny_nz = s.c.ny * s.c.nz; a.nz = s.c.nz;
     a.posv_in = s.posv.cur(); a.posv_out = s.posv.alt();
     a.velm_in = s.velm.cur(); a.velm_out = s.velm.alt();
     a.meta_in = s.meta.cur(); a.meta_out = s.meta.alt();
@@ -99,16 +90,15 @@ void l_scatter_impl(State &s, bool stable) {
         hipLaunchKernelGGL(k_scatter_index, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
                            s.cell_start, s.tmp_idx, s.c.n_dev);
         hipLaunchKernelGGL(k_scatter<true>, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
-                           s.cell_start, s.tmp_idx, a, s.c.n_dev, s.scan_partial, s.scan_blocks);
+                           s.cell_start, s.tmp_idx, a, s.c.n_dev);
     } else {
         hipLaunchKernelGGL(k_scatter<false>, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
-                           s.cell_start, s.tmp_idx, a, s.c.n_dev, s.scan_partial, s.scan_blocks);
+                           s.cell_start, s.tmp_idx, a, s.c.n_dev);
     }
     (void)tmp_idx;
     s.posv.flip(); s.velm.flip(); s.meta.flip(); s.pid.flip(); s.color.flip(); s.rho.flip();
     s.masks_valid = 0;  // new order, new candidate runs
-    if (fused_hdr) { s.perm_n = n; s.list_n = -1; s.perm_lanes = 0; }
-    else if (!s.slab_active) l_block_prep(s);
+    if (!s.slab_active) l_block_prep(s);
     else s.perm_n = s.list_n = -1;   // slab sharding: rebuilt once the dead particles behind the live ones are dropped (launch_pass)
     if (s.orig.cur()) s.orig.flip();
     if (s.slab_active) s.xcur = 1 - s.xcur;
@@ -127,7 +117,7 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     // neighbouring lanes on neighbouring cells, which is what makes its LDS reads conflict-free
     if (s.perm_n != n) l_block_prep(s);   // particles were appended since the last sort
     if (!(PassModes<P>::value & (1 << mask_mode))) mask_mode = 0;
-    const unsigned char *perm = (mask_mode == 2 && s.lane_perm && s.perm_lanes) ? s.lane_perm : nullptr;
+    const unsigned char *perm = (mask_mode == 2 && s.lane_perm) ? s.lane_perm : nullptr;
     // workgroups without fluid are not launched for functors that have nothing to do there
     const bool use_list = PassFluidOnly<P>::value && !s.c.all_fluid && s.list_n == n && s.c.force_global == 0;
     const int *bl = use_list ? s.blk_list : nullptr, *bc = use_list ? s.blk_count : nullptr;

@@ -20,10 +20,18 @@ __device__ __forceinline__ WrenchRows &wrench_rows() {
     __shared__ WrenchRows s_rows;   // (one instance per kernel: every caller gets the same array)
     return s_rows;
 }
+// the bodies' centres of mass (rigid_body_centers_of_mass, the reference point of the torques), copied into LDS once per workgroup: the
+// pair loop read them from global memory behind the neighbour's meta word -- two dependent round trips per fluid-rigid pair
+typedef float WrenchCom[SPH_NOBJ][3];
+__device__ __forceinline__ WrenchCom &wrench_com() {
+    __shared__ WrenchCom s_com;
+    return s_com;
+}
 // start of a workgroup (every thread, before the first barrier) / behind the pair loops (every thread, behind a barrier)
-__device__ __forceinline__ void wrench_init_all() {
+__device__ __forceinline__ void wrench_init_all(const RigidPose *pose) {
     float *r = &wrench_rows()[0][0][0];
     for (int k = threadIdx.x; k < 4 * SPH_NOBJ * 6; k += 256) r[k] = 0.0f;
+    if (threadIdx.x < SPH_NOBJ * 3) (&wrench_com()[0][0])[threadIdx.x] = (&pose->com[0][0])[threadIdx.x];
 }
 __device__ __forceinline__ void wrench_flush_all(DevScalars *scal) {
     const int k = threadIdx.x;   // (body, component)
@@ -136,7 +144,7 @@ struct NonPressurePass {
             const int m = meta[j];
             const bool fl = META_MAT(m) == 1;
             aw = fl ? v.w : rho0 * p.w;
-            bw = fl ? rho_raw[j] : (META_DYN(m) ? -2.0f : -1.0f);
+            bw = fl ? rho_raw[j] : (META_DYN(m) ? -2.0f - (float)META_OBJ(m) : -1.0f);   // dynamic rigid: the body rides along (no meta load in the pair loop)
         }
         bj = make_float4(v.x, v.y, v.z, bw);
         return make_float4(p.x, p.y, p.z, aw);
@@ -181,10 +189,10 @@ struct NonPressurePass {
             const float cc = fdiv2(c.cvb * a.w, o.rho, rn2 + c.visc_eps) * v_xy;
             const float acx = cc * gx, acy = cc * gy, acz = cc * gz;
             o.ax += acx; o.ay += acy; o.az += acz;
-            if (bj.w == -2.0f) {  // dynamic rigid neighbour: base_solver.py:272-278
-                const int obj = META_OBJ(meta[j]);
+            if (bj.w <= -2.0f) {  // dynamic rigid neighbour: base_solver.py:272-278
+                const int obj = (int)(-bj.w) - 2;
                 const float fx = fdiv(-acx * o.m, c.rho0), fy = fdiv(-acy * o.m, c.rho0), fz = fdiv(-acz * o.m, c.rho0);
-                const float rx = a.x - pose->com[obj][0], ry = a.y - pose->com[obj][1], rz = a.z - pose->com[obj][2];
+                const float rx = a.x - wrench_com()[obj][0], ry = a.y - wrench_com()[obj][1], rz = a.z - wrench_com()[obj][2];
                 add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
             }
         }
@@ -246,7 +254,7 @@ struct PressurePass {
         if (AF) { bj = ptm[j]; return make_float4(p.x, p.y, p.z, m); }
         const int mt = meta[j];
         const bool fl = META_MAT(mt) == 1;
-        bj = fl ? ptm[j] : (META_DYN(mt) ? -2.0f : -1.0f);
+        bj = fl ? ptm[j] : (META_DYN(mt) ? -2.0f - (float)META_OBJ(mt) : -1.0f);
         return make_float4(p.x, p.y, p.z, fl ? m : rho0 * p.w);
     }
     __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }
@@ -274,11 +282,11 @@ struct PressurePass {
         } else {
             const float cc = fdiv(-a.w * o.p, o.rho2);
             o.ax += cc * gx; o.ay += cc * gy; o.az += cc * gz;
-            if (bj == -2.0f) {  // base_solver.py:174-187 (torque about pos_i, sic)
-                const int obj = META_OBJ(meta[j]);
+            if (bj <= -2.0f) {  // base_solver.py:174-187 (torque about pos_i, sic)
+                const int obj = (int)(-bj) - 2;
                 const float cf = fdiv(a.w * o.p, o.rho2);
                 const float fx = (cf * gx) * o.m0, fy = (cf * gy) * o.m0, fz = (cf * gz) * o.m0;
-                const float rx = o.x - pose->com[obj][0], ry = o.y - pose->com[obj][1], rz = o.z - pose->com[obj][2];
+                const float rx = o.x - wrench_com()[obj][0], ry = o.y - wrench_com()[obj][1], rz = o.z - wrench_com()[obj][2];
                 add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
             }
         }
@@ -341,7 +349,7 @@ struct WcsphForcePass {
         }
         const int m = meta[j];
         const bool fl = META_MAT(m) == 1;
-        bj = make_float4(v.x, v.y, v.z, fl ? rho_raw[j] : (META_DYN(m) ? -2.0f : -1.0f));
+        bj = make_float4(v.x, v.y, v.z, fl ? rho_raw[j] : (META_DYN(m) ? -2.0f - (float)META_OBJ(m) : -1.0f));
         cj = fl ? ptm[j] : 0.0f;
         return make_float4(p.x, p.y, p.z, fl ? v.w : rho0 * p.w);
     }
@@ -396,17 +404,17 @@ struct WcsphForcePass {
             o.ax += acx; o.ay += acy; o.az += acz;
             const float cp = fdiv(-a.w * o.p, o.rho2);
             o.px += cp * gx; o.py += cp * gy; o.pz += cp * gz;
-            if (bj.w == -2.0f) {  // dynamic rigid neighbour
-                const int obj = META_OBJ(meta[j]);
+            if (bj.w <= -2.0f) {  // dynamic rigid neighbour
+                const int obj = (int)(-bj.w) - 2;
                 {   // base_solver.py:272-278
                     const float fx = fdiv(-acx * o.m, c.rho0), fy = fdiv(-acy * o.m, c.rho0), fz = fdiv(-acz * o.m, c.rho0);
-                    const float rx = a.x - pose->com[obj][0], ry = a.y - pose->com[obj][1], rz = a.z - pose->com[obj][2];
+                    const float rx = a.x - wrench_com()[obj][0], ry = a.y - wrench_com()[obj][1], rz = a.z - wrench_com()[obj][2];
                     add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
                 }
                 if (AF || o.dyn) {   // base_solver.py:174-187 (torque about pos_i, sic)
                     const float cf = fdiv(a.w * o.p, o.rho2);
                     const float fx = (cf * gx) * o.m0, fy = (cf * gy) * o.m0, fz = (cf * gz) * o.m0;
-                    const float rx = o.x - pose->com[obj][0], ry = o.y - pose->com[obj][1], rz = o.z - pose->com[obj][2];
+                    const float rx = o.x - wrench_com()[obj][0], ry = o.y - wrench_com()[obj][1], rz = o.z - wrench_com()[obj][2];
                     add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
                 }
             }

@@ -196,7 +196,7 @@ struct DfsphCorrectPass {
         float4 p = posv[j];
         if (!AF) {
             const int m = meta[j];
-            if (META_MAT(m) != 1) { p.w = -p.w; bj = make_float2(META_DYN(m) ? 1.0f : 0.0f, 1.0f); return p; }
+            if (META_MAT(m) != 1) { p.w = -p.w; bj = make_float2(META_DYN(m) ? 1.0f + (float)META_OBJ(m) : 0.0f, 1.0f); return p; }   // dynamic rigid: 1 + its body
         }
         bj = make_float2(kappa[j], rho[j]);
         return p;
@@ -230,11 +230,10 @@ struct DfsphCorrectPass {
                 const float cc = fdiv(o.k, o.rho);
                 const float tx = ((V * gx) * cc) * c.rho0, ty = ((V * gy) * cc) * c.rho0, tz = ((V * gz) * cc) * c.rho0;
                 o.vx -= tx; o.vy -= ty; o.vz -= tz;
-                if (bj.x == 1.0f) {  // dynamic rigid: DFSPH.py:195-204 / :277-285
-                    const int obj = META_OBJ(meta[j]);
+                if (bj.x >= 1.0f) {  // dynamic rigid: DFSPH.py:195-204 / :277-285 (body and position staged with the neighbour, centre of mass in LDS)
+                    const int obj = (int)bj.x - 1;
                     const float fx = fdiv(tx, c.dt) * o.m0, fy = fdiv(ty, c.dt) * o.m0, fz = fdiv(tz, c.dt) * o.m0;
-                    const float4 pj = posv[j];
-                    const float rx = pj.x - pose->com[obj][0], ry = pj.y - pose->com[obj][1], rz = pj.z - pose->com[obj][2];
+                    const float rx = a.x - wrench_com()[obj][0], ry = a.y - wrench_com()[obj][1], rz = a.z - wrench_com()[obj][2];
                     add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
                 }
             }
