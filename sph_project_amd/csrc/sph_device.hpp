@@ -535,55 +535,6 @@ __device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int
     return nm;
 }
 
-// Ordered walk out of the tile: lane i walks run [js, je) itself, 32 candidates at a time.  Used for the groups the merged loop
-// below does not take (a run of more than 64 candidates somewhere in the wave; debug mode 4).  A run that does not fit the tile
-// takes process_chunk instead.
-template <bool LDS, int ZW_OFF, int MASKMODE, class P>
-__device__ __forceinline__ void process_run(const Consts &c, const P &p, typename P::Own &own, int i, float xi,
-                                            float yi, float zi, int js, int je, int loff, const float2 *sXY,
-                                            const float2 *sZW, const typename P::BT *sB,
-                                            const typename PassC<P>::type *sC, int cap,
-                                            unsigned &npairs, unsigned stored, unsigned stored_hi, unsigned *store_to,
-                                            unsigned *store_hi) {
-    static_assert(LDS, "candidates come from the tile (the L2 walk of rounds 1-2 is gone: process_chunk)");
-    {
-        int it = 0;
-        for (int j0 = js; __any(j0 < je); j0 += 32, ++it) {  // wave-uniform trip count
-            int m = je - j0;
-            m = m < 0 ? 0 : (m > 32 ? 32 : m);
-            int base = j0 + loff;
-            base = base > cap ? cap : base;            // lanes already past their run stay inside the tile
-            unsigned nm;
-            if (MASKMODE == 2 && it < 2) {
-                // a lane without candidates may sit here because of its wave neighbours: its slot was never written by
-                // the storing pass if no lane of *that* wave had candidates (wave composition differs with the lane
-                // permutation)
-                nm = m > 0 ? (it == 0 ? stored : stored_hi) : 0u;
-            } else {
-                nm = phase1_mask<ZW_OFF, MASKMODE == 2 || pass_reuses_masks<P>()>(sXY, base, m, xi, yi, zi, c.h2);
-                const unsigned self = (unsigned)(i - j0);
-                if (self < 32u) nm &= ~(1u << self);                 // p_i != p_j (base_container.py:559)
-                if (MASKMODE == 1 && it == 0) *store_to = nm;
-                if (MASKMODE == 1 && it == 1 && m > 0) *store_hi = nm;
-            }
-            npairs += __popc(nm);
-            while (nm) {
-                const int t = __ffs(nm) - 1;   // ascending t: same accumulation order as the reference
-                nm &= nm - 1;
-                const float2 xy = sXY[base + t];
-                const float2 zw = sZW[base + t];
-                const float dx = xi - xy.x, dy = yi - xy.y, dz = zi - zw.x;
-                const float r2 = dx * dx + dy * dy + dz * dz;
-                typename P::BT bj = typename P::BT();
-                if (P::HAS_B) bj = sB[base + t];
-                typename PassC<P>::type cj = typename PassC<P>::type();
-                if (PassC<P>::value) cj = sC[base + t];
-                pass_pair(p, c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, cj, j0 + t);
-            }
-        }
-    }
-}
-
 // Tile overflow (one run longer than the tile; every run in debug mode 1): the run goes through the tile in chunks of CAP slots and every
 // lane walks the part of its candidates [js, je) that lies in the chunk [cs, ce) (sorted indices), in 32-candidate blocks aligned to js --
 // so the two stored mask words keep their meaning -- and ascending throughout: the reference's order.  Masks are always recomputed here (a
@@ -845,6 +796,9 @@ k_compact_blocks(const int *__restrict__ flag, int nb, int *__restrict__ list, i
 // walks spill 10 VGPRs, with 2 nothing spills in either the all-fluid or the rigid-aware instantiations).  Measured at C3 / PCISPH
 // (profiles/r03n_ab_medium_occupancy.txt): 24-byte subset -2 %, 28 bytes with spills -3.5 %, 28 bytes / batches of 2 (this) -3 % from
 // rest and -6 % in motion, no spills.  0 bytes = off.
+#ifndef SPH_NBR_LIGHT_CAP
+#define SPH_NBR_LIGHT_CAP 1280
+#endif
 #ifndef SPH_NBR_HEAVY_BUDGET
 #define SPH_NBR_HEAVY_BUDGET 40960   // LDS bytes per workgroup of the functors that are neither light nor medium (A/B: 32768 with SPH_NBR_WAVES_HEAVY=5)
 #endif
@@ -870,7 +824,9 @@ template <class P> constexpr int nbr_tile_cap() {
     const int per_slot = pass_slot_bytes<P>();
     const int budget = pass_is_medium<P>() ? 32768 : SPH_NBR_HEAVY_BUDGET;   // a fifth / a quarter of the CU's 160 KB
     const int slots = (budget - 9 * NBR_CS_PITCH * 2 - 1536) / per_slot - NBR_PAD;   // 1.5 KB for the small arrays and the allocation granule
-    return slots > 1280 ? 1280 : slots / 8 * 8;
+    // the payload-free passes (16 B per slot) could hold far more than a group ever needs: SPH_NBR_LIGHT_CAP slots, so that their tile
+    // leaves room for SPH_NBR_WAVES_LIGHT workgroups per CU (1280 slots = 23.7 KB: six; 1232 = 22.9 KB: seven)
+    return slots > SPH_NBR_LIGHT_CAP ? SPH_NBR_LIGHT_CAP : slots / 8 * 8;
 }
 // Staging plan of one round of one x-offset group (workgroup-uniform; see the group loop of k_nbr_pass): which of the group's three
 // runs go into the tile (bit q of rm), at which tile offset (lo_[q] = offset - run start; INT_MIN: not staged), how many slots in all.
@@ -1244,20 +1200,26 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     if (m > 32) nbr_mask_hi[(size_t)k * mask_stride + i] = (unsigned)(w01 >> 32);
                 }
             } else if (c.force_global == 4 || __any(longrun)) {
-                // a pile-up of more than 64 candidates in three cells (or debug mode 4): the runs one by one, out of the tile, wave-uniformly
+                // a pile-up of more than 64 candidates in three cells (or debug mode 4): the runs one by one, wave-uniformly, through the same
+                // ordered walk that takes a run longer than the tile (process_chunk: the staged run is ONE chunk at tile offset lo_, masks
+                // recomputed).  Until round 4 a second walk (process_run) did this with the stored masks; it is rare enough not to deserve
+                // its registers.
 #pragma unroll 1
                 for (int q = 0; q < RPG; ++q) {
                     const int k = g * RPG + q;
-                    const int js = q == 0 ? js_[0] : (q == 1 ? js_[1] : js_[2]);
-                    const int m = q == 0 ? m_[0] : (q == 1 ? m_[1] : m_[2]);
                     const bool in = q == 0 ? inr[0] : (q == 1 ? inr[1] : inr[2]);
+                    const int js = in ? (q == 0 ? js_[0] : (q == 1 ? js_[1] : js_[2])) : 0;
+                    const int m = in ? (q == 0 ? m_[0] : (q == 1 ? m_[1] : m_[2])) : 0;
                     const int loff = q == 0 ? lo_[0] : (q == 1 ? lo_[1] : lo_[2]);
-                    if (!in) continue;
-                    unsigned *mslot = nbr_mask + (size_t)k * mask_stride + i;
-                    unsigned *mslot_hi = nbr_mask_hi + (size_t)k * mask_stride + i;
-                    unsigned stored = 0, stored_hi = 0;
-                    if (MASKMODE == 2) { stored = q == 0 ? mk[0] : (q == 1 ? mk[1] : mk[2]); stored_hi = q == 0 ? mh[0] : (q == 1 ? mh[1] : mh[2]); }
-                    process_run<true, ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, loff, sXY, sZW, sB, sC, CAP, npairs, stored, stored_hi, mslot, mslot_hi);
+                    const int lnq = q == 0 ? ln_[0] : (q == 1 ? ln_[1] : ln_[2]);
+                    const int cs = loff == INT_MIN ? 0 : -loff;          // sorted index of tile slot 0 for this run
+                    const int ce = loff == INT_MIN ? 0 : cs + lnq;
+                    unsigned long long w01 = 0ull;
+                    process_chunk<ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, cs, ce, sXY, sZW, sB, sC, npairs, w01);
+                    if (MASKMODE == 1 && in) {
+                        nbr_mask[(size_t)k * mask_stride + i] = (unsigned)w01;
+                        if (m > 32) nbr_mask_hi[(size_t)k * mask_stride + i] = (unsigned)(w01 >> 32);
+                    }
                 }
             } else {
                 // acceptance masks of the three runs, then one merged loop

@@ -164,7 +164,7 @@ def test_wrench_is_bit_reproducible_and_cheap(gpu):
     """the wrench onto a dynamic body used to be six f32 atomicAdd per fluid-rigid pair onto the same six words -- order-
     dependent and serialised.  add_wrench (csrc/sph_passes.hpp) now sums over the lanes of a wave in a fixed order and accumulates in
     64-bit fixed point: (1) two runs of the same scene give the SAME bits, step after step; (2) a scene with > 100 k fluid -- dynamic-rigid
-    pairs per step costs no more than the same scene with the plate declared static (no wrench at all) + 15 %."""
+    pairs per step: the force pass costs no more than with the plate declared static (same branches, no wrench at all) + 10 %."""
     import time
     cfg = H.dam_break_scene(domain_end=(1.6, 0.8, 1.6), start=(0.1, 0.1, 0.1), end=(1.36, 0.3, 1.36), translation=(0, 0, 0),
                             particleSpacing=0.019, viscosity_b=0.4, velocity=(0.0, -0.2, 0.0))
@@ -185,17 +185,25 @@ def test_wrench_is_bit_reproducible_and_cheap(gpu):
     runs[1][0].close()
     eng_sta, _ = _engine_with_plate(cfg, plate, dynamic=False)
 
-    def ms_per_step(e, k=60):
+    def kernel_us(e, k=40):
+        """per-kernel microseconds per step (HIP events around every launch)"""
+        names = [e.lib.sph_kernel_name(q).decode() for q in range(19)]
         e.step_async(10); e.synchronize()
-        t0 = time.perf_counter(); e.step_async(k); e.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / k
-    t_sta = min(ms_per_step(eng_sta) for _ in range(2))
-    t_dyn = min(ms_per_step(eng_dyn) for _ in range(2))
+        e.profile_enable(-1, True); e.profile_reset()
+        e.step_async(k); e.synchronize()
+        t = {names[q]: e.profile_read(q) for q in range(19)}
+        e.profile_enable(-1, False)
+        return {n: 1e3 * ms / k for n, (cnt, ms) in t.items() if cnt}
+    k_sta, k_dyn = kernel_us(eng_sta), kernel_us(eng_dyn)
     # pairs with the plate: fluid particles within the support of a plate particle
     pos, mat = eng_dyn.download(L.F_POSITION), eng_dyn.download(L.F_MATERIAL)
     near = int(((mat == 1) & (pos[:, 1] < 0.08 + 0.04)).sum())
-    print("wrench: %d fluid particles (%d within the plate's support, ~%d fluid-rigid pairs per pass), %.4f ms/step dynamic vs %.4f static plate" % (
-        n_f, near, near * 12, t_dyn, t_sta))
+    print("wrench: %d fluid particles (%d within the plate's support, ~%d fluid-rigid pairs per pass)" % (n_f, near, near * 12))
+    print("wrench: us per step, static plate :", {k: round(v, 1) for k, v in sorted(k_sta.items())})
+    print("wrench: us per step, dynamic plate:", {k: round(v, 1) for k, v in sorted(k_dyn.items())})
     assert near * 12 > 100000
-    assert t_dyn <= 1.15 * t_sta + 0.01, (t_dyn, t_sta)
+    # the pass that accumulates the wrench (both runs take the rigid branches of its pair(); only the dynamic one calls add_wrench).
+    # (A dynamic body also costs a rigid-volume pass per step and 16 B more per particle in the sort -- the reference recomputes the
+    #  volumes of moving bodies every step, base_solver.py:696 -- which is why whole steps are not compared.)
+    assert k_dyn["wcsph_forces"] <= 1.10 * k_sta["wcsph_forces"] + 3.0, (k_dyn["wcsph_forces"], k_sta["wcsph_forces"])
     eng_dyn.close(); eng_sta.close()
