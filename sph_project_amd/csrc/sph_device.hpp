@@ -1211,9 +1211,8 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     const int js = in ? (q == 0 ? js_[0] : (q == 1 ? js_[1] : js_[2])) : 0;
                     const int m = in ? (q == 0 ? m_[0] : (q == 1 ? m_[1] : m_[2])) : 0;
                     const int loff = q == 0 ? lo_[0] : (q == 1 ? lo_[1] : lo_[2]);
-                    const int lnq = q == 0 ? ln_[0] : (q == 1 ? ln_[1] : ln_[2]);
-                    const int cs = loff == INT_MIN ? 0 : -loff;          // sorted index of tile slot 0 for this run
-                    const int ce = loff == INT_MIN ? 0 : cs + lnq;
+                    const int cs = loff == INT_MIN ? 0 : -loff;          // sorted index of tile slot 0 as this run sees it (thin grids: the three
+                    const int ce = loff == INT_MIN ? 0 : cs + total;     // runs share one staged stretch); the lane's own [js, js + m) lies inside
                     unsigned long long w01 = 0ull;
                     process_chunk<ZW_OFF, MASKMODE>(c, p, own, i, pi.x, pi.y, pi.z, js, js + m, cs, ce, sXY, sZW, sB, sC, npairs, w01);
                     if (MASKMODE == 1 && in) {

@@ -406,17 +406,19 @@ struct WcsphForcePass {
             o.px += cp * gx; o.py += cp * gy; o.pz += cp * gz;
             if (bj.w <= -2.0f) {  // dynamic rigid neighbour
                 const int obj = (int)(-bj.w) - 2;
-                {   // base_solver.py:272-278
-                    const float fx = fdiv(-acx * o.m, c.rho0), fy = fdiv(-acy * o.m, c.rho0), fz = fdiv(-acz * o.m, c.rho0);
-                    const float rx = a.x - wrench_com()[obj][0], ry = a.y - wrench_com()[obj][1], rz = a.z - wrench_com()[obj][2];
-                    add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
-                }
-                if (AF || o.dyn) {   // base_solver.py:174-187 (torque about pos_i, sic)
+                // the viscous part (base_solver.py:272-278, torque about pos_j) and the pressure part (:174-187, torque about pos_i, sic) of
+                // this pair go to the body's accumulators together: one add_wrench (six LDS adds) instead of two
+                float fx = fdiv(-acx * o.m, c.rho0), fy = fdiv(-acy * o.m, c.rho0), fz = fdiv(-acz * o.m, c.rho0);
+                float rx = a.x - wrench_com()[obj][0], ry = a.y - wrench_com()[obj][1], rz = a.z - wrench_com()[obj][2];
+                float tx = ry * fz - rz * fy, ty = rz * fx - rx * fz, tz = rx * fy - ry * fx;
+                if (AF || o.dyn) {
                     const float cf = fdiv(a.w * o.p, o.rho2);
-                    const float fx = (cf * gx) * o.m0, fy = (cf * gy) * o.m0, fz = (cf * gz) * o.m0;
-                    const float rx = o.x - wrench_com()[obj][0], ry = o.y - wrench_com()[obj][1], rz = o.z - wrench_com()[obj][2];
-                    add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
+                    const float gxf = (cf * gx) * o.m0, gyf = (cf * gy) * o.m0, gzf = (cf * gz) * o.m0;
+                    rx = o.x - wrench_com()[obj][0]; ry = o.y - wrench_com()[obj][1]; rz = o.z - wrench_com()[obj][2];
+                    tx += ry * gzf - rz * gyf; ty += rz * gxf - rx * gzf; tz += rx * gyf - ry * gxf;
+                    fx += gxf; fy += gyf; fz += gzf;
                 }
+                add_wrench(scal, obj, fx, fy, fz, tx, ty, tz);
             }
         }
     }
