@@ -202,7 +202,20 @@ def cpu_baseline(cfg, steps):
                 break
     except OSError:
         pass
+    # how many of those hardware threads may this process actually use?  (a container with a CPU quota reports all of the host's threads
+    # in os.cpu_count(); a sweep that peaks at 16-32 threads and collapses beyond is the quota's throttling, not the code's scaling)
+    quota = None
+    try:
+        a, b_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if a == "max" else float(a) / float(b_)
+    except (OSError, ValueError):
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = None
     return dict(value=table[best], cores=best, secs=best_dt, pairs_per_s=pairs * steps / best_dt, sweep=table, model=model, ncpu=ncpu,
+                cpu_quota_cores=quota, affinity_threads=affinity,
                 speedup_over_1_thread=table[best] / table[1] if 1 in table else None)
 
 
@@ -627,6 +640,7 @@ def run_rank(args, rank, world, local_rank):
             "pair_interactions_per_s": cb["pairs_per_s"], "cpu": cb["model"], "hardware_threads": cb["ncpu"],
             "threads_sweep": {str(k): v for k, v in cb["sweep"].items()},
             "speedup_over_1_thread": cb["speedup_over_1_thread"],
+            "cgroup_cpu_quota_cores": cb["cpu_quota_cores"], "affinity_threads": cb["affinity_threads"],
             "thread_binding": "OMP_PROC_BIND=%s OMP_PLACES=%s, arrays first-touched page-interleaved over the threads" % (
                 os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
         }

@@ -288,6 +288,39 @@ def test_slab_cuts_follow_the_fluid(gpu, tmp_path):
     assert max(owned) <= 1.6 * min(owned), "still balanced"
 
 
+def test_a_cut_that_moves_hands_over_a_layer_larger_than_the_async_margin(gpu, tmp_path):
+    """after a rebalance moved a cut, the gaining rank receives a whole cell layer in ONE step message.  With fewer
+    than 16 layers per rank that is more than the margin of an asynchronous launch bound (max(16384, n / 16)), SLAB_ST_BOUND was raised
+    and the run died at the next settle -- the only rebalance test had 5 k particles and stayed under the floor.  Here a layer holds
+    ~19 k particles (> 16384 and > n / 16 = 8.3 k at 7 layers per rank), the steps go to the device in ONE advance() call, and the cuts
+    move: the step right after a cut moved runs with exact launches (sph_comm_api.hpp slab_neighbor_search)."""
+    cfg = H.dam_break_scene(domain_end=(2.2, 2.1, 1.4), start=(0.1, 0.1, 0.1), end=(2.08, 1.98, 0.66), translation=(0, 0, 0),
+                            velocity=(0.0, 0.0, 8.0), particleSpacing=0.02, gravitation=[0.0, 0.0, 0.0])
+    steps, nranks = 40, 2
+    outs, logs = _run_ranks(cfg, nranks, steps, tmp_path, jitter=0.002, seed=9, rebalance=4, advance=True)
+    ref = H.build_oracle(cfg, jitter=0.002, seed=9)
+    ref.prepare()
+    ref.step(steps)
+    ids = H.oracle_ids(ref)
+    x_ref = H.by_id(ids, ref.field("particle_positions").copy())
+    _, geo, _b = H.scene_particles(cfg)
+    all_ids = np.concatenate([o["ids"] for o in outs])
+    assert len(all_ids) == len(ids) and len(np.unique(all_ids)) == len(ids)
+    x = np.empty_like(x_ref)
+    for o in outs:
+        x[o["ids"]] = o["pos"]
+    d = H.drift(x, x_ref, geo.dh)
+    cuts0 = [int(v) for v in outs[0]["cuts"]]
+    cuts1 = [int(outs[0]["z_lo"])] + [int(o["z_hi"]) for o in outs]
+    nz = int(geo.grid_num[2])
+    layer = np.bincount(np.clip((x_ref[:, 2] / geo.dh).astype(int), 0, nz - 1), minlength=nz).max()
+    print("big-layer rebalance: n %d, fullest layer %d, cuts %s -> %s, drift %.2e" % (len(ids), layer, cuts0, cuts1, d.max()))
+    assert layer > max(16384, len(ids) // nranks // 16)
+    assert cuts1[1] > cuts0[1], "the fluid moved up, the cut followed"
+    assert d.max() <= 1e-5
+    _pairs_agree(sum(int(o["pairs"]) for o in outs), ref.last_pairs)
+
+
 @pytest.mark.parametrize("method", ["wcsph", "dfsph"])
 def test_late_entry_under_slab_sharding(gpu, tmp_path, method):
     """a block with a late entryTime enters a sharded run (base_container.py:218-221).  Every rank
