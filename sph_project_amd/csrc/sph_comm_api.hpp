@@ -695,10 +695,11 @@ extern "C" int sph_comm_set_rebalance(SphHandle *h, int every_steps) {
 //           bounds against the real counts (SLAB_ST_BOUND, sticky, reported at the next settle); the host never runs more than
 //           SLAB_MAX_LAG steps ahead of the mirror (back-pressure, not a drain).
 #define SLAB_MAX_LAG 3
-static int slab_neighbor_search_push(SphHandle *h, bool async) {
+static int slab_neighbor_search_push(SphHandle *h, bool async, bool cut_moved = false) {
     State &s = h->st;
     SlabComm &c = h->comm;
     if (!async) {
+        const int est_before = c.est_recv;
         int rc = slab_settle(h); if (rc) return rc;
         s.async_counts = 0; s.c.n_dev = nullptr;
         { ProfScope p(h, SPH_K_HALO);
@@ -712,6 +713,10 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
         if (m.status) return fail(h, SPH_ERR_COMM, "halo exchange failed (status %d): %s", m.status, slab_status_text(m.status));
         for (int side = 0; side < 2; ++side) { c.n_send[side] = m.n_send[side]; c.n_recv[side] = m.n_recv[side]; }
         c.est_recv = m.n_recv[0] + m.n_recv[1];
+        // the step in which a layer changes hands is not typical for the rank that GIVES it: the new owner has no boundary copies of that
+        // layer to send yet (they arrive as migrants in this very message), so this rank receives next to nothing now -- and a full layer
+        // of copies one step later.  The estimate of the steps before stands.
+        if (cut_moved) c.est_recv = std::max(c.est_recv, est_before);
         h->n = m.n_app;
         refresh_counts(h);
         ph_sort_hashed(h);
@@ -750,7 +755,11 @@ static int slab_neighbor_search_push(SphHandle *h, bool async) {
         }
         grid_n = c.bound_live;
     }
-    const long long margin = std::max<long long>(16384, live_known / 16) + (long long)lag * std::max<long long>(4096, live_known / 64);
+    // margin: a sixteenth of the slab (>= 16 k particles), one more cell layer's worth for thin slabs (a layer of boundary copies that was
+    // not there the step before: a cut moved, fluid reached a face), and a little per step the host runs ahead of the mirror
+    const int layers = std::max(1, s.z_hi - s.z_lo);
+    const long long margin = std::max<long long>(16384, live_known / 16) + (layers < 16 ? live_known / layers : 0) +
+                             (long long)lag * std::max<long long>(4096, live_known / 64);
     const int bound_app = (int)std::min<long long>(s.cap, app_known + margin);
     const int bound_live = (int)std::min<long long>(s.cap, live_known + margin);
     h->n_exact = false;
@@ -786,7 +795,7 @@ static int slab_neighbor_search(SphHandle *h, bool allow_async = false) {
     // A cut that moved hands a whole cell layer over in this step's message: ~n / layers particles on top of the usual trickle, more than
     // the margin of an asynchronous launch bound as soon as a slab has fewer than 16 layers (C4 on 8 ranks: 12).  That one step runs with
     // exact launches (one read-back); est_recv then holds the layer, and the following asynchronous steps are sized from real counts.
-    if (s.push.on) return slab_neighbor_search_push(h, allow_async && c.async_enabled != 0 && !cut_moved);
+    if (s.push.on) return slab_neighbor_search_push(h, allow_async && c.async_enabled != 0 && !cut_moved, cut_moved);
     { ProfScope p(h, SPH_K_HALO); h->L->halo_classify_pack(s, h->n); }
     const void *send[2] = {s.sendbuf[0], s.sendbuf[1]};
     void *recv[2] = {s.recvbuf[0], s.recvbuf[1]};

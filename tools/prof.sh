@@ -8,8 +8,8 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $*"
-[ -n "${SKIP_TRACE:-}" ] || timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/trace.log 2>&1
+BENCH="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --motion-step 0 $*"
+[ -n "${SKIP_TRACE:-}" ] || timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/trace.log 2>&1
 i=0
 for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
@@ -17,7 +17,7 @@ for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS S
             "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   if [ -n "${PMC_SETS:-}" ] && [[ " $PMC_SETS " != *" $i "* ]]; then continue; fi
-  timeout 300 rocprofv3 --kernel-trace --pmc $CTRS -d $OUT/pmc$i -o pmc --output-format csv -- $BENCH > $OUT/pmc$i.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $CTRS -d $OUT/pmc$i -o pmc --output-format csv -- $BENCH > $OUT/pmc$i.log 2>&1
 done
 cd $REPO
 python tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
