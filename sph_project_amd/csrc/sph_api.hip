@@ -286,9 +286,9 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     }
     s.orig.b[0] = s.orig.b[1] = nullptr;
     const size_t G = (size_t)s.c.G;
-    CHK_CREATE(dalloc(h, &s.cell_count, G + 2)); CHK_CREATE(dalloc(h, &s.cell_start, G + 2));   // + graveyard cell (slab sharding)
+    CHK_CREATE(dalloc(h, &s.cell_count, G + SPH_NGRAVE + 1)); CHK_CREATE(dalloc(h, &s.cell_start, G + SPH_NGRAVE + 1));   // + graveyard cells (slab sharding)
     CHK_CREATE(dalloc(h, &s.cellid, cap)); CHK_CREATE(dalloc(h, &s.rank, cap)); CHK_CREATE(dalloc(h, &s.tmp_idx, cap));
-    s.scan_blocks = (int)((G + 1 + 2047) / 2048);
+    s.scan_blocks = (int)((G + SPH_NGRAVE + 2047) / 2048);
     if (s.scan_blocks < SPH_STAT_SLOTS / 256) s.scan_blocks = SPH_STAT_SLOTS / 256;   // k_scan_final also clears the statistics slots
     CHK_CREATE(dalloc(h, &s.scan_partial, (size_t)s.scan_blocks + 1));
     s.cell_count_clean = 1;

@@ -224,7 +224,7 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
             rc = dalloc(h, &s.recvbuf[k], 4 * cap); if (rc) return rc;
         }
         for (int k = 0; k < 8; ++k) { int rc = dalloc(h, &s.halo_tab[k], cap); if (rc) return rc; }
-        { int rc = dalloc(h, &s.halo_counts, 8); if (rc) return rc; }
+        { int rc = dalloc(h, &s.halo_counts, 2 * HC_BANK); if (rc) return rc; }
         if (h->slab_axis == 0 && !getenv("SPH_NO_SLAB_OVERLAP")) {   // boundary / interior tile lists (State::tile_list): slowest-axis slabs only
             for (int k = 0; k < 2; ++k) { int rc = dalloc(h, &s.tile_list[k], ((size_t)s.cap + 255) / 256 + 1); if (rc) return rc; }
             int rc = dalloc(h, &s.tile_cnt, 2); if (rc) return rc;
@@ -814,13 +814,13 @@ static int slab_neighbor_search(SphHandle *h, bool allow_async = false) {
         NCCLCHK(h, ncclGroupStart());
         for (int side = 0; side < 2; ++side) {
             if (!has[side]) continue;
-            NCCLCHK(h, ncclSend(s.halo_counts + side, 1, ncclInt32, peer[side], comm, s.stream));
+            NCCLCHK(h, ncclSend(s.halo_counts + HC(side), 1, ncclInt32, peer[side], comm, s.stream));
             NCCLCHK(h, ncclSend(c.cnt_dev + 4 + side, 1, ncclInt32, peer[side], comm, s.stream));
             NCCLCHK(h, ncclRecv(c.cnt_dev + 2 + side, 1, ncclInt32, peer[side], comm, s.stream));
             NCCLCHK(h, ncclRecv(c.cnt_dev + 6 + side, 1, ncclInt32, peer[side], comm, s.stream));
         }
         NCCLCHK(h, ncclGroupEnd());
-        HIPCHK(h, hipMemcpyAsync(c.cnt_host, s.halo_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+        for (int q = 0; q < 3; ++q) HIPCHK(h, hipMemcpyAsync(c.cnt_host + q, s.halo_counts + HC(q), sizeof(int), hipMemcpyDeviceToHost, s.stream));
         HIPCHK(h, hipMemcpyAsync(c.cnt_host + 4, c.cnt_dev, 8 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
         { int rc = stream_sync_bounded(h, "halo exchange (message sizes)"); if (rc) return rc; }
         dropped = c.cnt_host[2];
@@ -840,7 +840,7 @@ static int slab_neighbor_search(SphHandle *h, bool allow_async = false) {
         size_t br[2] = {(size_t)c.n_recv[0] * rec, (size_t)c.n_recv[1] * rec};
         int rc = comm_exchange(h, send, bs, recv, br, true); if (rc) return rc;
     } else {
-        HIPCHK(h, hipMemcpyAsync(c.cnt_host, s.halo_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+        for (int q = 0; q < 3; ++q) HIPCHK(h, hipMemcpyAsync(c.cnt_host + q, s.halo_counts + HC(q), sizeof(int), hipMemcpyDeviceToHost, s.stream));
         HIPCHK(h, hipStreamSynchronize(s.stream));
         dropped = c.cnt_host[2];
         for (int side = 0; side < 2; ++side) {

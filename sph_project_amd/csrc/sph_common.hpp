@@ -68,6 +68,15 @@ __device__ __forceinline__ int live_n(const Consts &c) { return c.n_dev ? *c.n_d
 
 // z-slab sharding: per-step counts, kept on the device by the halo kernels (sph_halo.hpp) and mirrored into pinned host memory.
 // status bits: see SLAB_ST_* below.
+// Slab sharding files the particles a rank drops (last step's ghosts, migrants) behind its live particles: SPH_NGRAVE graveyard cells
+// G .. G + SPH_NGRAVE - 1 behind the grid.  More than one because every run of dead lanes costs an atomic on its graveyard cell's
+// counter, the dead sit in short runs all over the sorted order (the ghost cells at both ends of every z column), and atomics on ONE
+// address are served one at a time: a single graveyard cell took the hash kernel from 8 to 50 us with two ranks (profiles/r04_two_ranks_*).
+#define SPH_NGRAVE 64
+// the three counters of a step message (records for the lower / upper rank, particles that die) sit in separate 128-byte lines of L2 and
+// a bank (message parity) is HC_BANK ints: thousands of waves add to them per step, and atomics on one line are served one at a time
+#define HC(k) ((k) * 32)
+#define HC_BANK 128
 struct SlabDyn {
     int n_app;       // particles while the step's sort runs: last step's + arrivals (dead ones still in)
     int n_live;      // after the sort: the dead ones (last step's ghosts, migrants that left) dropped

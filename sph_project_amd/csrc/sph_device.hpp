@@ -198,7 +198,7 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
         const int cy = cell_coord(p.y, c.grid_size, c.ny);
         const int cz = cell_coord_z(c, p.z);
         lin = (cx * c.ny + cy) * c.nz + cz;
-        if (meta_dead && META_DEAD(meta_dead[i])) lin = c.G;   // slab sharding: graveyard cell behind the grid
+        if (meta_dead && META_DEAD(meta_dead[i])) lin = c.G + ((i >> 6) & (SPH_NGRAVE - 1));   // slab sharding: a graveyard cell behind the grid
         cellid[i] = lin;
     }
     // The input is the previous step's sorted order, so lanes of one wave fall into a few runs of equal

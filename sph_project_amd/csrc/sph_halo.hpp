@@ -69,14 +69,14 @@ k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z
         const HaloVerdict vd = halo_classify_one(m, slab_layer(c, p), z_lo, z_hi, has_down, has_up);   // (sph_halo_defs.hpp)
         side = vd.side; dead = vd.dead; mnew = vd.mnew; mrec = vd.mrec;
     }
-    const int k0 = halo_wave_slot(side == 0, &counts[0]);
-    const int k1 = halo_wave_slot(side == 1, &counts[1]);
-    halo_wave_slot(dead != 0, &counts[2]);
+    const int k0 = halo_wave_slot(side == 0, &counts[HC(0)]);
+    const int k1 = halo_wave_slot(side == 1, &counts[HC(1)]);
+    halo_wave_slot(dead != 0, &counts[HC(2)]);
     if (hash.cellid) {   // k_hash_count (sph_device.hpp), same wave-aggregated atomics: one per run of equal cell ids
         const int lane = threadIdx.x & 63;
         int lin = -1 - lane;
         if (i < n) {
-            if (dead) lin = c.G;
+            if (dead) lin = c.G + ((i >> 6) & (SPH_NGRAVE - 1));   // (one of the graveyard cells: by wave, so that a run of dead lanes stays one run)
             else {
                 const float4 q = a.posv[i];
                 lin = (cell_coord_x(c, q.x) * c.ny + cell_coord(q.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, q.z);
@@ -138,7 +138,7 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
         // my own header first (workgroup 0): a neighbour waiting for it is released before I start waiting for its
         if (blockIdx.x == 0 && lane < 2 && w.out_ctl[lane]) {
             HaloCtl *ctl = w.out_ctl[lane];
-            const int cnt = w.counts[lane];
+            const int cnt = w.counts[HC(lane)];
             halo_store_sys(&ctl->rec_count, cnt);
             halo_store_sys(&ctl->rec_status, w.dyn_old->status | (cnt > w.halo_cap ? SLAB_ST_SEND_OVERFLOW : 0));
             halo_store_sys(&ctl->rec_stride, w.stride);
@@ -162,7 +162,7 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
         int r0 = __shfl(cnt, 0, 64), r1 = __shfl(cnt, 1, 64);
         st = __shfl(st, 0, 64) | __shfl(st, 1, 64);
         if (lane == 0) {
-            const int s0 = w.counts[0], s1 = w.counts[1], dropped = w.counts[2];
+            const int s0 = w.counts[HC(0)], s1 = w.counts[HC(1)], dropped = w.counts[HC(2)];
             st |= w.dyn_old->status;                        // sticky
             if (s0 > w.halo_cap || s1 > w.halo_cap) st |= SLAB_ST_SEND_OVERFLOW;
             const int n_old = w.n_old >= 0 ? w.n_old : w.dyn_old->n_live;
@@ -187,7 +187,7 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
                 SlabDyn *d = w.dyn_new;
                 d->n_app = n_app; d->n_live = n_live; d->n_send[0] = s0 > w.halo_cap ? w.halo_cap : s0; d->n_send[1] = s1 > w.halo_cap ? w.halo_cap : s1;
                 d->n_recv[0] = r0; d->n_recv[1] = r1; d->dropped = dropped; d->longest = longest; d->seq = w.seq;
-                w.counts_next[0] = w.counts_next[1] = w.counts_next[2] = 0;   // the next classify starts from zero without a memset
+                w.counts_next[HC(0)] = w.counts_next[HC(1)] = w.counts_next[HC(2)] = 0;   // the next classify starts from zero without a memset
                 if (w.mirror) {
                     volatile SlabDyn *m = w.mirror;
                     m->wseq = 2u * w.seq + 1u;   // odd: fields in flux (the host's reader retries)
@@ -451,14 +451,27 @@ __global__ void k_loop_criterion(DevScalars *scal, int slot, int kind, float den
     if (kind == 1 ? ((double)avg <= thr) : (avg < (float)thr)) scal->flags[0] = 1;
 }
 
-// owned particles per global cell layer (slab rebalancing: the cuts follow the fluid)
+// owned particles per global cell layer (slab rebalancing: the cuts follow the fluid), from the cell lists of the last sort: one workgroup
+// per local layer adds up the populations of its cells -- no atomics.  (Until round 4: one atomicAdd per particle onto the ~50 layer
+// counters; atomics on one address are served one at a time, and the kernel took 6 ms at 1.23 M particles -- 0.09 ms per step at a
+// re-plan every 64 steps.  A particle that changed layer since the last sort is counted where it was: this is a planning figure.)
 __global__ void __launch_bounds__(256)
-k_layer_hist(const Consts c, int n, const float4 *posv, const int *meta, int *hist) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int m = meta[i];
-    if (META_GHOST(m) || META_DEAD(m)) return;
-    atomicAdd(&hist[slab_layer(c, posv[i])], 1);
+k_layer_hist(const Consts c, const int *__restrict__ cell_start, int z_lo, int z_hi, int *__restrict__ hist) {
+    __shared__ int s_w[4];
+    const int L = blockIdx.x;                                      // local layer
+    const int glob = L + (c.slab_axis == 0 ? c.cx_off : c.cz_off);
+    if (glob < z_lo || glob >= z_hi) return;                       // ghost layer (uniform)
+    int sum = 0;
+    if (c.slab_axis == 0) {                                        // the layer is one contiguous stretch of cells
+        if (threadIdx.x == 0) sum = cell_start[(L + 1) * c.ny * c.nz] - cell_start[L * c.ny * c.nz];
+    } else {
+        for (int col = threadIdx.x; col < c.nx * c.ny; col += 256) { const int lin = col * c.nz + L; sum += cell_start[lin + 1] - cell_start[lin]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) hist[glob] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
 // number of ghost copies among the first n particles (sph_comm_get_slab): one atomic per wave

@@ -66,9 +66,9 @@ __device__ __forceinline__ HaloVerdict halo_classify_one(int m, int layer, int z
 __device__ __forceinline__ void halo_presend(const Consts &c, const HaloSend &hs, int i, const float4 &p, const float4 &v, float rho) {
     const int m = hs.meta_w[i];
     const HaloVerdict vd = halo_classify_one(m, slab_layer(c, p), hs.z_lo, hs.z_hi, hs.has_down, hs.has_up);
-    const int k0 = halo_wave_slot(vd.side == 0, &hs.counts[0]);
-    const int k1 = halo_wave_slot(vd.side == 1, &hs.counts[1]);
-    halo_wave_slot(vd.dead != 0, &hs.counts[2]);
+    const int k0 = halo_wave_slot(vd.side == 0, &hs.counts[HC(0)]);
+    const int k1 = halo_wave_slot(vd.side == 1, &hs.counts[HC(1)]);
+    halo_wave_slot(vd.dead != 0, &hs.counts[HC(2)]);
     int xi = 0, mnew = vd.mnew;
     if (vd.side >= 0) {
         const int k = vd.side == 0 ? k0 : k1;

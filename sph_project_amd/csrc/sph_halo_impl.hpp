@@ -16,17 +16,17 @@ static void l_halo_classify_pack(State &s, int n) {
     HaloHash hash{nullptr, nullptr, nullptr};
     if (s.push.on) {
         // this kernel and k_halo_unpack2 are the step's k_hash_count as well (ph_sort_hashed follows instead of ph_neighbor_search)
-        if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 2), s.stream);
+        if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + SPH_NGRAVE + 1), s.stream);
         s.cell_count_clean = 0;
         hash = HaloHash{s.cellid, s.rank, s.cell_count};
         const unsigned seq = ++s.push.rec_seq;
         for (int side = 0; side < 2; ++side)
             if (s.push.peer[side]) dst[side] = (float4 *)inbox_rec(s, s.push.peer[side], 1 - side, seq);   // I am the neighbour's OTHER side
-        counts = s.halo_counts + 4 * (seq & 1u);   // zeroed by the previous step's k_halo_unpack2
+        counts = s.halo_counts + HC_BANK * (seq & 1u);   // zeroed by the previous step's k_halo_unpack2
         if (s.async_counts) n_dev = &s.dyn[(seq - 1) & 1u].n_live;
         if (n <= 0) return;
     } else {
-        hipMemsetAsync(s.halo_counts, 0, 4 * sizeof(int), s.stream);
+        hipMemsetAsync(s.halo_counts, 0, HC_BANK * sizeof(int), s.stream);
         if (n <= 0) return;
     }
     hipLaunchKernelGGL(k_halo_classify, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, n, n_dev, s.z_lo, s.z_hi, s.has_down, s.has_up, a,
@@ -43,7 +43,7 @@ static void l_halo_presend_begin(State &s) {
     hs.cap = s.push.rec_cap; hs.rs = s.orig.cur() ? 4 : 3;
     for (int side = 0; side < 2; ++side)
         hs.dst[side] = s.push.peer[side] ? (float4 *)inbox_rec(s, s.push.peer[side], 1 - side, seq) : s.sendbuf[side];
-    hs.counts = s.halo_counts + 4 * (seq & 1u);   // zeroed by this step's k_halo_unpack2
+    hs.counts = s.halo_counts + HC_BANK * (seq & 1u);   // zeroed by this step's k_halo_unpack2
     hs.meta_w = s.meta.cur(); hs.xidx = s.xidx[s.xcur];
     hs.pid = s.pid.cur(); hs.color = s.color.cur(); hs.orig = s.orig.cur();
 }
@@ -73,7 +73,7 @@ static void l_halo_unpack2(State &s, int n_old, int bound_app, int bound_live, i
     }
     w.seq = seq; w.stride = s.orig.cur() ? 4 : 3; w.cap = s.cap; w.halo_cap = s.push.rec_cap;
     w.n_old = n_old; w.bound_app = bound_app; w.bound_live = bound_live; w.timeout_ticks = s.push.timeout_ticks;
-    w.counts = s.halo_counts + 4 * (seq & 1u); w.counts_next = s.halo_counts + 4 * ((seq + 1) & 1u);
+    w.counts = s.halo_counts + HC_BANK * (seq & 1u); w.counts_next = s.halo_counts + HC_BANK * ((seq + 1) & 1u);
     w.dyn_old = s.dyn + ((seq - 1) & 1u); w.dyn_new = s.dyn + (seq & 1u);
     w.mirror = (volatile SlabDyn *)s.push.mirror;
     s.dyn_cur = s.dyn + (seq & 1u);
@@ -192,7 +192,8 @@ static void l_loop_criterion(State &s, int slot) {
 
 static void l_layer_hist(State &s, int *hist) {
     hipMemsetAsync(hist, 0, sizeof(int) * (size_t)(s.c.slab_axis == 0 ? s.c.nx_glob : s.c.nz_glob), s.stream);
-    if (s.c.n > 0) hipLaunchKernelGGL(k_layer_hist, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.c.n, s.posv.cur(), s.meta.cur(), hist);
+    const int nloc = s.c.slab_axis == 0 ? s.c.nx : s.c.nz;
+    if (s.c.n > 0) hipLaunchKernelGGL(k_layer_hist, dim3(nloc), dim3(256), 0, s.stream, s.c, s.cell_start, s.z_lo, s.z_hi, hist);
 }
 
 static void l_count_ghosts(State &s, int *out) {

@@ -26,7 +26,7 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 void l_hash_count(State &s) {
     const int n = s.c.n;
-    if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + 2), s.stream);
+    if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + SPH_NGRAVE + 1), s.stream);
     s.cell_count_clean = 0;
     if (n == 0) return;
     hipLaunchKernelGGL(k_hash_count, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.cellid,
@@ -34,7 +34,7 @@ void l_hash_count(State &s) {
 }
 
 void l_scan(State &s) {
-    const int G = s.c.G + (s.slab_active ? 1 : 0);   // + graveyard cell
+    const int G = s.c.G + (s.slab_active ? SPH_NGRAVE : 0);   // + graveyard cells
     int nb = cdiv(G, SCAN_TILE);                      // <= s.scan_blocks (sized for the global grid)
     if (nb < SPH_STAT_SLOTS / SCAN_TPB) nb = SPH_STAT_SLOTS / SCAN_TPB;   // k_scan_final also clears the statistics slots
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial);
