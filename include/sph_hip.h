@@ -229,8 +229,12 @@ int sph_comm_init(SphHandle *h, int rank, int nranks, const void *id128);
    ncclSend / ncclRecv.  "ipc": push or fail; "rccl": RCCL only; "shm" / "shm+ipc": shared-memory control plane (several ranks on
    one GPU, test rig) with host-staged mailboxes / with the push transport. */
 const char *sph_comm_transport(SphHandle *h);
-/* turn the handle into one z-slab: it owns the cell layers [z_lo, z_hi) of the global grid plus one ghost
-   layer on each interior side; before any particle is appended */
+/* turn the handle into one z-slab: it owns the cell layers [z_lo, z_hi) of the SCENE's z (global grid) plus one ghost layer on each
+   interior side; before any particle is appended.  Everything a caller hands over or reads back stays in the scene's frame.  Inside,
+   the slabs are cut along the fastest axis of the cell order (default) or -- SPH_SLAB_LAYOUT=slow -- the scene's z is mapped onto the
+   library's slowest axis at this boundary (positions, velocities, every 3-vector field, gravity, domain, rigid poses and wrenches are
+   permuted).  Inside a multi-step call (sph_step_async(n)) a sharded WCSPH step lets its force pass write the NEXT step's
+   halo message: between such steps the device state is half-classified, which no host call can observe (every read settles first). */
 int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi);
 int sph_comm_get_slab(SphHandle *h, int *z_lo, int *z_hi, int *n_owned, int *n_ghost);
 /* slab cuts follow the fluid: every `every_steps` steps (default 64, env SPH_SLAB_REBALANCE; 0 = never) the ranks
