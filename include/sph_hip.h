@@ -264,6 +264,15 @@ int sph_voxelize_mesh(const double *vertices, int n_vertices, const int32_t *fac
 int sph_points_in_mesh(const double *vertices, int n_vertices, const int32_t *faces, int n_faces, const double *xs, int nx,
                        const double *ys, int ny, const double *zs, int nz, uint8_t *inside);
 
+/* --- frame export (host code, no GPU involved) ------------------------------------------ */
+/* replaces ti.tools.PLYWriter(num_vertices = n).add_vertex_pos(x, y, z).export_ascii(path) of run_simulation.py:139-144: the ASCII PLY of
+   one fluid object and frame (header as Taichi's python/taichi/tools/ply.py prints it, every value as str(np.float32) followed by a
+   blank).  xyz: f32[n][3] in the scene's frame, e.g. what sph_download(SPH_F_POSITION) returned.  SPH_ERR_UNSUPPORTED: the file could
+   not be written. */
+int sph_write_ply_ascii(const char *path, const float *xyz, int64_t n);
+/* str(np.float32(v)) -- the number format of that file -- into out (>= 48 bytes, no terminator); returns the length */
+int sph_format_f32(float v, char *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,8 @@ _SIGNATURES = [
     ("sph_device_count", C.c_int, []),
     ("sph_voxelize_mesh", C.c_int, [_VP, C.c_int, _VP, C.c_int, C.c_double, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     ("sph_points_in_mesh", C.c_int, [_VP, C.c_int, _VP, C.c_int] + [_VP, C.c_int] * 3 + [_VP]),
+    ("sph_write_ply_ascii", C.c_int, [C.c_char_p, _VP, C.c_int64]),
+    ("sph_format_f32", C.c_int, [C.c_float, C.c_char_p]),
     ("sph_comm_allreduce", C.c_int, [_VP, C.POINTER(C.c_double), C.c_int, C.c_int]),
     ("sph_comm_barrier", C.c_int, [_VP]),
     ("sph_comm_selftest", C.c_int, [_VP, C.c_int]),

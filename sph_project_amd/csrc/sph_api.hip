@@ -14,6 +14,7 @@
 #include <utility>
 #include <array>
 #include "sph_voxel.hpp"
+#include "sph_export.hpp"
 
 static thread_local std::string g_create_error;
 
@@ -982,6 +983,15 @@ extern "C" int sph_upload(SphHandle *h, int field, const void *src, size_t bytes
     }
     return fail(h, SPH_ERR_UNSUPPORTED, "upload: field %d is read-only", field);
 }
+
+// ---------------------------------------------------------------------------------- frame export (host code)
+// replaces ti.tools.PLYWriter(...).add_vertex_pos(...).export_ascii(path) of run_simulation.py:139-144: n vertices, xyz f32[n][3]
+extern "C" int sph_write_ply_ascii(const char *path, const float *xyz, int64_t n) {
+    const int rc = sphexp::write_ply_ascii(path, xyz, n);
+    return rc == 0 ? SPH_OK : (rc == -1 ? SPH_ERR_INVALID : SPH_ERR_UNSUPPORTED);
+}
+// str(np.float32(v)) into out (>= 48 bytes), returns its length: the number format of the PLY body, exported for the tests
+extern "C" int sph_format_f32(float v, char *out) { return out ? sphexp::format_f32(v, out) : SPH_ERR_INVALID; }
 
 // ---------------------------------------------------------------------------------- mesh -> particles (host code)
 // replaces trimesh's `mesh.voxelized(pitch).fill().points` (base_container.py:641-642).  Call with out == NULL to get the

@@ -152,12 +152,18 @@ def test_oracle_pair_metric_counts_four_wcsph_passes():
     assert abs(sim.last_pairs - 4 * brute) <= 0.01 * 4 * brute
 
 
-def test_ply_writer_layout(tmp_path):
+@pytest.mark.parametrize("native", [True, False], ids=["c-abi", "python"])
+def test_ply_writer_layout(tmp_path, monkeypatch, native):
     """The bytes `ti.tools.PLYWriter(num_vertices=n).add_vertex_pos(x, y, z).export_ascii(path)` writes (run_simulation.py:139-144),
     restated from Taichi's python/taichi/tools/ply.py (print_header + export_ascii; default comment "created by PLYWriter"; every
     value is `str(np.float32)` followed by one blank).  Taichi is not installed here: the expected text below is that restatement
-    written out by hand, not the output of a Taichi run."""
+    written out by hand, not the output of a Taichi run.  Two writers produce it: sph_write_ply_ascii (C++ behind the C-ABI, the
+    default: 0.3 s per 1.23 M-particle frame) and the numpy one (SPH_PLY_PYTHON=1, ~5 s)."""
     from sph_project_amd.run_simulation import read_ply_ascii, write_ply_ascii
+    if native:
+        monkeypatch.delenv("SPH_PLY_PYTHON", raising=False)
+    else:
+        monkeypatch.setenv("SPH_PLY_PYTHON", "1")
     p = tmp_path / "a.ply"
     pos = np.array([[0.0, 1.0, 2.5], [0.1, -3.0e-5, 123456.7], [1.0 / 3.0, 1e16, -0.0]], dtype=np.float32)
     write_ply_ascii(str(p), pos)
@@ -170,8 +176,8 @@ def test_ply_writer_layout(tmp_path):
     assert p.read_text().endswith("end_header\n" + body)
     # shortest round-trip digits: reading the file back gives the float32 values bit for bit
     rng = np.random.default_rng(5)
-    big = np.concatenate([rng.uniform(-8, 8, (2000, 3)), rng.uniform(-1e-6, 1e-6, (50, 3)), rng.uniform(-1e9, 1e9, (50, 3))]).astype(np.float32)
-    write_ply_ascii(str(p), big)
+    big = np.concatenate([rng.uniform(-8, 8, (40000, 3)), rng.uniform(-1e-6, 1e-6, (50, 3)), rng.uniform(-1e9, 1e9, (50, 3))]).astype(np.float32)
+    write_ply_ascii(str(p), big)   # (> 1 MiB of text: the native writer flushes its buffer in between)
     back = read_ply_ascii(str(p))
     assert back.dtype == np.float32 and np.array_equal(back.view(np.uint32), big.view(np.uint32))
     lines = p.read_text().splitlines()
@@ -179,6 +185,31 @@ def test_ply_writer_layout(tmp_path):
     write_ply_ascii(str(p), np.zeros((0, 3), np.float32))     # an object that has not entered yet
     assert p.read_text().endswith("element vertex 0\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
     assert read_ply_ascii(str(p)).shape == (0, 3)
+
+
+def test_native_number_format_is_numpys(tmp_path):
+    """sph_format_f32 (csrc/sph_export.hpp: std::to_chars shortest digits laid out by numpy's rule -- positional with one digit behind
+    the point for 0 and 1e-4 <= |v| < 1e16, else scientific with a two-digit exponent) against `str(np.float32)` on 250 k values: uniform,
+    tiny, over the whole exponent range, arbitrary bit patterns (subnormals, NaNs, infinities), and the edges of the two notations."""
+    import ctypes as C
+    from sph_project_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    with np.errstate(over="ignore"):
+        vals = np.concatenate([
+            rng.uniform(-10, 10, 60000), rng.uniform(-1e-3, 1e-3, 40000), 10.0 ** rng.uniform(-45, 38, 60000) * rng.choice([-1, 1], 60000),
+            [0.0, -0.0, 1.0, 0.1, 1e-4, 9.99999e-5, 1e16, 9.9999e15, 1e-5, 123456792.0, np.inf, -np.inf, np.nan, 1.17549435e-38, 1e-45,
+             3.4028235e38, 0.0001234, 100.0, 1e15]]).astype(np.float32)
+    vals = np.concatenate([vals, rng.integers(0, 2 ** 32, 90000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    buf = C.create_string_buffer(64)
+    ref = vals.astype(str).tolist()
+    bad = []
+    for v, r in zip(vals.tolist(), ref):
+        n = lib.sph_format_f32(C.c_float(v), buf)
+        if buf.raw[:n].decode() != r:
+            bad.append((v, buf.raw[:n], r))
+    assert not bad, bad[:5]
+    assert ref[vals.tolist().index(100.0)] == "100.0" and "1e-05" in ref and "1e+16" in ref
 
 
 def test_bench_secondary_bound_is_recomputable_from_the_committed_profile():
