@@ -309,7 +309,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.alpha = s.kappa = s.kappa_v = s.rho_star = s.rho_deriv = s.kappa_next = s.kappa_v_next = nullptr; s.kr = nullptr;
     s.pacc = s.pvel = s.ppos = s.acc_np = nullptr; s.np_acc_out = nullptr; s.np_visc_vel = nullptr;
     s.cg_p2 = nullptr; s.cg_fuse = s.cg_fused_loop = 0;
-    s.cg_p = s.cg_Ap = s.cg_x = s.cg_b = s.cg_r = s.cg_v0 = nullptr; s.cg_dinv = nullptr; s.cg_part = nullptr; s.cg_split = 0; s.split_next_pass = 0;
+    s.cg_p = s.cg_Ap = s.cg_x = s.cg_b = s.cg_r = s.cg_v0 = nullptr; s.cg_dinv = nullptr; s.cg_part = nullptr; s.cg_split = 0; s.cg_nocombine = 0; s.split_next_pass = 0;
     if (p.method == SPH_METHOD_DFSPH) {
         CHK_CREATE(dalloc(h, &s.alpha, cap)); CHK_CREATE(dalloc(h, &s.kappa, cap)); CHK_CREATE(dalloc(h, &s.kappa_v, cap));
         CHK_CREATE(dalloc(h, &s.rho_star, cap)); CHK_CREATE(dalloc(h, &s.rho_deriv, cap)); CHK_CREATE(dalloc(h, &s.kr, cap));

@@ -170,10 +170,23 @@ struct CgApPass {
         z = d[6] * sx + d[7] * sy + d[8] * sz;
 #endif
     }
-    __device__ void partial(const Consts &, int i, int g, const Own &o) const {
+    // Split launch (one workgroup per tile and x-offset group): this group's part of the sum, and -- part_dot set: the unsharded loop with
+    // the fused p update -- its share of p . A p, so that no combining kernel is needed between the walk and the x / r update:
+    //   A p = dt / rho0 (part_0 + part_1 + part_2) + p   =>   p . A p = sum_g p . (dt / rho0 part_g)  +  |p|^2   (the latter counted by group 0);
+    // the x / r update adds the three parts up on the fly (k_cg_update_xr2).  Two launches per CG iteration instead of three.
+    float *part_dot;   // [3][dot_stride] per-workgroup partials of the split walks, or null
+    int dot_stride;
+    __device__ float *split_out(int g) const { return part_dot ? part_dot + (size_t)g * dot_stride : nullptr; }
+    __device__ float partial(const Consts &c, int i, int g, const Own &o) const {
         float x = o.x, y = o.y, z = o.z;
         apply_dinv(i, x, y, z);
         part[(size_t)g * part_stride + i] = make_float4(x, y, z, 0.f);
+        if (!part_dot) return 0.0f;
+        const float4 p = own_p(i);
+        const float ax = fdiv(x * c.dt, c.rho0), ay = fdiv(y * c.dt, c.rho0), az = fdiv(z * c.dt, c.rho0);
+        float d = p.x * ax + p.y * ay + p.z * az;
+        if (g == 0) d += p.x * p.x + p.y * p.y + p.z * p.z;
+        return d;
     }
 
     __device__ float4 stage_impl(int j, BT &bj) const {
@@ -350,9 +363,10 @@ k_cg_check(int nb, const float *part_rr, DevScalars *scal, float tol, const int 
 
 // :394 compute_cg_alpha + :409 update_cg_x + :415 update_cg_r_and_beta (partials)
 __global__ void __launch_bounds__(256)
-k_cg_update_xr2(int n, int nb, const int *meta, int all_fluid, float4 *x, float4 *r, const float4 *p, const float4 *Ap,
+k_cg_update_xr2(const Consts c, int n, int nb, const int *meta, int all_fluid, float4 *x, float4 *r, const float4 *p, const float4 *Ap,
                 const float *part_rr, const float *part_den, float *part_rr_next, float *part_rold, DevScalars *scal,
-                const int *stop_flag, const int *blk_list, const int *blk_count, const float *glob, int count_iteration) {
+                const int *stop_flag, const int *blk_list, const int *blk_count, const float *glob, int count_iteration,
+                const float4 *part3, int part_stride, int den_stride) {
     if (stop_flag && *stop_flag) return;
     // (a physical workgroup beyond the list of fluid-holding ones has no particles, but workgroup 0 keeps the loop's books
     //  whatever the list holds -- with NO active fluid particle at all, e.g. an emitter scene before its first release, the
@@ -361,14 +375,25 @@ k_cg_update_xr2(int n, int nb, const int *meta, int all_fluid, float4 *x, float4
     if (blk < 0 && blockIdx.x != 0) return;
     __shared__ float s4[4];
     const float num_a = glob ? glob[0] : cg_total(part_rr, nb, blk_list, blk_count, s4);
-    const float den_a = glob ? glob[1] : cg_total(part_den, nb, blk_list, blk_count, s4);
+    float den_a = glob ? glob[1] : cg_total(part_den, nb, blk_list, blk_count, s4);
+    if (part3 && !glob) {   // split walks without a combining kernel: part_den = [3][den_stride] (CgApPass::partial)
+        den_a += cg_total(part_den + den_stride, nb, blk_list, blk_count, s4);
+        den_a += cg_total(part_den + 2 * (size_t)den_stride, nb, blk_list, blk_count, s4);
+    }
     const float alpha = den_a > 1e-18f ? num_a / den_a : 0.0f;     // :403
     if (blockIdx.x == 0 && threadIdx.x == 0) { scal->red[4] = alpha; if (count_iteration) scal->flags[1] += 1; }   // (fused p update: this kernel ends the iteration)
     int i = blk * 256 + threadIdx.x;
     float num = 0.f, den = 0.f;
     if (blk >= 0 && i < n && is_fluid(meta, i, all_fluid)) {
         float4 xx = x[i];
-        const float4 pp = p[i], rr = r[i], a = Ap[i];
+        const float4 pp = p[i], rr = r[i];
+        float4 a;
+        if (part3) {   // A p of the split walks, added up here (what k_cg_ap_combine did in a launch of its own)
+            const float4 a0 = part3[i], a1 = part3[(size_t)part_stride + i], a2 = part3[2 * (size_t)part_stride + i];
+            float ax = ((a0.x + a1.x) + a2.x) * c.dt, ay = ((a0.y + a1.y) + a2.y) * c.dt, az = ((a0.z + a1.z) + a2.z) * c.dt;
+            ax = fdiv(ax, c.rho0); ay = fdiv(ay, c.rho0); az = fdiv(az, c.rho0);
+            a = make_float4(ax + pp.x, ay + pp.y, az + pp.z, 0.f);
+        } else a = Ap[i];
         xx.x += alpha * pp.x; xx.y += alpha * pp.y; xx.z += alpha * pp.z;
         x[i] = xx;
         const float4 nr = make_float4(rr.x - alpha * a.x, rr.y - alpha * a.y, rr.z - alpha * a.z, 0.f);

@@ -27,7 +27,7 @@ static int implicit_viscosity_non_pressure(SphHandle *h) {
     // ghosts' p has to exist in memory to be exchanged, so the p update stays a kernel of its own.
     static const char *no_fuse = getenv("SPH_NO_CG_FUSED_P");
     const bool fused = !slab && !no_fuse && s.cg_p2;
-    s.cg_fused_loop = fused ? 1 : 0;
+    s.cg_fused_loop = 0;   // (set for the loop only: the A p pass in front of it feeds prepare2 through cg_Ap)
     bool first = true;
     auto iteration = [&]() {
         refresh(s.cg_p);
@@ -45,6 +45,7 @@ static int implicit_viscosity_non_pressure(SphHandle *h) {
     { ProfScope p(h, SPH_K_CG_AP); h->L->cg_ap(s); }                               // :511
     { ProfScope p(h, SPH_K_CG_VECTOR); h->L->cg_prepare2(s); h->L->cg_alpha(s); }  // :512 (+ |r0|^2 for the first alpha)
     dots(0);
+    s.cg_fused_loop = fused ? 1 : 0;
     float tol = 1000.0f;
     int itr = 0;
     const int max_itr = fixed > 0 ? fixed : 1000;

@@ -180,6 +180,7 @@ struct State {
     int cg_fused_loop;   // this solve runs the two-launch iteration (A p [+ combine], x / r update)
     float *cg_dinv;      // 9 floats per particle
     float4 *cg_part;     // 3 x cap: per-group parts of A p when the pass is split (CgApPass::SPLIT3)
+    int cg_nocombine;    // the last A p pass was split and left its dot-product shares itself: the x / r update adds the parts up (no k_cg_ap_combine)
     int cg_split;        // this solve splits its A p passes (few fluid particles: see implicit_viscosity_non_pressure)
     int split_next_pass; // launch_pass: launch the next SPLIT3 functor with gridDim.y = 3
     int cg_parity;       // which of the two |r|^2 partial arrays the next x / r update reads

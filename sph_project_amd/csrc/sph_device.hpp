@@ -930,7 +930,12 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     const int skip_tile = tile_skip ? (int)tile_skip[b] : 0;
     const int n_live = live_n(c);
     if (i0 >= n_live) {   // launch bound of an asynchronous slab step: no such tile (its header was never written)
-        if constexpr (P::HAS_REDUCE) { if (tid == 0 && !(PassSplit<P>::value && gridDim.y == 3)) p.red_out[b] = 0.0f; }
+        if constexpr (P::HAS_REDUCE) {
+            if (tid == 0) {
+                if constexpr (PassSplit<P>::value) { if (gridDim.y == 3) { if (float *o = p.split_out((int)blockIdx.y)) o[b] = 0.0f; } else p.red_out[b] = 0.0f; }
+                else p.red_out[b] = 0.0f;
+            }
+        }
         return;
     }
     // which particle of the workgroup this lane owns for the whole pass
@@ -1281,16 +1286,19 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     NBR_STAMP(14);
     float red = 0.0f;
     bool split_launch = false;
+    float *red_to = nullptr;   // where this workgroup's partial sum goes (split launch: the functor may keep one per x-offset group)
+    if constexpr (P::HAS_REDUCE) red_to = p.red_out;
     if constexpr (PassSplit<P>::value) {
         split_launch = gridDim.y == GROUPS;
-        if (split_launch && valid && active) p.partial(c, i, (int)blockIdx.y, own);
+        if (split_launch && valid && active) red = p.partial(c, i, (int)blockIdx.y, own);
+        if (split_launch) red_to = p.split_out((int)blockIdx.y);
     }
     if (valid && !split_launch) {
         if (active) red = p.finish(c, i, pi, own);
         else p.passive(c, i, pi);
     }
     NBR_STAMP(15);
-    if (split_launch) return;   // uniform; the combining kernel reduces
+    if (split_launch && !red_to) return;   // uniform; the combining kernel reduces
     if constexpr (P::HAS_REDUCE) {
         // deterministic per-workgroup partial sum: particle order and a fixed tree (whatever the lane permutation),
         // finished by k_reduce_partials
@@ -1306,7 +1314,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             float t = 0.0f;
 #pragma unroll
             for (int k = 0; k < BLOCK / 64; ++k) t += s_red[k];
-            p.red_out[b] = t;
+            red_to[b] = t;
         }
     }
 }

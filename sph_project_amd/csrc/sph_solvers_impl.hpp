@@ -147,18 +147,24 @@ static void l_cg_ap(State &s) {
     const int fuse = s.cg_fuse ? 1 : 0;
     const bool lst = !s.c.all_fluid && s.list_n == s.c.n;
     const int nb = s.c.n > 0 ? cdiv(s.c.n, 256) : 0;
+    // inside the unsharded loop with the fused p update the split walks leave their shares of p . A p themselves (CG_PART(4..6)) and the
+    // x / r update adds the three parts up: no combining kernel (SPH_CG_COMBINE=1: the round-3 sequence, for A/B)
+    static const bool keep_combine = getenv("SPH_CG_COMBINE") != nullptr;
+    const bool nocombine = split && s.cg_fused_loop && !s.slab_active && !keep_combine && s.red_blocks >= nb;
+    s.cg_nocombine = nocombine ? 1 : 0;
+    float *pdot = nocombine ? CG_PART(4) : nullptr;
     if (s.c.all_fluid) {
         CgApPass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2), s.cg_part, s.cap,
                          s.cg_r, s.cg_p2, CG_PART(s.cg_parity), CG_PART(3), nb, lst ? s.blk_list : nullptr, lst ? s.blk_count : nullptr,
-                         fuse, s.loop_flag ? 1 : 0, (float)s.loop_thr, 0.0f};
+                         fuse, s.loop_flag ? 1 : 0, (float)s.loop_thr, 0.0f, pdot, s.red_blocks};
         launch_pass(s, p, 2);
     } else {
         CgApPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), CG_RHO, s.cg_p, s.cg_dinv, s.cg_Ap, CG_PART(2), s.cg_part, s.cap,
                           s.cg_r, s.cg_p2, CG_PART(s.cg_parity), CG_PART(3), nb, lst ? s.blk_list : nullptr, lst ? s.blk_count : nullptr,
-                          fuse, s.loop_flag ? 1 : 0, (float)s.loop_thr, 0.0f};
+                          fuse, s.loop_flag ? 1 : 0, (float)s.loop_thr, 0.0f, pdot, s.red_blocks};
         launch_pass(s, p, 2);
     }
-    if (split)   // the three parts -> A p and the partials of p . A p (what finish() and the pass's reduction do otherwise)
+    if (split && !nocombine)   // the three parts -> A p and the partials of p . A p (what finish() and the pass's reduction do otherwise)
         hipLaunchKernelGGL(k_cg_ap_combine, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.meta.cur(), CG_AF, s.cg_part, s.cap, s.cg_p,
                            s.cg_Ap, CG_PART(2), s.loop_flag, CG_LIST, fuse ? s.cg_r : (const float4 *)nullptr, s.cg_p2, s.scal);
     if (fuse) std::swap(s.cg_p, s.cg_p2);   // cg_p is the search direction of the running iteration again
@@ -187,9 +193,11 @@ static void l_cg_fold(State &s, int which) {
 static void l_cg_update_xr(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
-    hipLaunchKernelGGL(k_cg_update_xr2, dim3(nb), dim3(256), 0, s.stream, s.c.n, nb, s.meta.cur(), CG_AF, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap,
-                       CG_PART(s.cg_parity), CG_PART(2), CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag, CG_LIST, CG_GLOB,
-                       (s.cg_fused_loop && s.loop_flag) ? 1 : 0);
+    const bool nc = s.cg_nocombine != 0;   // the A p pass in front of this kernel left three parts and three sets of p . A p partials
+    hipLaunchKernelGGL(k_cg_update_xr2, dim3(nb), dim3(256), 0, s.stream, s.c, s.c.n, nb, s.meta.cur(), CG_AF, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap,
+                       CG_PART(s.cg_parity), nc ? CG_PART(4) : CG_PART(2), CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag, CG_LIST, CG_GLOB,
+                       (s.cg_fused_loop && s.loop_flag) ? 1 : 0, nc ? s.cg_part : (const float4 *)nullptr, s.cap, s.red_blocks);
+    s.cg_nocombine = 0;
     // fused p update: nothing else closes the iteration -- the partials just written are what the next A p pass reads
     if (s.cg_fused_loop) s.cg_parity = 1 - s.cg_parity;
 }
