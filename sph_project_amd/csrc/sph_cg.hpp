@@ -97,9 +97,15 @@ struct CgPreparePass {
 // all of them hold the same alpha / beta -- and workgroup 0 of the p update does the loop's book-keeping (error, iteration
 // count, stop flag).  Partials: rr[2] (|r|^2, ping-pong: the x / r update reads one and writes the other), den (p . Ap, from
 // the A p pass), rold (|r|^2 before the update, the denominator of beta).
-__device__ __forceinline__ float cg_total(const float *part, int nb, const int *blk_list, const int *blk_count, float *s4) {
+// (stride3 != 0: `part` is three arrays stride3 apart -- the per-group partials of a split A p walk -- added up entry by entry)
+__device__ __forceinline__ float cg_total(const float *part, int nb, const int *blk_list, const int *blk_count, float *s4, int stride3 = 0) {
     float a = 0.f;
-    if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) a += part[blk_list[k]]; }
+    if (stride3) {
+        const float *p1 = part + stride3, *p2 = part + 2 * (size_t)stride3;
+        if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) { const int b = blk_list[k]; a += (part[b] + p1[b]) + p2[b]; } }
+        else for (int k = threadIdx.x; k < nb; k += 256) a += (part[k] + p1[k]) + p2[k];
+    }
+    else if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) a += part[blk_list[k]]; }
     else for (int k = threadIdx.x; k < nb; k += 256) a += part[k];
     a = wave_sum(a);
     __syncthreads();   // s4 may still be read from a previous call
@@ -375,11 +381,8 @@ k_cg_update_xr2(const Consts c, int n, int nb, const int *meta, int all_fluid, f
     if (blk < 0 && blockIdx.x != 0) return;
     __shared__ float s4[4];
     const float num_a = glob ? glob[0] : cg_total(part_rr, nb, blk_list, blk_count, s4);
-    float den_a = glob ? glob[1] : cg_total(part_den, nb, blk_list, blk_count, s4);
-    if (part3 && !glob) {   // split walks without a combining kernel: part_den = [3][den_stride] (CgApPass::partial)
-        den_a += cg_total(part_den + den_stride, nb, blk_list, blk_count, s4);
-        den_a += cg_total(part_den + 2 * (size_t)den_stride, nb, blk_list, blk_count, s4);
-    }
+    // (split walks without a combining kernel: part_den = [3][den_stride], CgApPass::partial)
+    const float den_a = glob ? glob[1] : cg_total(part_den, nb, blk_list, blk_count, s4, part3 ? den_stride : 0);
     const float alpha = den_a > 1e-18f ? num_a / den_a : 0.0f;     // :403
     if (blockIdx.x == 0 && threadIdx.x == 0) { scal->red[4] = alpha; if (count_iteration) scal->flags[1] += 1; }   // (fused p update: this kernel ends the iteration)
     int i = blk * 256 + threadIdx.x;
