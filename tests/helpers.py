@@ -97,3 +97,60 @@ def drift(x, x_ref, dh):
     num = np.linalg.norm(x.astype(np.float64) - x_ref.astype(np.float64), axis=1)
     den = np.maximum(np.linalg.norm(x_ref.astype(np.float64), axis=1), dh)
     return num / den
+
+
+def wcsph_pressure_accel_f64(x, rho, prs, mass, vol, mat, h, rho0):
+    """The reference's pressure acceleration (base_solver.py:136-178 with the cubic kernel gradient of base_solver.py:41-58)
+    restated in float64 over a KD-tree pair list -- an independent evaluation, not the oracle: a_i = -sum_j m_j (p_i / rho_i^2 +
+    p_j / rho_j^2) grad W_ij over fluid neighbours, -rho0 V_j p_i / rho_i^2 grad W_ij over boundary neighbours.
+    Returns per particle and component (rows of non-fluid particles are zero): the sum, sum_j |term_j|, and sum_j |term_j| amp_j with
+    amp_j = |q W'' / W'| the factor by which a relative error of q = r / h shows up in the term: 2 q / (1 - q) on the outer branch
+    ((1 - q)^2 cancels towards the edge of the support), |6 q - 2| / |3 q - 2| <= 2 on the inner one."""
+    from scipy.spatial import cKDTree
+    x = x.astype(np.float64)
+    n = len(x)
+    pairs = cKDTree(x).query_pairs(h * (1 + 1e-6), output_type="ndarray")
+    i = np.concatenate([pairs[:, 0], pairs[:, 1]])
+    j = np.concatenate([pairs[:, 1], pairs[:, 0]])
+    R = x[i] - x[j]
+    r = np.linalg.norm(R, axis=1)
+    keep = (mat[i] == 1) & (r > 1e-5) & (r <= h)
+    i, j, R, r = i[keep], j[keep], R[keep], r[keep]
+    q = r / h
+    kg = 6.0 * (8.0 / np.pi) / h ** 3
+    s = np.where(q <= 0.5, kg * q * (3 * q - 2), -kg * (1 - q) ** 2) / (r * h)
+    s_amp = np.where(q <= 0.5, kg * q * np.abs(6 * q - 2), kg * 2 * q * (1 - q)) / (r * h)   # |s| amp, finite at q = 1
+    pt = prs.astype(np.float64) / rho.astype(np.float64) ** 2
+    coef = np.where(mat[j] == 1, mass[j].astype(np.float64) * (pt[i] + pt[j]), rho0 * vol[j].astype(np.float64) * pt[i])
+    t = -(coef * s)[:, None] * R
+    a, mag, mag_amp = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3))
+    np.add.at(a, i, t)
+    np.add.at(mag, i, np.abs(t))
+    np.add.at(mag_amp, i, np.abs((coef * s_amp)[:, None] * R))
+    return a, mag, mag_amp
+
+
+def dfsph_density_derivative_f64(x, v, vol, mat, h):
+    """DFSPH.py:66-98 restated in float64 over a KD-tree pair list (independent of the oracle): (D rho / Dt) / rho0 of particle i =
+    max(sum_j V_j (v_i - v_j) . grad W_ij, 0), zero where the particle has fewer than 20 neighbours.  Returns (value before the
+    neighbour-count rule, sum_j sum_c |V_j (v_i - v_j)_c grad W_c|, neighbour count with the support radius shrunk / grown by 1e-6):
+    the two counts bracket what an f32 `r < h` can decide for pairs that sit exactly one support radius apart (lattices)."""
+    from scipy.spatial import cKDTree
+    x, v = x.astype(np.float64), v.astype(np.float64)
+    n = len(x)
+    pairs = cKDTree(x).query_pairs(h * (1 + 1e-6), output_type="ndarray")
+    i = np.concatenate([pairs[:, 0], pairs[:, 1]])
+    j = np.concatenate([pairs[:, 1], pairs[:, 0]])
+    keep = mat[i] == 1
+    i, j = i[keep], j[keep]
+    R = x[i] - x[j]
+    r = np.linalg.norm(R, axis=1)
+    n_hi = np.bincount(i, minlength=n)
+    n_lo = np.bincount(i[r < h * (1 - 1e-6)], minlength=n)
+    q = r / h
+    kg = 6.0 * (8.0 / np.pi) / h ** 3
+    with np.errstate(invalid="ignore", divide="ignore"):
+        s = np.where(q <= 0.5, kg * q * (3 * q - 2), -kg * (1 - q) ** 2) / (r * h)
+    s = np.where((r > 1e-5) & (q <= 1.0), s, 0.0)
+    prod = (v[i] - v[j]) * R * (vol[j].astype(np.float64) * s)[:, None]
+    return np.bincount(i, prod.sum(axis=1), minlength=n), np.bincount(i, np.abs(prod).sum(axis=1), minlength=n), n_lo, n_hi
