@@ -121,6 +121,14 @@ __device__ __forceinline__ float kernW(const Consts &c, const Geom &g) {
     return res;
 }
 
+// fast build: grad W_ij = kernGradScale * (x_i - x_j) -- for the functors that fold the scalar into their pair coefficients instead of
+// carrying the gradient as a vector (three multiplies and three registers less per pair)
+__device__ __forceinline__ float kernGradScale(const Consts &c, const Geom &g) {
+    const float q = g.q, f = 1.0f - q;
+    const float s = c.kG * (q <= 0.5f ? q * (3.0f * q - 2.0f) : -f * f);
+    return g.rn > 1e-5f ? s * g.inv_rnh : 0.0f;   // (no q <= 1 test, see kernW)
+}
+
 // base_solver.py:81 kernel_gradient; R = x_i - x_j
 __device__ __forceinline__ void kernGrad(const Consts &c, float dx, float dy, float dz, const Geom &g,
                                          float &gx, float &gy, float &gz) {
