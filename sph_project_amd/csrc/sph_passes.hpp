@@ -157,7 +157,11 @@ struct NonPressurePass {
         if (visc_vel) { const float4 u = visc_vel[i]; v.x = u.x; v.y = u.y; v.z = u.z; }  // base_solver.py:464
         o.vx = v.x; o.vy = v.y; o.vz = v.z; o.m = v.w;
         o.rho = rho_raw[i];
+#if SPH_FAST
+        o.st_m = fdiv(c.st, v.w) * c.rho0;   // (the fast pair() keeps rho0 x (surface tension + viscosity) in o.ax)
+#else
         o.st_m = fdiv(c.st, v.w);
+#endif
         o.sx = o.sy = o.sz = 0.0f;
         o.ax = o.ay = o.az = 0.0f;
         return ok;
@@ -166,10 +170,31 @@ struct NonPressurePass {
                          const BT &bj, int j) const {
         const Geom g = geom(c, r2);
 #if SPH_FAST
-        const float rn2 = r2;               // base_solver.py:254 R.norm()**2
+        // scalar-coefficient form (see WcsphForcePass::pair): o.ax accumulates rho0 x (surface tension + viscosity), one fma per component
+        if (AF || bj.w >= 0.0f) {
+            const float w = r2 > c.diameter2 ? kernW(c, g) : c.Wd;
+            float k = -((o.st_m * a.w) * w);                       // (st_m carries the rho0)
+            if (!skip_viscosity) {
+                const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
+                const float m_ij = (o.m + a.w) * 0.5f;
+                k += (fdiv2(c.cv * m_ij, bj.w, r2 + c.visc_eps) * v_xy) * kernGradScale(c, g);
+            }
+            o.ax += k * dx; o.ay += k * dy; o.az += k * dz;
+        } else {
+            if (skip_viscosity) return;
+            const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
+            const float k = (fdiv2(c.cvb * a.w, o.rho, r2 + c.visc_eps) * v_xy) * kernGradScale(c, g);
+            const float acx = k * dx, acy = k * dy, acz = k * dz;
+            o.ax += acx; o.ay += acy; o.az += acz;
+            if (bj.w <= -2.0f) {  // dynamic rigid neighbour: base_solver.py:272-278
+                const int obj = (int)(-bj.w) - 2;
+                const float fx = fdiv(-acx * o.m, c.rho0), fy = fdiv(-acy * o.m, c.rho0), fz = fdiv(-acz * o.m, c.rho0);
+                const float rx = a.x - wrench_com()[obj][0], ry = a.y - wrench_com()[obj][1], rz = a.z - wrench_com()[obj][2];
+                add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
+            }
+        }
 #else
-        const float rn2 = g.rn * g.rn;
-#endif
+        const float rn2 = g.rn * g.rn;      // base_solver.py:254 R.norm()**2
         float gx, gy, gz;
         if (AF || bj.w >= 0.0f) {
             // surface tension
@@ -196,6 +221,7 @@ struct NonPressurePass {
                 add_wrench(scal, obj, fx, fy, fz, ry * fz - rz * fy, rz * fx - rx * fz, rx * fy - ry * fx);
             }
         }
+#endif
     }
     __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {
         float ax = c.gx, ay = c.gy, az = c.gz;
@@ -274,6 +300,13 @@ struct PressurePass {
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a,
                          const BT &bj, int j) const {
         const Geom g = geom(c, r2);
+#if SPH_FAST
+        if (AF || bj >= 0.0f) {   // scalar x (x_i - x_j), see WcsphForcePass::pair
+            const float k = (-a.w * (o.pt + bj)) * kernGradScale(c, g);
+            o.ax += k * dx; o.ay += k * dy; o.az += k * dz;
+            return;
+        }
+#endif
         float gx, gy, gz;
         kernGrad(c, dx, dy, dz, g, gx, gy, gz);
         if (AF || bj >= 0.0f) {
