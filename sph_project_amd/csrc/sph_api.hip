@@ -35,6 +35,9 @@ struct SphHandle {
     bool n_exact = true;
     int n_fluid = 0;      // fluid_particle_num
     int n_nonfluid = 0;
+    // every fluid particle appended so far carries the same mass (one fluid density: the usual scene), and nobody has uploaded masses:
+    // the fused force pass then runs its uniform-mass instantiation (bit-identical sums, four VALU less per pair)
+    bool fluid_mass_seen = false, fluid_mass_uniform = true; float fluid_mass0 = 0.0f;
     bool any_rigid_object = false;   // a non-fluid object was registered (slab sharding: its particles may live on another rank)
     int64_t steps = 0;
     int steps_to_follow = 0;       // sph_step_async(n): steps of this call still to come after the running one
@@ -194,6 +197,7 @@ static void refresh_counts(SphHandle *h) {
     h->st.c.all_fluid = (h->n_nonfluid == 0 && !h->st.has_emitter && !(h->st.slab_active && h->any_rigid_object)) ? 1 : 0;
     h->st.c.ghosts = h->st.slab_active ? 1 : 0;
     h->st.has_rigid = h->n_nonfluid > 0;
+    h->st.uniform_mass = (h->st.c.all_fluid && h->fluid_mass_uniform && !h->st.slab_active && !getenv("SPH_NO_UNIFORM_MASS")) ? 1 : 0;
 }
 
 extern "C" const char *sph_last_error(SphHandle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -394,7 +398,11 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
         hc[k] = r | (g << 8) | (b << 16);
         hr[k] = density[k];
         hpr[k] = pressure ? pressure[k] : 0.0f;
-        if (material[k] == SPH_MAT_FLUID) nfl++;
+        if (material[k] == SPH_MAT_FLUID) {
+            nfl++;
+            if (!h->fluid_mass_seen) { h->fluid_mass_seen = true; h->fluid_mass0 = hv[k].w; }
+            else if (hv[k].w != h->fluid_mass0) h->fluid_mass_uniform = false;
+        }
         if (material[k] == SPH_MAT_RIGID && is_dynamic[k]) any_dyn_rigid = true;
     }
     if (any_dyn_rigid) { int rc = ensure_orig(h); if (rc) return rc; }
@@ -947,7 +955,7 @@ extern "C" int sph_upload(SphHandle *h, int field, const void *src, size_t bytes
         case SPH_F_POSITION: vdst = s.posv.cur(); break;
         case SPH_F_VELOCITY: vdst = s.velm.cur(); break;
         case SPH_F_REST_VOLUME: vdst = s.posv.cur(); w_only = true; break;
-        case SPH_F_MASS: vdst = s.velm.cur(); w_only = true; break;
+        case SPH_F_MASS: vdst = s.velm.cur(); w_only = true; h->fluid_mass_uniform = false; refresh_counts(h); break;
         case SPH_F_CG_X: vdst = s.cg_x; break;
         default: break;
     }

@@ -348,7 +348,8 @@ struct PressurePass {
 // update sequence (v* = v + dt a_np; v = v* + dt a_p; x += dt v; boundary) with the same roundings.
 // Per candidate: A = (x, y, z, m_j | rho0 V_j), B = (v_j, rho_raw_j | -1 static / -2 dynamic rigid), C = p_j / rho_j^2.
 // Bytes / particle: R posv 16 + velm 16 + rho_raw 4 + ptm 4 (+ own prs, rho 8) -> W acc 16 + posv 16 + velm 16.
-template <bool AF>
+template <bool AF, bool UM = false>   // UM (fast build, all fluid): every particle carries the same mass -- m_ij = m, the products with it are hoisted
+
 struct WcsphForcePass {
     static constexpr bool HAS_WRENCH = !AF;
     static constexpr int BLOCK = 256, GROUPS = 3;
@@ -365,6 +366,7 @@ struct WcsphForcePass {
     struct Own {
         float vx, vy, vz, m, rho, st_m, sx, sy, sz, ax, ay, az;   // non-pressure part (NonPressurePass::Own)
         float pt, p, rho2, px, py, pz, x, y, z, m0;                // pressure part (PressurePass::Own)
+        float cvm, cstm;                                           // UM: c.cv m and (st / m rho0) m, the same roundings as per pair
         int dyn;
     };
     const float4 *posv, *velm; const int *meta; const float *rho_raw, *ptm, *prs, *rho;
@@ -406,6 +408,7 @@ struct WcsphForcePass {
 #else
         o.st_m = fdiv(c.st, v.w);
 #endif
+        o.cvm = c.cv * ((v.w + v.w) * 0.5f); o.cstm = o.st_m * v.w;
         o.sx = o.sy = o.sz = 0.0f;
         o.ax = o.ay = o.az = 0.0f;
         o.x = pi.x; o.y = pi.y; o.z = pi.z; o.m0 = rho0 * pi.w;
@@ -427,12 +430,12 @@ struct WcsphForcePass {
         const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
         if (AF || bj.w >= 0.0f) {
             const float w = r2 > c.diameter2 ? kernW(c, g) : c.Wd;
-            const float cw = (o.st_m * a.w) * w;                                    // surface tension (:210), times rho0
-            const float m_ij = (o.m + a.w) * 0.5f;                                  // viscosity (:232)
-            const float cc = fdiv2(c.cv * m_ij, bj.w, r2 + c.visc_eps) * v_xy;
+            const float cw = (UM ? o.cstm : o.st_m * a.w) * w;                      // surface tension (:210), times rho0
+            const float cvm = UM ? o.cvm : c.cv * ((o.m + a.w) * 0.5f);             // viscosity (:232); UM: (m + m) / 2 = m exactly
+            const float cc = fdiv2(cvm, bj.w, r2 + c.visc_eps) * v_xy;
             const float k = cc * gs - cw;
             o.ax += k * dx; o.ay += k * dy; o.az += k * dz;
-            const float cp = (-a.w * (o.pt + cj)) * gs;                             // pressure (:136)
+            const float cp = (-(UM ? o.m : a.w) * (o.pt + cj)) * gs;                // pressure (:136)
             o.px += cp * dx; o.py += cp * dy; o.pz += cp * dz;
         } else {
             const float k = (fdiv2(c.cvb * a.w, o.rho, r2 + c.visc_eps) * v_xy) * gs;
