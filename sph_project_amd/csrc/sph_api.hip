@@ -167,6 +167,8 @@ static void fill_consts(SphHandle *h) {
     c.W0 = host_kernel_W(hd, 0.0f);
     const float d = (float)(2.0 * p.particle_radius);
     c.Wd = host_kernel_W(hd, sqrtf(d * d + 0.0f + 0.0f));
+    c.kGh = c.kG * c.inv_h;
+    c.Wd_poly = c.Wd / c.kW;
     const double dd = 2.0 * p.particle_radius;
     c.diameter2 = (float)(dd * dd);
     c.dt = (float)p.dt;

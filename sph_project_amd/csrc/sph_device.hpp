@@ -77,7 +77,7 @@ __device__ __forceinline__ int slab_layer(const Consts &c, const float4 &p) {
 
 // Per-pair geometry shared by kernel_W / kernel_gradient.  Strict build: rn = sqrt(r2), q = rn / h (IEEE).
 // Fast build: one v_rsq_f32 gives 1/rn; rn = r2 * (1/rn), q = rn * (1/h), 1/(rn h) = (1/rn)(1/h).
-struct Geom { float rn, q, inv_rnh; };
+struct Geom { float rn, q, inv_rnh, rinv; };
 __device__ __forceinline__ Geom geom(const Consts &c, float r2) {
     Geom g;
 #if SPH_FAST
@@ -85,10 +85,12 @@ __device__ __forceinline__ Geom geom(const Consts &c, float r2) {
     g.rn = r2 * rinv;
     g.q = g.rn * c.inv_h;
     g.inv_rnh = rinv * c.inv_h;
+    g.rinv = rinv;
 #else
     g.rn = __builtin_sqrtf(r2);
     g.q = g.rn / c.h;
     g.inv_rnh = 0.0f;  // unused
+    g.rinv = 0.0f;
 #endif
     return g;
 }
@@ -125,8 +127,13 @@ __device__ __forceinline__ float kernW(const Consts &c, const Geom &g) {
 // carrying the gradient as a vector (three multiplies and three registers less per pair)
 __device__ __forceinline__ float kernGradScale(const Consts &c, const Geom &g) {
     const float q = g.q, f = 1.0f - q;
-    const float s = c.kG * (q <= 0.5f ? q * (3.0f * q - 2.0f) : -f * f);
-    return g.rn > 1e-5f ? s * g.inv_rnh : 0.0f;   // (no q <= 1 test, see kernW)
+    const float s = (q <= 0.5f ? q * (3.0f * q - 2.0f) : -f * f) * g.rinv;
+    return g.rn > 1e-5f ? s * c.kGh : 0.0f;   // kG / (rn h); (no q <= 1 test, see kernW)
+}
+// kernW / kW of an accepted pair (fast build): for the functors that fold kW into a per-particle coefficient
+__device__ __forceinline__ float kernWpoly(const Geom &g) {
+    const float q = g.q, t = 1.0f - q;
+    return q <= 0.5f ? 1.0f - 6.0f * (q * q) * t : 2.0f * (t * t * t);
 }
 
 // base_solver.py:81 kernel_gradient; R = x_i - x_j

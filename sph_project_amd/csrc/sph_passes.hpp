@@ -158,7 +158,7 @@ struct NonPressurePass {
         o.vx = v.x; o.vy = v.y; o.vz = v.z; o.m = v.w;
         o.rho = rho_raw[i];
 #if SPH_FAST
-        o.st_m = fdiv(c.st, v.w) * c.rho0;   // (the fast pair() keeps rho0 x (surface tension + viscosity) in o.ax)
+        o.st_m = (fdiv(c.st, v.w) * c.rho0) * c.kW;   // (the fast pair() keeps rho0 x (surface tension + viscosity) in o.ax and takes W without its kW)
 #else
         o.st_m = fdiv(c.st, v.w);
 #endif
@@ -172,8 +172,8 @@ struct NonPressurePass {
 #if SPH_FAST
         // scalar-coefficient form (see WcsphForcePass::pair): o.ax accumulates rho0 x (surface tension + viscosity), one fma per component
         if (AF || bj.w >= 0.0f) {
-            const float w = r2 > c.diameter2 ? kernW(c, g) : c.Wd;
-            float k = -((o.st_m * a.w) * w);                       // (st_m carries the rho0)
+            const float w = r2 > c.diameter2 ? kernWpoly(g) : c.Wd_poly;
+            float k = -((o.st_m * a.w) * w);                       // (st_m carries rho0 and kW)
             if (!skip_viscosity) {
                 const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
                 const float m_ij = (o.m + a.w) * 0.5f;
@@ -404,7 +404,7 @@ struct WcsphForcePass {
         o.vx = v.x; o.vy = v.y; o.vz = v.z; o.m = v.w;
         o.rho = rho_raw[i];
 #if SPH_FAST
-        o.st_m = fdiv(c.st, v.w) * c.rho0;   // (the fast pair() keeps rho0 x (surface tension + viscosity) in o.ax)
+        o.st_m = (fdiv(c.st, v.w) * c.rho0) * c.kW;   // (the fast pair() keeps rho0 x (surface tension + viscosity) in o.ax and takes W without its kW)
 #else
         o.st_m = fdiv(c.st, v.w);
 #endif
@@ -429,7 +429,7 @@ struct WcsphForcePass {
         const float gs = kernGradScale(c, g);
         const float v_xy = (o.vx - bj.x) * dx + (o.vy - bj.y) * dy + (o.vz - bj.z) * dz;
         if (AF || bj.w >= 0.0f) {
-            const float w = r2 > c.diameter2 ? kernW(c, g) : c.Wd;
+            const float w = r2 > c.diameter2 ? kernWpoly(g) : c.Wd_poly;            // (kW sits in st_m)
             const float cw = (UM ? o.cstm : o.st_m * a.w) * w;                      // surface tension (:210), times rho0
             const float cvm = UM ? o.cvm : c.cv * ((o.m + a.w) * 0.5f);             // viscosity (:232); UM: (m + m) / 2 = m exactly
             const float cc = fdiv2(cvm, bj.w, r2 + c.visc_eps) * v_xy;
