@@ -77,11 +77,19 @@ struct DensityPass {
     }
     __device__ void pair(const Consts &c, Own &o, float, float, float, float r2, const float4 &a, const BT &,
                          int) const {
+#if SPH_FAST
+        o.sum += a.w * kernWpoly(geom(c, r2));   // kW is applied to the sum (finish): one multiply less per pair
+#else
         o.sum += a.w * kernW(c, geom(c, r2));
+#endif
     }
     __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
         float den = pi.w * c.W0;
+#if SPH_FAST
+        den += c.kW * o.sum;
+#else
         den += o.sum;
+#endif
         den *= c.rho0;
         if (EOS) {
             rho_raw[i] = den;

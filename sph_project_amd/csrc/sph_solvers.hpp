@@ -35,7 +35,11 @@ struct DfsphDensityAlphaPass {
                          int) const {
         const Geom g = geom(c, r2);
         const float V = fabsf(a.w);
+#if SPH_FAST
+        o.sum += V * kernWpoly(g);   // kW is applied to the sum (finish)
+#else
         o.sum += V * kernW(c, g);
+#endif
         float gx, gy, gz;
         kernGrad(c, dx, dy, dz, g, gx, gy, gz);
         const float px = -V * gx, py = -V * gy, pz = -V * gz;
@@ -44,7 +48,11 @@ struct DfsphDensityAlphaPass {
     }
     __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
         float den = pi.w * c.W0;
+#if SPH_FAST
+        den += c.kW * o.sum;
+#else
         den += o.sum;
+#endif
         den *= c.rho0;
         rho[i] = den;
         float s = o.s3;
@@ -93,7 +101,11 @@ struct DfsphDensityAlphaDivPass {
     __device__ void pair(const Consts &c, Own &o, float dx, float dy, float dz, float r2, const float4 &a, const BT &bj, int) const {
         const Geom g = geom(c, r2);
         const float V = fabsf(a.w);
+#if SPH_FAST
+        o.sum += V * kernWpoly(g);   // kW is applied to the sum (finish)
+#else
         o.sum += V * kernW(c, g);
+#endif
         float gx, gy, gz;
         kernGrad(c, dx, dy, dz, g, gx, gy, gz);
         const float px = -V * gx, py = -V * gy, pz = -V * gz;
@@ -105,7 +117,11 @@ struct DfsphDensityAlphaDivPass {
     }
     __device__ float finish(const Consts &c, int i, const float4 &pi, Own &o) const {
         float den = pi.w * c.W0;
+#if SPH_FAST
+        den += c.kW * o.sum;
+#else
         den += o.sum;
+#endif
         den *= c.rho0;
         rho[i] = den;
         float s = o.s3;
