@@ -168,6 +168,7 @@ static void fill_consts(SphHandle *h) {
     const float d = (float)(2.0 * p.particle_radius);
     c.Wd = host_kernel_W(hd, sqrtf(d * d + 0.0f + 0.0f));
     c.kGh = c.kG * c.inv_h;
+    c.inv_h2 = c.inv_h * c.inv_h;
     c.Wd_poly = c.Wd / c.kW;
     const double dd = 2.0 * p.particle_radius;
     c.diameter2 = (float)(dd * dd);

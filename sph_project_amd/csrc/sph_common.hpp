@@ -43,6 +43,7 @@ struct Consts {
     float h, h2, inv_h;     // support radius, squared, reciprocal (fast build)
     float kW, kG;           // cubic spline constants (base_solver.py:57, :81)
     float kGh, Wd_poly;     // fast build: kG / h; kernel_W(particle diameter) / kW (the polynomial alone)
+    float inv_h2;           // fast build: 1 / h^2
     float W0, Wd;           // kernel_W(0), kernel_W(particle diameter)
     float diameter2;
     float dt, inv_dt, rho0, inv_rho0, g_upper;

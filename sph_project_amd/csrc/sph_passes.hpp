@@ -78,7 +78,11 @@ struct DensityPass {
     __device__ void pair(const Consts &c, Own &o, float, float, float, float r2, const float4 &a, const BT &,
                          int) const {
 #if SPH_FAST
-        o.sum += a.w * kernWpoly(geom(c, r2));   // kW is applied to the sum (finish): one multiply less per pair
+        // W / kW from q^2 = r^2 / h^2 and one v_sqrt (the gradient passes need 1 / r and go through v_rsq; here three VALU less per pair);
+        // kW is applied to the sum (finish)
+        const float q2 = r2 * c.inv_h2, q = __builtin_amdgcn_sqrtf(q2), t = 1.0f - q;
+        const float lo = 1.0f - (6.0f * q2) * t, hi = 2.0f * (t * t * t);
+        o.sum += a.w * (q <= 0.5f ? lo : hi);
 #else
         o.sum += a.w * kernW(c, geom(c, r2));
 #endif
