@@ -512,8 +512,10 @@ __device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int
     // (mask = 2 mask + VCC): two VOPC/VOP2 instructions per slot, no SGPR-pair results, no shift constants.
     // After S pushes slot t sits at bit S-1-t.
     unsigned mask = 0;
-    int S = 0;
-    for (int t0 = 0; __any(t0 < m); t0 += 8) {
+    int S = 0;   // (== t0 behind the loop: one counter)
+    int t0 = 0;
+    do {   // bottom-tested (a top-tested loop keeps a copy of t0 and of the mask for its exit: two moves per chunk, 72 -> 67 VALU); a wave
+           // whose lanes ALL have an empty run tests one chunk at its base for nothing (reads inside the tile, bits dropped below)
         // All 16 ds_read_b64 of the chunk are issued back to back from one base register with immediate
         // offsets and waited for once (hand-placed: left to itself the scheduler keeps at most one candidate
         // in flight, or fuses neighbours into ds_read2_b64 = 8 LDS cycles per 16 bytes).
@@ -526,7 +528,7 @@ __device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int
                 const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zz[u];
                 const float r2 = dx * dx + dy * dy + dz * dz;
                 asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                    : "+v"(mask) : "v"(r2), "v"(h2) : "vcc");  // not volatile: ordered by the dependence on mask
+                    : "+v"(mask) : "v"(r2), "s"(h2) : "vcc");  // not volatile: ordered by the dependence on mask
             }
         } else {
 #pragma unroll
@@ -539,12 +541,13 @@ __device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int
                     const float dx = xi - xy[u].x, dy = yi - xy[u].y, dz = zi - zz[u];
                     const float r2 = dx * dx + dy * dy + dz * dz;
                     asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                        : "+v"(mask) : "v"(r2), "v"(h2) : "vcc");
+                        : "+v"(mask) : "v"(r2), "s"(h2) : "vcc");
                 }
             }
         }
-        S += 8;
-    }
+        t0 += 8;
+    } while (__any(t0 < m));
+    S = t0;
     unsigned nm = S > 0 ? __brev(mask) >> (32 - S) : 0u;   // bit t = slot t
     nm &= m >= 32 ? 0xffffffffu : ((1u << m) - 1u);        // drop slots past this lane's run
     return nm;
@@ -900,8 +903,12 @@ template <class P, int MASKMODE> constexpr int nbr_lds_bytes() {
 #ifndef SPH_NBR_WAVES_HEAVY
 #define SPH_NBR_WAVES_HEAVY (SPH_FAST ? 4 : 3)   // strict build (IEEE division / sqrt sequences): 3, i.e. <= 168 VGPRs, rather than spills
 #endif
+// P::MAX_WAVES: a functor that runs rarely and would spill at its class's register budget asks for fewer waves (RigidVolumePass)
+template <class P, class = void> struct PassMaxWaves { static constexpr int value = 8; };
+template <class P> struct PassMaxWaves<P, decltype((void)P::MAX_WAVES)> { static constexpr int value = P::MAX_WAVES; };
 template <class P, int MASKMODE> constexpr int nbr_waves_per_simd() {
-    return P::HAS_B ? (pass_is_medium<P>() ? 5 : SPH_NBR_WAVES_HEAVY) : (sizeof(typename P::Own) <= 8 ? SPH_NBR_WAVES_LIGHT : 4);
+    const int w = P::HAS_B ? (pass_is_medium<P>() ? 5 : SPH_NBR_WAVES_HEAVY) : (sizeof(typename P::Own) <= 8 ? SPH_NBR_WAVES_LIGHT : 4);
+    return w < PassMaxWaves<P>::value ? w : PassMaxWaves<P>::value;
 }
 template <class P, int MASKMODE>
 __global__ void __launch_bounds__(P::BLOCK, (nbr_waves_per_simd<P, MASKMODE>()))

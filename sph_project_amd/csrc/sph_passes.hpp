@@ -545,6 +545,7 @@ struct WcsphForcePass {
 // base_solver.py:106 compute_rigid_particle_volume (+task :117).  i rigid, j same object.
 struct RigidVolumePass {
     static constexpr int MODES = 0b001;               // runs before the density pass (no masks yet), rarely
+    static constexpr int MAX_WAVES = 5;               // (one register over the six-wave budget since phase 1 became bottom-tested; it runs once per body)
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = false;
     static constexpr bool HAS_B = false, COUNT_PAIRS = false;
