@@ -302,7 +302,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.cell_count_clean = 1;
     CHK_CREATE(dalloc(h, &s.rho_raw, cap)); CHK_CREATE(dalloc(h, &s.prs, cap)); CHK_CREATE(dalloc(h, &s.ptm, cap));
     CHK_CREATE(dalloc(h, &s.acc, cap));
-    s.nbr_mask = nullptr; s.masks_valid = 0;
+    s.nbr_mask = nullptr; s.masks_valid = 0; s.density_books_forces = 0; s.uniform_mass = 0;
     s.nbr_mask_hi = nullptr;
     if (!getenv("SPH_NO_MASK_REUSE")) { CHK_CREATE(dalloc(h, &s.nbr_mask, cap * 9 + 256)); CHK_CREATE(dalloc(h, &s.nbr_mask_hi, cap * 9 + 256)); }   // + 256: the lanes past the last particle of the last tile read (and drop) a word too
     s.lane_perm = nullptr; s.perm_n = -1;

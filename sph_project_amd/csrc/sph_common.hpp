@@ -234,6 +234,7 @@ struct State {
     unsigned *nbr_mask;  // [9][cap]: acceptance mask of the first 32 candidates of every (particle, run), see process_run
     unsigned *nbr_mask_hi;  // [9][cap]: candidates 32..63 of the runs that have them
     int masks_valid;
+    int density_books_forces;   // WCSPH step with the fused force pass: the density pass counts that pass's pairs too (it walks the same masks)
     int uniform_mass;    // all-fluid scene whose particles all carry the same mass (sph_api.hip refresh_counts): WcsphForcePass<true, true>
     // device-controlled solver loops (sph_steps.hpp device_loop): every kernel of an iteration starts with a look at
     // scal->flags[0] (stop) when loop_flag is set; the iteration's reduction kernel evaluates the stop criterion itself

@@ -464,6 +464,8 @@ template <class P, class = void> struct PassWrench { static constexpr bool value
 template <class P> struct PassWrench<P, decltype((void)P::HAS_WRENCH)> { static constexpr bool value = P::HAS_WRENCH; };
 __device__ __forceinline__ void wrench_init_all(const RigidPose *pose);
 __device__ __forceinline__ void wrench_flush_all(DevScalars *scal);
+template <class P, class = void> struct PassStatW { static constexpr bool value = false; };
+template <class P> struct PassStatW<P, decltype((void)P::STAT_W)> { static constexpr bool value = P::STAT_W; };
 template <class P, class = void> struct PassPrologue { static constexpr bool value = false; };
 template <class P> struct PassPrologue<P, decltype((void)P::HAS_PROLOGUE)> { static constexpr bool value = P::HAS_PROLOGUE; };
 
@@ -1043,11 +1045,10 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
         e0 = (lin - cfirst) + (z0 - cz) + 1;   // s_cs entry of (.., .., z0) in every run
         e1 = e0 + (z1 - z0) + 1;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int xx = cx + k / 3 - 1, yy = cy + k % 3 - 1;
-            if (xx >= 0 && xx < c.nx && yy >= 0 && yy < c.ny) dom |= 1u << k;
-        }
+        // bit k = 3 (ox + 1) + (oy + 1): column (cx + ox, cy + oy) lies inside the grid.  The three y bits, copied to where the x offsets
+        // that exist put them (nine range tests -> four)
+        const unsigned by = (cy > 0 ? 1u : 0u) | 2u | (cy < c.ny - 1 ? 4u : 0u);
+        dom = (cx > 0 ? by : 0u) | (by << 3) | (cx < c.nx - 1 ? by << 6 : 0u);
     }
     if (skip_tile) return;   // (uniform)
     if (__syncthreads_or(active ? 1 : 0)) {  // workgroup-uniform; also publishes s_cs
@@ -1294,14 +1295,18 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         }
         if constexpr (PassWrench<P>::value) { __syncthreads(); wrench_flush_all(scal); }   // six atomics per body and workgroup that touched it
         if (P::COUNT_PAIRS) {
+            // (P::STAT_W: the functor carries its weights -- the WCSPH density pass also books the fused force pass, which walks the same
+            //  accepted pairs out of the stored masks and does not count them again)
+            unsigned long long wp = P::PAIR_WEIGHT, we = 1ull;
+            if constexpr (PassStatW<P>::value) { wp = (unsigned long long)p.stat_pairs; we = (unsigned long long)p.stat_evals; }
             float fp = wave_sum((float)npairs);  // <= 64 * few hundred: exact in f32
             if ((tid & 63) == 0 && fp > 0.0f) {
                 // two 64-bit tallies per slot: pairs weighted by the reference passes this walk stands for (SURVEY 8d
                 // metric) and pairs as evaluated.  (They used to share one word, 32 bits each: hundreds of solver
                 // iterations over ~2^28 particles could carry from one into the other.)
                 const int slot = (b * (BLOCK / 64) + (tid >> 6)) & (SPH_STAT_SLOTS - 1);
-                atomicAdd(&scal->pairs[c.stat_bank][slot], (unsigned long long)fp * P::PAIR_WEIGHT);
-                atomicAdd(&scal->evals[c.stat_bank][slot], (unsigned long long)fp);
+                atomicAdd(&scal->pairs[c.stat_bank][slot], (unsigned long long)fp * wp);
+                atomicAdd(&scal->evals[c.stat_bank][slot], (unsigned long long)fp * we);
             }
         }
     }

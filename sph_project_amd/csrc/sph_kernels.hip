@@ -175,12 +175,13 @@ void l_density(State &s, int eos) {
     HaloFieldSend fs = s.fieldsend;
     if (!eos) fs.on = 0;
     s.fieldsend.on = 0;
+    const int sp = s.density_books_forces ? 1 + 3 : 1, se = s.density_books_forces ? 2 : 1;   // (WcsphForcePass: PAIR_WEIGHT 3, one evaluation per pair)
     if (s.c.all_fluid) {
-        if (eos) { DensityPass<true, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs}; launch_pass(s, p, 1); }
-        else { DensityPass<true, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs}; launch_pass(s, p, 1); }
+        if (eos) { DensityPass<true, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_pass(s, p, 1); }
+        else { DensityPass<true, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_pass(s, p, 1); }
     } else {
-        if (eos) { DensityPass<false, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs}; launch_pass(s, p, 1); }
-        else { DensityPass<false, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs}; launch_pass(s, p, 1); }
+        if (eos) { DensityPass<false, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_pass(s, p, 1); }
+        else { DensityPass<false, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_pass(s, p, 1); }
     }
 }
 

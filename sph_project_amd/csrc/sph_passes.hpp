@@ -66,6 +66,8 @@ struct DensityPass {
     const float4 *posv; const int *meta;
     float *rho_raw, *rho, *prs, *ptm;
     HaloFieldSend fs;   // slab sharding (EOS form only): boundary values go straight into the neighbours' field message; fs.on = 0 otherwise
+    static constexpr bool STAT_W = true;
+    int stat_pairs, stat_evals;   // weights of this walk's accepted pairs in the pair statistics (1, 1; 4, 2 when it books the fused force pass too)
 
     __device__ float4 loadA(int j) const { return posv[j]; }
     __device__ BT loadB(int) const { return 0; }
@@ -366,7 +368,8 @@ struct WcsphForcePass {
     static constexpr bool HAS_WRENCH = !AF;
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
-    static constexpr bool HAS_B = true, HAS_C = true, COUNT_PAIRS = true;
+    static constexpr bool HAS_B = true, HAS_C = true;
+    static constexpr bool COUNT_PAIRS = false;   // booked by the density pass that stored the masks this pass walks (DensityPass::stat_pairs)
 #ifndef SPH_FORCE_MASK_PIPE
 #define SPH_FORCE_MASK_PIPE 0
 #endif
