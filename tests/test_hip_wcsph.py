@@ -330,3 +330,51 @@ def test_bench_line_contract(gpu):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["value"] > d["cpu_baseline"]["value"] > 0
+
+
+def _run_fast(cfg, steps, jitter=0.003, seed=2):
+    container, solver = H.build_product(cfg, jitter=jitter, seed=seed, fast_math=1)
+    solver.prepare()
+    for _ in range(steps):
+        solver.step()
+    e = container.engine
+    return e.download(L.F_PARTICLE_ID), e.download(L.F_POSITION), e.download(L.F_VELOCITY), e.download(L.F_DENSITY)
+
+
+def test_uniform_mass_force_pass_is_the_generic_one_bit_for_bit(gpu, monkeypatch):
+    """A scene with ONE fluid mass runs WcsphForcePass<true, true> in the fast build (the products with the mass hoisted out of the pair
+    loop): the same roundings in the same order, so every field must be bit-identical to the generic instantiation (SPH_NO_UNIFORM_MASS)."""
+    cfg = H.dam_break_scene(end=(0.3, 0.26, 0.22), translation=(0.13, 0.11, 0.07))
+    monkeypatch.delenv("SPH_NO_UNIFORM_MASS", raising=False)
+    a = _run_fast(cfg, 40)
+    monkeypatch.setenv("SPH_NO_UNIFORM_MASS", "1")
+    b = _run_fast(cfg, 40)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("fast_math", [0, 1])
+def test_two_fluid_masses_against_the_oracle(gpu, fast_math):
+    """Two touching fluid blocks of different density (masses 8e-3 and 5.6e-3): m_ij = (m_i + m_j) / 2 and the neighbour's mass in every
+    pair term matter (base_solver.py:136-240) -- the uniform-mass instantiation would be wrong here and must not be chosen."""
+    cfg = H.dam_break_scene(end=(0.16, 0.2, 0.16), translation=(0.1, 0.1, 0.1), velocity=(0.2, 0.0, 0.0))
+    second = dict(cfg["FluidBlocks"][0], objectId=1, translation=[0.27, 0.107, 0.093], density=700.0, velocity=[-0.2, 0.0, 0.0], color=[200, 100, 50])
+    cfg["FluidBlocks"].append(second)
+    container, solver = H.build_product(cfg, fast_math=fast_math)   # (no jitter: the helpers perturb a multi-block scene block by block / all at once)
+    solver.prepare()
+    ref = H.build_oracle(cfg)
+    ref.prepare()
+    np.testing.assert_array_equal(container.engine.download(L.F_POSITION), ref.field("particle_positions"))
+    m = container.engine.download(L.F_MASS)
+    assert len(np.unique(m)) == 2
+    solver.step()
+    ref.step(1)
+    assert solver.stats()["pair_interactions"] == ref.last_pairs     # (later, pairs at the edge of the support flip with the last bits)
+    for _ in range(9):
+        solver.step()
+    ref.step(9)
+    a, b = _state(container), _ref_state(ref)
+    assert abs(solver.stats()["pair_interactions"] - ref.last_pairs) <= 1e-3 * ref.last_pairs
+    d = H.drift(a["x"], b["x"], container.dh)
+    assert d.max() <= 1e-5, d.max()
+    np.testing.assert_allclose(a["v"], b["v"], rtol=0, atol=5e-5 * float(np.abs(b["v"]).max()))
