@@ -44,6 +44,7 @@ struct SphHandle {
     double total_time = 0.0;
     bool prepared = false;
     bool pose_dirty = false;
+    bool pose_given = false;     // sph_set_rigid_pose was called: pose_h holds library-frame vectors of the CURRENT axis order
     bool rigid_volume_done = false;
     bool sort_dirty = false;      // particles appended since the last sort
     bool in_step = false;         // between sph_step_begin and sph_step_end
@@ -471,6 +472,7 @@ extern "C" int sph_set_rigid_pose(SphHandle *h, int o, const float *com, const f
         for (int q = 0; q < 3; ++q) h->pose_h.rot[o][3 * a + q] = rot9[3 * b + h->perm[q]];
     }
     h->pose_dirty = true;
+    h->pose_given = true;
     return upload_pose(h);
 }
 

@@ -202,6 +202,9 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
         const bool slow = lay && (lay[0] == 's' || lay[0] == 'S');
         const char *ord = getenv("SPH_AXIS_ORDER");
         if (slow) {
+            // (the permutation is derived HERE, after sph_create: a pose pushed earlier sits in pose_h in the old library frame and would
+            //  be silently wrong -- ADVICE r04; poses go in after the slab is set)
+            if (h->pose_given) return fail(h, SPH_ERR_INVALID, "comm_set_slab: SPH_SLAB_LAYOUT=slow changes the library frame; call sph_set_rigid_pose after sph_comm_set_slab, not before");
             if (!set_axis_order(h, ord ? ord : "zxy") || h->perm[0] != 2)
                 return fail(h, SPH_ERR_INVALID, "comm_set_slab: with SPH_SLAB_LAYOUT=slow, SPH_AXIS_ORDER must be a permutation of xyz that starts with z");
             h->slab_axis = 0;

@@ -52,10 +52,10 @@ static int write_ply_ascii(const char *path, const float *xyz, int64_t n) {
     if (!path || n < 0 || (n > 0 && !xyz)) return -1;
     FILE *f = fopen(path, "wb");
     if (!f) return -2;
-    fprintf(f, "ply\nformat ascii 1.0\ncomment created by PLYWriter\nelement vertex %lld\nproperty float x\nproperty float y\nproperty float z\nend_header\n", (long long)n);
+    int rc = 0;
+    if (fprintf(f, "ply\nformat ascii 1.0\ncomment created by PLYWriter\nelement vertex %lld\nproperty float x\nproperty float y\nproperty float z\nend_header\n", (long long)n) < 0) rc = -3;
     std::vector<char> buf(1 << 20);
     size_t used = 0;
-    int rc = 0;
     for (int64_t i = 0; i < n && rc == 0; ++i) {
         if (used + 3 * 48 + 4 > buf.size()) { if (fwrite(buf.data(), 1, used, f) != used) rc = -3; used = 0; }
         for (int c = 0; c < 3; ++c) { used += (size_t)format_f32(xyz[3 * i + c], buf.data() + used); buf[used++] = ' '; }

@@ -235,6 +235,15 @@ void l_pressure_integrate(State &s) {
 
 // WCSPH.py:30-36, 45 as one pass (see WcsphForcePass); same buffer choreography as the two passes it replaces
 void l_wcsph_forces(State &s) {
+    if (!s.density_books_forces) {   // launched outside wcsph_step's density + forces pair: nobody has booked this walk's pairs
+        if (s.c.all_fluid) {
+            WcsphForcePass<true, false, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend};
+            launch_pass(s, p, 2);
+        } else {
+            WcsphForcePass<false, false, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend};
+            launch_pass(s, p, 2);
+        }
+    } else
 #if SPH_FAST
     if (s.c.all_fluid && s.uniform_mass && !s.slab_active) {   // one fluid mass in the whole scene: the instantiation with the mass products hoisted (same sums)
         WcsphForcePass<true, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend};

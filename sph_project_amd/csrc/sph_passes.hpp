@@ -111,11 +111,15 @@ struct DensityPass {
             const float pt = pr / (rc * rc);
             ptm[i] = pt;
             if (fs.on) {   // (uniform) layout of a field message: [ my n_send records | the records I received from that side ], k_halo_pack2
+                // (bounded by this step's CLAMPED counts: after SLAB_ST_SEND_OVERFLOW k_halo_classify still tags particles with k >= rec_cap,
+                //  and the neighbour's field region -- IPC-mapped remote memory -- holds 2 rec_cap entries)
                 const int x = fs.xidx[i], kind = HALO_KIND(x), k = HALO_IDX(x);
-                if (kind == HALO_SEND || kind == HALO_SEND + 1) { if (fs.out[kind - HALO_SEND]) fs.out[kind - HALO_SEND][k] = make_float4(den, rc, pr, pt); }
-                else if (kind == HALO_ECHO_SEND || kind == HALO_ECHO_SEND + 1) {
+                if (kind == HALO_SEND || kind == HALO_SEND + 1) {
+                    const int side = kind - HALO_SEND;
+                    if (fs.out[side] && k < fs.dyn->n_send[side]) fs.out[side][k] = make_float4(den, rc, pr, pt);
+                } else if (kind == HALO_ECHO_SEND || kind == HALO_ECHO_SEND + 1) {
                     const int side = kind - HALO_ECHO_SEND;
-                    if (fs.out[side]) fs.out[side][fs.dyn->n_send[side] + k] = make_float4(den, rc, pr, pt);
+                    if (fs.out[side] && k < fs.dyn->n_recv[side]) fs.out[side][fs.dyn->n_send[side] + k] = make_float4(den, rc, pr, pt);
                 }
             }
         } else {
@@ -362,14 +366,17 @@ struct PressurePass {
 // update sequence (v* = v + dt a_np; v = v* + dt a_p; x += dt v; boundary) with the same roundings.
 // Per candidate: A = (x, y, z, m_j | rho0 V_j), B = (v_j, rho_raw_j | -1 static / -2 dynamic rigid), C = p_j / rho_j^2.
 // Bytes / particle: R posv 16 + velm 16 + rho_raw 4 + ptm 4 (+ own prs, rho 8) -> W acc 16 + posv 16 + velm 16.
-template <bool AF, bool UM = false>   // UM (fast build, all fluid): every particle carries the same mass -- m_ij = m, the products with it are hoisted
-
+// CNT: the pass counts its own accepted pairs.  Inside wcsph_step they are booked by the density pass whose masks it walks
+// (DensityPass::stat_pairs, State::density_books_forces); a caller that launches this pass any other way gets the counting
+// instantiation (l_wcsph_forces), so that pair_interactions never under-reports.
+template <bool AF, bool UM = false, bool CNT = false>   // UM (fast build, all fluid): every particle carries the same mass -- m_ij = m, the products with it are hoisted
 struct WcsphForcePass {
     static constexpr bool HAS_WRENCH = !AF;
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, HAS_C = true;
-    static constexpr bool COUNT_PAIRS = false;   // booked by the density pass that stored the masks this pass walks (DensityPass::stat_pairs)
+    static constexpr bool COUNT_PAIRS = CNT;     // false: booked by the density pass that stored the masks this pass walks (DensityPass::stat_pairs)
+    static constexpr int MAX_WAVES = CNT ? (SPH_FAST ? 4 : 3) : 8;   // (the rarely used counting instantiation takes its class's register budget, never less)
 #ifndef SPH_FORCE_MASK_PIPE
 #define SPH_FORCE_MASK_PIPE 0
 #endif

@@ -68,7 +68,7 @@ static int wcsph_step(SphHandle *h) {
     if (s.slab_active) { int rc = slab_neighbor_search(h, fused); if (rc) return rc; }
     else ph_neighbor_search(h);                                               // WCSPH.py:28
     ph_rigid_volume(h);                                                       // base_solver.py:696 (see ph_rigid_volume)
-    s.density_books_forces = fused ? 1 : 0;
+    s.density_books_forces = (fused && !getenv("SPH_FORCES_COUNT_OWN")) ? 1 : 0;   // (switch: the force pass counts its own pairs -- the counting instantiation any other caller of l_wcsph_forces gets)
     struct Unbook { State &s; ~Unbook() { s.density_books_forces = 0; } } unbook{s};
     // Sharded over the push transport, fluid only: the density pass runs the slab's BOUNDARY tiles first, their rho / p go out to the
     // neighbours, and the INTERIOR tiles (everything more than two layers from a face) run while that message is in flight; only

@@ -354,6 +354,36 @@ def test_uniform_mass_force_pass_is_the_generic_one_bit_for_bit(gpu, monkeypatch
 
 
 @pytest.mark.parametrize("fast_math", [0, 1])
+@pytest.mark.parametrize("with_plate", [False, True], ids=["fluid", "rigid"])
+def test_force_pass_that_counts_its_own_pairs(gpu, monkeypatch, fast_math, with_plate):
+    """ADVICE r04: the fused force pass leaves its pair statistics to the density pass whose masks it walks (State::density_books_forces).
+    A launch that the density pass did not book for must count itself (WcsphForcePass<AF, false, true>, chosen by l_wcsph_forces):
+    SPH_FORCES_COUNT_OWN makes wcsph_step take that road -- same state bit for bit, same pair_interactions, and the oracle's count."""
+    cfg = H.dam_break_scene(end=(0.3, 0.26, 0.22), translation=(0.13, 0.11, 0.07), add_domain_box=with_plate)
+    out = []
+    for own in (False, True):
+        if own:
+            monkeypatch.setenv("SPH_FORCES_COUNT_OWN", "1")
+        else:
+            monkeypatch.delenv("SPH_FORCES_COUNT_OWN", raising=False)
+        container, solver = H.build_product(cfg, fast_math=fast_math)
+        solver.prepare()
+        for _ in range(5):
+            solver.step()
+        e = container.engine
+        out.append((e.download(L.F_PARTICLE_ID), e.download(L.F_POSITION), e.download(L.F_VELOCITY), solver.stats()))
+    for k in range(3):
+        np.testing.assert_array_equal(out[0][k], out[1][k])
+    assert out[0][3]["pair_interactions"] == out[1][3]["pair_interactions"] > 0
+    assert out[0][3]["pair_evaluations"] == out[1][3]["pair_evaluations"]
+    ref = H.build_oracle(cfg)
+    ref.prepare()
+    ref.step(5)
+    if not fast_math:
+        assert out[1][3]["pair_interactions"] == ref.last_pairs
+
+
+@pytest.mark.parametrize("fast_math", [0, 1])
 def test_two_fluid_masses_against_the_oracle(gpu, fast_math):
     """Two touching fluid blocks of different density (masses 8e-3 and 5.6e-3): m_ij = (m_i + m_j) / 2 and the neighbour's mass in every
     pair term matter (base_solver.py:136-240) -- the uniform-mass instantiation would be wrong here and must not be chosen."""

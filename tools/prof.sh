@@ -8,7 +8,8 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --motion-step 0 $*"
+# BENCH_CMD="python $REPO/tools/bench_c5.py --no-events" tools/prof.sh <tag>  profiles another driver (C5)
+BENCH=${BENCH_CMD:-"python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --motion-step 0 $*"}
 [ -n "${SKIP_TRACE:-}" ] || timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $BENCH > $OUT/trace.log 2>&1
 i=0
 for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
