@@ -457,12 +457,62 @@ void sphref_wcsph_compute_pressure(SphRef *s) {
     }
 }
 
-static void add_rigid_wrench(SphRef *s, int obj, v3 force, v3 torque) {
-#pragma omp critical(sphref_wrench)
-    {
-        s->rigid_body_forces[obj] = v3_add(s->rigid_body_forces[obj], force);
-        s->rigid_body_torques[obj] = v3_add(s->rigid_body_torques[obj], torque);
+/* rigid_body_forces / _torques accumulate f32 sums over (fluid particle, rigid neighbour) pairs (base_solver.py:174-187, :272-278;
+ * DFSPH.py:173-203).  The reference's serial semantics add them in the order p_i ascending, neighbours in walk order.  A parallel
+ * loop that adds under a lock does it in whatever order the threads arrive (f32 addition does not commute in the last bits): the
+ * checker was noisier than the product, whose wrench is bit-reproducible since round 4.  Now every thread LOGS its pairs (a particle
+ * is walked by one thread, so its records are consecutive and in walk order), and flush_rigid_wrench() -- called behind each of the
+ * three loops -- sorts the records by particle and adds them up serially: the same bits as a single-threaded run, whatever the
+ * thread count or schedule. */
+typedef struct { int p_i, obj; long long seq; v3 f, t; } WrenchRec;
+#define SPHREF_MAX_THREADS 512
+static WrenchRec *wlog_[SPHREF_MAX_THREADS];
+static int wlen_[SPHREF_MAX_THREADS], wcap_[SPHREF_MAX_THREADS];
+
+static int omp_tid_(void) {
+#ifdef _OPENMP
+    extern int omp_get_thread_num(void);
+    return omp_get_thread_num() % SPHREF_MAX_THREADS;
+#else
+    return 0;
+#endif
+}
+
+static void add_rigid_wrench(SphRef *s, int p_i, int obj, v3 force, v3 torque) {
+    (void)s;
+    const int t = omp_tid_();
+    if (wlen_[t] == wcap_[t]) {
+        wcap_[t] = wcap_[t] ? 2 * wcap_[t] : 4096;
+        wlog_[t] = (WrenchRec *)realloc(wlog_[t], sizeof(WrenchRec) * (size_t)wcap_[t]);
     }
+    WrenchRec *r = &wlog_[t][wlen_[t]];
+    r->p_i = p_i; r->obj = obj; r->seq = wlen_[t]; r->f = force; r->t = torque;
+    wlen_[t]++;
+}
+
+static int wrench_cmp_(const void *a, const void *b) {
+    const WrenchRec *x = (const WrenchRec *)a, *y = (const WrenchRec *)b;
+    if (x->p_i != y->p_i) return x->p_i < y->p_i ? -1 : 1;
+    return x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0);   /* (same particle = same thread: its own order) */
+}
+
+static void flush_rigid_wrench(SphRef *s) {
+    size_t total = 0;
+    for (int t = 0; t < SPHREF_MAX_THREADS; t++) total += (size_t)wlen_[t];
+    if (!total) return;
+    WrenchRec *all = (WrenchRec *)malloc(sizeof(WrenchRec) * total);
+    size_t k = 0;
+    for (int t = 0; t < SPHREF_MAX_THREADS; t++) {
+        if (wlen_[t]) memcpy(all + k, wlog_[t], sizeof(WrenchRec) * (size_t)wlen_[t]);
+        k += (size_t)wlen_[t];
+        wlen_[t] = 0;
+    }
+    qsort(all, total, sizeof(WrenchRec), wrench_cmp_);
+    for (k = 0; k < total; k++) {
+        s->rigid_body_forces[all[k].obj] = v3_add(s->rigid_body_forces[all[k].obj], all[k].f);
+        s->rigid_body_torques[all[k].obj] = v3_add(s->rigid_body_torques[all[k].obj], all[k].t);
+    }
+    free(all);
 }
 
 /* base_solver.py:136 compute_pressure_acceleration (+task :147) */
@@ -499,7 +549,7 @@ void sphref_compute_pressure_acceleration(SphRef *s) {
                             v3 force_j = v3_scale(v3_scale_l(cf, nabla_ij),
                                                   s->density_0 * s->particle_rest_volumes[p_i]);
                             v3 torque_j = v3_cross(v3_sub(pos_i, com_j), force_j);
-                            add_rigid_wrench(s, object_j, force_j, torque_j);
+                            add_rigid_wrench(s, p_i, object_j, force_j, torque_j);
                         }
                     }
                 });
@@ -507,6 +557,7 @@ void sphref_compute_pressure_acceleration(SphRef *s) {
             }
         }
     }
+    flush_rigid_wrench(s);
     s->last_pairs += npairs_;
 }
 
@@ -577,13 +628,14 @@ void sphref_compute_viscosity_acceleration_standard(SphRef *s) {
                         v3 force_j = v3_div(v3_scale(v3_make(-acc.x, -acc.y, -acc.z), s->particle_masses[p_i]),
                                             s->density_0);
                         v3 torque_j = v3_cross(v3_sub(pos_j, com_j), force_j);
-                        add_rigid_wrench(s, object_j, force_j, torque_j);
+                        add_rigid_wrench(s, p_i, object_j, force_j, torque_j);
                     }
                 }
             });
             s->particle_accelerations[p_i] = v3_add(s->particle_accelerations[p_i], v3_div(a_i, s->density_0));
         }
     }
+    flush_rigid_wrench(s);
     s->last_pairs += npairs_;
 }
 
@@ -953,7 +1005,7 @@ static void dfsph_correct_step(SphRef *s, const float *kappa, int in_loop_update
                             v3 com_j = s->rigid_body_centers_of_mass[object_j];
                             v3 force_j = v3_scale(v3_div(t, s->dt), s->particle_rest_volumes[p_i] * s->density_0);
                             v3 torque_j = v3_cross(v3_sub(s->particle_positions[p_j], com_j), force_j);
-                            add_rigid_wrench(s, object_j, force_j, torque_j);
+                            add_rigid_wrench(s, p_i, object_j, force_j, torque_j);
                         }
                     }
                 }
@@ -962,6 +1014,7 @@ static void dfsph_correct_step(SphRef *s, const float *kappa, int in_loop_update
             else s->particle_velocities[p_i] = v3_add(s->particle_velocities[p_i], dv);
         }
     }
+    flush_rigid_wrench(s);
     s->last_pairs += npairs_;
 }
 

@@ -44,6 +44,7 @@ struct SphHandle {
     double total_time = 0.0;
     bool prepared = false;
     bool pose_dirty = false;
+    int loop_hint[4] = {0, 0, 0, 0};   // iterations the last solve of each device-controlled loop took (sph_steps.hpp device_loop), by reduction slot
     bool pose_given = false;     // sph_set_rigid_pose was called: pose_h holds library-frame vectors of the CURRENT axis order
     bool rigid_volume_done = false;
     bool sort_dirty = false;      // particles appended since the last sort
@@ -296,7 +297,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.orig.b[0] = s.orig.b[1] = nullptr;
     const size_t G = (size_t)s.c.G;
     CHK_CREATE(dalloc(h, &s.cell_count, G + SPH_NGRAVE + 1)); CHK_CREATE(dalloc(h, &s.cell_start, G + SPH_NGRAVE + 1));   // + graveyard cells (slab sharding)
-    CHK_CREATE(dalloc(h, &s.cellid, cap)); CHK_CREATE(dalloc(h, &s.rank, cap)); CHK_CREATE(dalloc(h, &s.tmp_idx, cap));
+    CHK_CREATE(dalloc(h, &s.cellid, cap)); CHK_CREATE(dalloc(h, &s.rank, cap)); CHK_CREATE(dalloc(h, &s.tmp_idx, 2 * cap));   // (int2 run records of the stable sort)
     s.scan_blocks = (int)((G + SPH_NGRAVE + 2047) / 2048);
     if (s.scan_blocks < SPH_STAT_SLOTS / 256) s.scan_blocks = SPH_STAT_SLOTS / 256;   // k_scan_final also clears the statistics slots
     CHK_CREATE(dalloc(h, &s.scan_partial, (size_t)s.scan_blocks + 1));

@@ -162,7 +162,7 @@ struct State {
     int *cell_count;     // G+1
     int *cell_start;     // G+1 (exclusive scan, cell_start[G] = n)
     int *cellid, *rank;  // per particle (pre-sort)
-    int *tmp_idx;        // stable-sort scratch (source index per sorted slot)
+    int *tmp_idx;        // stable-sort scratch: int2 (first source index, length) per run, filed at the run's first slot (2 x cap ints)
     int *scan_partial;   // block sums
     int scan_blocks;
     int cell_count_clean;              // cell_count is all zero (the scan clears it behind itself)

@@ -197,6 +197,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Runs of equal key among the consecutive lanes of a wave (the input of the sort is last step's sorted order, so a wave is a few
+// runs of ~8 particles that stay in their cell, plus strays): head = first lane of a run, hl = the head's lane, len = run length
+// (meaningful in the head lane).  k_hash_count, k_scatter_index and k_scatter<true> must see the same runs: same thread -> particle map.
+__device__ __forceinline__ void wave_runs(int key, int lane, bool &head, int &hl, int &len) {
+    const int prev = __shfl_up(key, 1, 64);
+    head = lane == 0 || key != prev;
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long upto = hm & ((2ull << lane) - 1ull);          // heads at or below this lane
+    hl = 63 - __clzll(upto);
+    const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
+    len = above ? __ffsll(above) : 64 - lane;
+}
+
 // ------------------------------------------------------------------ grid build
 // base_container.py:496 init_grid: cell id + histogram.  The atomic's return value is the
 // particle's arrival rank inside its cell, which replaces the second atomic pass of :515.
@@ -218,13 +231,8 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
     }
     // The input is the previous step's sorted order, so lanes of one wave fall into a few runs of equal
     // cell id.  One atomic per run (by its first lane) instead of one per particle: ~8x fewer L2 atomics.
-    const int prev = __shfl_up(lin, 1, 64);
-    const bool head = lane == 0 || lin != prev;
-    const unsigned long long hm = __ballot(head);
-    const unsigned long long upto = hm & ((2ull << lane) - 1ull);          // heads at or below this lane
-    const int hl = 63 - __clzll(upto);
-    const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
-    const int len = above ? __ffsll(above) : 64 - lane;                      // run length if this lane is a head
+    bool head; int hl, len;
+    wave_runs(lin, lane, head, hl, len);
     int base = 0;
     if (head && valid) base = atomicAdd(&cell_count[lin], len);
     base = __shfl(base, hl, 64);
@@ -317,15 +325,23 @@ k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total_dev ? *total_dev : total_particles;
 }
 
-// deterministic mode: list the source indices of every cell, so that the scatter can compute a
-// stable rank (= serial execution of base_container.py:510-515).
+// deterministic mode, first half: one record per RUN (first source index, length), filed at the slot the run's first particle got
+// from the histogram atomics.  The slots [cell_start[c], cell_start[c + 1]) of a cell are partitioned by its runs (one atomicAdd of
+// `len` per run, k_hash_count), so a walk from cell_start[c] that jumps by the recorded lengths visits exactly the run records;
+// the slots inside a run are never read.  (Until round 5 this kernel listed every particle's source index and the scatter counted,
+// per particle, the entries of its cell below its own index: one dependent L2 round trip per cell-mate -- 8 at rest, 16-24 where the
+// fluid has piled up: the scatter went from 23.5 to 49 us in motion, profiles/r04_c2_in_motion_per_kernel.txt.)
 __global__ void __launch_bounds__(256)
 k_scatter_index(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
-                const int *__restrict__ cell_start, int *__restrict__ tmp_idx, const int *__restrict__ n_dev) {
-    int i = blockIdx.x * 256 + threadIdx.x;
+                const int *__restrict__ cell_start, int2 *__restrict__ runs, const int *__restrict__ n_dev) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     if (n_dev) n = *n_dev;
-    if (i >= n) return;
-    tmp_idx[cell_start[cellid[i]] + rank[i]] = i;
+    const bool valid = i < n;
+    const int cell = valid ? cellid[i] : -1 - lane;
+    bool head; int hl, len;
+    wave_runs(cell, lane, head, hl, len);
+    if (valid && head) runs[cell_start[cell] + rank[i]] = make_int2(i, len);
 }
 
 struct SortArrays {
@@ -346,21 +362,39 @@ struct SortArrays {
 template <bool STABLE>
 __global__ void __launch_bounds__(256)
 k_scatter(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
-          const int *__restrict__ cell_start, const int *__restrict__ tmp_idx, SortArrays a, const int *__restrict__ n_dev) {
-    int i = blockIdx.x * 256 + threadIdx.x;
+          const int *__restrict__ cell_start, const int2 *__restrict__ runs, SortArrays a, const int *__restrict__ n_dev) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     if (n_dev) n = *n_dev;
-    if (i >= n) return;
-    int cell = cellid[i];
-    int s = cell_start[cell];
-    int r;
-    if (STABLE && cell < a.G) {   // the graveyard cell (slab sharding) may hold 1e5 particles nobody looks at again
-        int e = cell_start[cell + 1];
-        r = 0;
-        for (int k = s; k < e; ++k) r += tmp_idx[k] < i ? 1 : 0;
-    } else {
+    const bool valid = i < n;
+    const int cell = valid ? cellid[i] : -1 - lane;
+    int r = 0, s = 0;
+    if (STABLE) {
+        // stable rank = serial execution of base_container.py:510-515 = number of particles of the same cell with a lower source index
+        //             = (lengths of the cell's runs that start below this particle's run) + (position inside its own run)
+        bool head; int hl, len;
+        wave_runs(cell, lane, head, hl, len);
+        int r0 = 0;
+        if (valid) s = cell_start[cell];
+        if (valid && head && cell < a.G) {   // (a graveyard cell of the slab sharding may hold 1e5 particles nobody looks at again)
+            const int e = cell_start[cell + 1];
+            if (e - s != len) {              // other runs share the cell (at rest: only where a cell straddles two waves)
+                for (int p = s; p < e;) {
+                    const int2 rec = runs[p];
+                    r0 += rec.x < i ? rec.y : 0;
+                    p += rec.y > 0 ? rec.y : 1;
+                }
+            }
+        }
+        r0 = __shfl(r0, hl, 64);
+        r = r0 + (lane - hl);
+        if (valid && cell >= a.G) r = rank[i];
+    } else if (valid) {
+        s = cell_start[cell];
         r = rank[i];
     }
-    int d = s + r;
+    if (!valid) return;
+    const int d = s + r;
     a.posv_out[d] = a.posv_in[i];
     a.velm_out[d] = a.velm_in[i];
     a.meta_out[d] = a.meta_in[i];

@@ -85,17 +85,15 @@ void l_scatter_impl(State &s, bool stable) {
     a.rho_in = s.rho.cur(); a.rho_out = s.rho.alt();
     a.orig_in = s.orig.cur(); a.orig_out = s.orig.alt();
     a.xidx_in = s.slab_active ? s.xidx[s.xcur] : nullptr; a.xidx_out = s.slab_active ? s.xidx[1 - s.xcur] : nullptr;
-    int *tmp_idx = (int *)s.red_partial;  // reused scratch (sized >= n ints by the allocator)
     if (stable) {
         hipLaunchKernelGGL(k_scatter_index, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
-                           s.cell_start, s.tmp_idx, s.c.n_dev);
+                           s.cell_start, (int2 *)s.tmp_idx, s.c.n_dev);
         hipLaunchKernelGGL(k_scatter<true>, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
-                           s.cell_start, s.tmp_idx, a, s.c.n_dev);
+                           s.cell_start, (const int2 *)s.tmp_idx, a, s.c.n_dev);
     } else {
         hipLaunchKernelGGL(k_scatter<false>, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
-                           s.cell_start, s.tmp_idx, a, s.c.n_dev);
+                           s.cell_start, (const int2 *)s.tmp_idx, a, s.c.n_dev);
     }
-    (void)tmp_idx;
     s.posv.flip(); s.velm.flip(); s.meta.flip(); s.pid.flip(); s.color.flip(); s.rho.flip();
     s.masks_valid = 0;  // new order, new candidate runs
     if (!s.slab_active) l_block_prep(s);

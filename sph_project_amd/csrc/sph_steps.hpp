@@ -19,9 +19,15 @@ static long long dfsph_particle_num(SphHandle *h) { return h->st.slab_active ? h
 // Solver loop with the stop test on the device.  `body` launches one iteration; its last reduction kernel evaluates
 // the reference's criterion (kind / denom / thr, see State::loop_kind), counts the iteration and raises
 // scal->flags[0]; every kernel of a later iteration starts with a look at that flag and returns.  Iterations go out in
-// growing batches (2, 4, 8, 8, ...) with ONE flag read-back per batch instead of one error read-back per iteration
-// (the reference, and this code before, synchronise with the host every iteration).  The state after the loop is the
-// state after exactly the iteration the reference would have stopped at.
+// batches with ONE read-back per batch instead of one error read-back per iteration (the reference, and this code before,
+// synchronise with the host every iteration).  The state after the loop is the state after exactly the iteration the
+// reference would have stopped at, whatever the batch sizes.
+// Batch sizes (round 5): a solve takes about as many iterations as the same solve of the last step (C5: 41.5 +- 1 CG
+// iterations; C3 in motion: 26.5 +- 1 density iterations), so the FIRST batch is last step's count less one and the
+// loop then goes on in small batches -- two read-backs per solve instead of five to seven.  Every read-back is a
+// stream drain plus the host's launch latency before the GPU has work again (~25-40 us of idle chip: the rocprofv3
+// traces of round 5 show 188 us of kernels per DFSPH iteration in motion against 285 us of wall time, profiles/
+// r05_rocprofv3_c3_motion_summary.txt).  Without a hint (first step, SPH_NO_LOOP_HINT): 2, 4, 8, 8, ... as before.
 template <class F>
 static int device_loop(SphHandle *h, int max_itr, int slot, int kind, float denom, double thr, F body, int *executed,
                        int *launched, float *last_val, void (*batch_end)(State &) = nullptr) {
@@ -29,23 +35,29 @@ static int device_loop(SphHandle *h, int max_itr, int slot, int kind, float deno
     HIPCHK(h, hipMemsetAsync(&s.scal->flags[0], 0, 2 * sizeof(int), s.stream));
     s.loop_flag = &s.scal->flags[0];
     s.loop_slot = slot; s.loop_kind = kind; s.loop_denom = denom; s.loop_thr = thr;
-    int n_launched = 0, batch = 2, rc = SPH_OK;
+    static const bool no_hint = getenv("SPH_NO_LOOP_HINT") != nullptr;
+    const int hint = (no_hint || slot < 0 || slot >= 4) ? 0 : h->loop_hint[slot];
+    int n_launched = 0, batch = hint > 3 ? hint - 1 : 2, rc = SPH_OK;
+    bool predicted = hint > 3;
+    // red[8] and flags[4] are neighbours in DevScalars: one 48-byte copy brings the residual and the flags
+    static_assert(offsetof(DevScalars, flags) == offsetof(DevScalars, red) + 8 * sizeof(float), "red / flags layout");
     while (n_launched < max_itr) {
         const int nb = batch < max_itr - n_launched ? batch : max_itr - n_launched;
         for (int k = 0; k < nb; ++k) body();
         if (batch_end) batch_end(s);
         n_launched += nb;
-        hipError_t e = hipMemcpyAsync(h->scal_h->flags, s.scal->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s.stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(&h->scal_h->red[slot], &s.scal->red[slot], sizeof(float), hipMemcpyDeviceToHost, s.stream);
+        hipError_t e = hipMemcpyAsync(h->scal_h->red, s.scal->red, 8 * sizeof(float) + 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream);
         if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
         if (e != hipSuccess) { rc = fail(h, SPH_ERR_HIP, "solver loop read-back failed: %s", hipGetErrorString(e)); break; }
         if (h->scal_h->flags[0]) break;
-        if (batch < 8) batch *= 2;
+        if (predicted) { batch = 2; predicted = false; }
+        else if (batch < 8) batch *= 2;
     }
     s.loop_flag = nullptr;
     *executed = h->scal_h->flags[1];
     *launched = n_launched;
     *last_val = h->scal_h->red[slot];
+    if (slot >= 0 && slot < 4 && rc == SPH_OK) h->loop_hint[slot] = h->scal_h->flags[1];
     return rc;
 }
 
