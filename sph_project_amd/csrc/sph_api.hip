@@ -45,6 +45,7 @@ struct SphHandle {
     bool prepared = false;
     bool pose_dirty = false;
     int loop_hint[4] = {0, 0, 0, 0};   // iterations the last solve of each device-controlled loop took (sph_steps.hpp device_loop), by reduction slot
+    int dev_cus = 256;           // compute units of the device (sizing of grids that should be resident at once)
     bool pose_given = false;     // sph_set_rigid_pose was called: pose_h holds library-frame vectors of the CURRENT axis order
     bool rigid_volume_done = false;
     bool sort_dirty = false;      // particles appended since the last sort
@@ -256,6 +257,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
     if (dev >= ndev) { delete h; return fail(nullptr, SPH_ERR_NO_DEVICE, "sph_create: device %d not present", dev); }
     h->device = dev;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->dev_cus = cus; }
 #define CHK_CREATE(call)                                                                   \
     do {                                                                                   \
         int rc_ = (call);                                                                  \

@@ -183,6 +183,7 @@ struct CgApPass {
     float *part_dot;   // [3][dot_stride] per-workgroup partials of the split walks, or null
     int dot_stride;
     __device__ float *split_out(int g) const { return part_dot ? part_dot + (size_t)g * dot_stride : nullptr; }
+    __device__ void partial_zero(int i, int g) const { part[(size_t)g * part_stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ float partial(const Consts &c, int i, int g, const Own &o) const {
         float x = o.x, y = o.y, z = o.z;
         apply_dinv(i, x, y, z);

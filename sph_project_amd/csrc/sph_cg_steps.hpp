@@ -11,7 +11,11 @@ static int implicit_viscosity_non_pressure(SphHandle *h) {
     // pure latency; splitting it by x-offset group triples the waves in flight (PassSplit).  A scene that fills the chip
     // anyway (> ~1500 tiles) gains nothing from it and keeps the single launch.
     static const char *no_split = getenv("SPH_NO_CG_SPLIT");
-    s.cg_split = (!no_split && h->n_fluid > 0 && h->n_fluid <= 400000) ? 1 : 0;
+    s.cg_split = (!no_split && h->n_fluid > 0 && h->n_fluid <= 400000) ? 3 : 0;
+    // (SPH_CG_SPLIT_WAYS=2: groups {0, 1} and {2} -- 832 instead of 1248 workgroups at C5, all resident in one round at 4 per CU; built in
+    //  round 5 on the theory that the second, mostly empty round of the three-way split costs a workgroup lifetime.  Measured: A p walk
+    //  0.94 -> 1.08 ms per step, C5 1.639 -> 1.757 ms/step: the longer life of the two-group workgroups costs more.  Kept as a switch.)
+    if (s.cg_split) { static const char *ways = getenv("SPH_CG_SPLIT_WAYS"); if (ways && atoi(ways) == 2) s.cg_split = 2; }
     // Slab sharding: the ghosts are the neighbour ranks' rows of the system.  Their search direction goes out before every
     // A p pass (12 B per ghost through the slot tables), the three dot products of an iteration are summed over the ranks
     // (k_cg_fold + one 1-float and one 2-float all-reduce), and the solved velocities of the ghosts after the loop.

@@ -200,9 +200,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Runs of equal key among the consecutive lanes of a wave (the input of the sort is last step's sorted order, so a wave is a few
 // runs of ~8 particles that stay in their cell, plus strays): head = first lane of a run, hl = the head's lane, len = run length
 // (meaningful in the head lane).  k_hash_count, k_scatter_index and k_scatter<true> must see the same runs: same thread -> particle map.
-__device__ __forceinline__ void wave_runs(int key, int lane, bool &head, int &hl, int &len) {
+// `slot`: the slot the particle got inside its cell (k_scatter_index / k_scatter): a run must also be CONTIGUOUS there.  Particles that
+// took their slots one by one (arrivals appended by k_halo_unpack2 under slab sharding: one atomic each) would otherwise be merged into a
+// "run" whose slots lie anywhere in the cell.
+__device__ __forceinline__ void wave_runs(int key, int lane, bool &head, int &hl, int &len, int slot = 0, bool use_slot = false) {
     const int prev = __shfl_up(key, 1, 64);
-    head = lane == 0 || key != prev;
+    const int prev_slot = __shfl_up(slot, 1, 64);
+    head = lane == 0 || key != prev || (use_slot && slot != prev_slot + 1);
     const unsigned long long hm = __ballot(head);
     const unsigned long long upto = hm & ((2ull << lane) - 1ull);          // heads at or below this lane
     hl = 63 - __clzll(upto);
@@ -339,9 +343,10 @@ k_scatter_index(int n, const int *__restrict__ cellid, const int *__restrict__ r
     if (n_dev) n = *n_dev;
     const bool valid = i < n;
     const int cell = valid ? cellid[i] : -1 - lane;
+    const int slot = valid ? rank[i] : 0;
     bool head; int hl, len;
-    wave_runs(cell, lane, head, hl, len);
-    if (valid && head) runs[cell_start[cell] + rank[i]] = make_int2(i, len);
+    wave_runs(cell, lane, head, hl, len, slot, true);
+    if (valid && head) runs[cell_start[cell] + slot] = make_int2(i, len);
 }
 
 struct SortArrays {
@@ -373,7 +378,8 @@ k_scatter(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
         // stable rank = serial execution of base_container.py:510-515 = number of particles of the same cell with a lower source index
         //             = (lengths of the cell's runs that start below this particle's run) + (position inside its own run)
         bool head; int hl, len;
-        wave_runs(cell, lane, head, hl, len);
+        const int slot = valid ? rank[i] : 0;
+        wave_runs(cell, lane, head, hl, len, slot, true);
         int r0 = 0;
         if (valid) s = cell_start[cell];
         if (valid && head && cell < a.G) {   // (a graveyard cell of the slab sharding may hold 1e5 particles nobody looks at again)
@@ -388,7 +394,7 @@ k_scatter(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
         }
         r0 = __shfl(r0, hl, 64);
         r = r0 + (lane - hl);
-        if (valid && cell >= a.G) r = rank[i];
+        if (valid && cell >= a.G) r = slot;
     } else if (valid) {
         s = cell_start[cell];
         r = rank[i];
@@ -946,6 +952,10 @@ template <class P, int MASKMODE> constexpr int nbr_waves_per_simd() {
     const int w = P::HAS_B ? (pass_is_medium<P>() ? 5 : SPH_NBR_WAVES_HEAVY) : (sizeof(typename P::Own) <= 8 ? SPH_NBR_WAVES_LIGHT : 4);
     return w < PassMaxWaves<P>::value ? w : PassMaxWaves<P>::value;
 }
+// P::SPLIT3 launches: gridDim.y = 3 -> workgroup (b, y) walks group y; gridDim.y = 2 -> (b, 0) walks groups 0 and 1, (b, 1) group 2
+// (for grids that would not be resident at once three ways: 3 x 416 tiles of the buckling sheet = 1248 > 1024 = a second, mostly empty round)
+__device__ __forceinline__ int split_lo(int ny, int y) { return ny == 3 ? y : (y == 0 ? 0 : 2); }
+__device__ __forceinline__ int split_hi(int ny, int y) { return ny == 3 ? y + 1 : (y == 0 ? 2 : 3); }
 template <class P, int MASKMODE>
 __global__ void __launch_bounds__(P::BLOCK, (nbr_waves_per_simd<P, MASKMODE>()))
 k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevScalars *__restrict__ scal,
@@ -990,7 +1000,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     if (i0 >= n_live) {   // launch bound of an asynchronous slab step: no such tile (its header was never written)
         if constexpr (P::HAS_REDUCE) {
             if (tid == 0) {
-                if constexpr (PassSplit<P>::value) { if (gridDim.y == 3) { if (float *o = p.split_out((int)blockIdx.y)) o[b] = 0.0f; } else p.red_out[b] = 0.0f; }
+                if constexpr (PassSplit<P>::value) { if (gridDim.y > 1) { if (float *o = p.split_out(split_lo((int)gridDim.y, (int)blockIdx.y))) o[b] = 0.0f; } else p.red_out[b] = 0.0f; }
                 else p.red_out[b] = 0.0f;
             }
         }
@@ -1018,7 +1028,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     bool active = p.begin(c, ic, pi, own) && valid;
     unsigned mk0[3] = {0u, 0u, 0u};   // first mask words of the first group's runs
     if (MASKMODE == 2 && pass_mask_pipe<P>()) {
-        const int g0 = (PassSplit<P>::value && gridDim.y == 3) ? (int)blockIdx.y : 0;
+        const int g0 = (PassSplit<P>::value && gridDim.y > 1) ? split_lo((int)gridDim.y, (int)blockIdx.y) : 0;
 #pragma unroll
         for (int q = 0; q < 3; ++q) mk0[q] = nbr_mask[(size_t)(g0 * 3 + q) * mask_stride + i];   // (the array has a tile of slack)
     }
@@ -1026,7 +1036,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     // the tile after the prologue's barrier; the records sit in registers only across the prologue, where little else is live.  One
     // round trip less per workgroup -- and 1-2 % SLOWER at C2 / C3 (profiles/r03w_ab_round_trips.txt): kept as a switch, like PAIR2.
     typedef typename PassC<P>::type CT;
-    const int g_first = (PassSplit<P>::value && gridDim.y == GROUPS) ? (int)blockIdx.y : 0;
+    const int g_first = (PassSplit<P>::value && gridDim.y > 1) ? split_lo((int)gridDim.y, (int)blockIdx.y) : 0;
 #ifdef SPH_PRESTAGE
     constexpr bool PRESTAGE = SPH_FAST || sizeof(BT) < 16;   // (the strict build's widest functors sit at the 128-VGPR limit already)
 #else
@@ -1088,7 +1098,10 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     if (__syncthreads_or(active ? 1 : 0)) {  // workgroup-uniform; also publishes s_cs
         NBR_STAMP(1);
         unsigned npairs = 0;
-        const int gsplit = (PassSplit<P>::value && gridDim.y == GROUPS) ? (int)blockIdx.y : -1;   // uniform: one group only
+        // split launch (uniform): this workgroup walks the x-offset groups [g_lo, g_hi) only -- one of three, or {0, 1} / {2} of a two-way split
+        const bool is_split = PassSplit<P>::value && gridDim.y > 1;
+        const int g_lo = is_split ? split_lo((int)gridDim.y, (int)blockIdx.y) : 0;
+        const int g_hi = is_split ? split_hi((int)gridDim.y, (int)blockIdx.y) : GROUPS;
         bool prestaged = false;   // the first round's records are already on their way (above)
         unsigned mkn[RPG] = {mk0[0], mk0[1], mk0[2]};   // first mask words of the coming round's group
         if constexpr (PRESTAGE) {
@@ -1105,7 +1118,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             prestaged = true;
         }
 #pragma unroll 1
-        for (int g = gsplit >= 0 ? gsplit : 0, qa = 0; g < (c.force_global == 11 ? 0 : (gsplit >= 0 ? gsplit + 1 : GROUPS)); ) {
+        for (int g = g_lo, qa = 0; g < (c.force_global == 11 ? 0 : g_hi); ) {
             // One group = the three runs of an x offset.  Its runs are staged in ROUNDS (uniform plan): a round takes the longest
             // prefix of the runs not yet done that fits the tile, laid out back to back -- normally all three in one round; where
             // the fluid has piled up, two rounds (e.g. {0, 1} then {2}) instead of sending the group down the slow ordered walk.
@@ -1350,9 +1363,15 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     float *red_to = nullptr;   // where this workgroup's partial sum goes (split launch: the functor may keep one per x-offset group)
     if constexpr (P::HAS_REDUCE) red_to = p.red_out;
     if constexpr (PassSplit<P>::value) {
-        split_launch = gridDim.y == GROUPS;
-        if (split_launch && valid && active) red = p.partial(c, i, (int)blockIdx.y, own);
-        if (split_launch) red_to = p.split_out((int)blockIdx.y);
+        split_launch = gridDim.y > 1;
+        const int part = split_lo((int)gridDim.y, (int)blockIdx.y);   // the part of the sum this workgroup leaves: its first group's
+        if (split_launch && valid && active) red = p.partial(c, i, part, own);
+        if (split_launch) red_to = p.split_out(part);
+        // two-way split: nobody walks "part 1" (its group rides in part 0), but the consumers add up three parts: zeros
+        if (split_launch && gridDim.y == 2 && blockIdx.y == 0) {
+            if (valid && active) p.partial_zero(i, 1);
+            if (tid == 0) { if (float *o = p.split_out(1)) o[b] = 0.0f; }
+        }
     }
     if (valid && !split_launch) {
         if (active) red = p.finish(c, i, pi, own);

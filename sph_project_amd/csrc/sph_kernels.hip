@@ -130,7 +130,7 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     if (tl) hipMemsetAsync(tl, 0, (size_t)nb * 16 * 8, s.stream);
     constexpr int MODES = PassModes<P>::value;
     if (!(MODES & (1 << mask_mode))) mask_mode = 0;   // every functor has mode 0
-    const int gy = (PassSplit<P>::value && s.split_next_pass) ? 3 : 1;   // one workgroup per (tile, x-offset group)
+    const int gy = (PassSplit<P>::value && s.split_next_pass) ? s.split_next_pass : 1;   // 3: one workgroup per (tile, x-offset group); 2: groups {0, 1} / {2}
     s.split_next_pass = 0;
     // debug ("time against resident workgroups"): SPH_DEBUG_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup lower the
     // number of workgroups a CU can hold without touching the code

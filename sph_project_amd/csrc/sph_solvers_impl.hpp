@@ -142,7 +142,7 @@ static void l_cg_prepare(State &s) {
 #define CG_LIST (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_list : nullptr, (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_count : nullptr
 static void l_cg_ap(State &s) {
     const bool split = s.cg_split && s.cg_part && s.c.n > 0;
-    s.split_next_pass = split ? 1 : 0;
+    s.split_next_pass = split ? s.cg_split : 0;   // 2 or 3 ways (sph_cg_steps.hpp)
     // s.cg_fuse: this A p pass applies the previous iteration's p update on the fly (CgApPass::fuse), p_old = cg_p, p_new = cg_p2
     const int fuse = s.cg_fuse ? 1 : 0;
     const bool lst = !s.c.all_fluid && s.list_n == s.c.n;

@@ -501,6 +501,11 @@ def _eight_way(cfg, steps, tmp_path, jitter, seed, exact_pairs):
     _, geo, _b = H.scene_particles(cfg)
     dh, nz = geo.dh, int(geo.grid_num[2])
     all_ids = np.concatenate([o["ids"] for o in outs])
+    if not (len(all_ids) == len(ids) and len(np.unique(all_ids)) == len(ids)):   # say which rank holds what before failing
+        for r, o in enumerate(outs):
+            u, cnt = np.unique(o["ids"], return_counts=True)
+            print("rank %d: %d owned, %d distinct ids, most repeated id %d x%d, ids == 0: %d, non-finite positions %d" % (
+                r, len(o["ids"]), len(u), int(u[cnt.argmax()]), int(cnt.max()), int((o["ids"] == 0).sum()), int((~np.isfinite(o["pos"])).any(1).sum())))
     assert len(all_ids) == len(ids) and len(np.unique(all_ids)) == len(ids), "every particle owned by exactly one rank"
     x, rho = np.empty_like(x_ref), np.empty_like(rho_ref)
     for o in outs:
