@@ -230,6 +230,8 @@ extern "C" void sph_destroy(SphHandle *h) {
     for (auto e : h->ev_pool) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->scal_h) hipHostFree(h->scal_h);
+    if (h->st.list_count_pinned) { hipHostFree((void *)h->st.list_count_pinned); h->st.list_count_pinned = nullptr; }
+    if (h->st.list_count_event) { hipEventDestroy(h->st.list_count_event); h->st.list_count_event = nullptr; }
     if (h->st.stream) hipStreamDestroy(h->st.stream);
     delete h;
 }
@@ -311,8 +313,8 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     if (!getenv("SPH_NO_MASK_REUSE")) { CHK_CREATE(dalloc(h, &s.nbr_mask, cap * 9 + 256)); CHK_CREATE(dalloc(h, &s.nbr_mask_hi, cap * 9 + 256)); }   // + 256: the lanes past the last particle of the last tile read (and drop) a word too
     s.lane_perm = nullptr; s.perm_n = -1;
     s.loop_flag = nullptr; s.loop_slot = 0; s.loop_kind = 0; s.loop_denom = 1.0f; s.loop_thr = 0.0;
-    CHK_CREATE(dalloc(h, &s.blk_hdr, (cap + 255) / 256 * 20));
-    s.blk_flag = s.blk_list = s.blk_count = nullptr; s.list_n = -1; s.last_pass_listed = 0;
+    CHK_CREATE(dalloc(h, &s.blk_hdr, (cap + 255) / 256 * (20 + 256)));   // headers of all tiles, then one cell word per particle slot (k_block_prep)
+    s.blk_flag = s.blk_list = s.blk_count = nullptr; s.list_n = -1; s.last_pass_listed = 0; s.list_count_pinned = nullptr; s.list_count_event = nullptr; s.list_count_known = -1;
     if (!getenv("SPH_NO_BLOCK_LIST")) {
         CHK_CREATE(dalloc(h, &s.blk_flag, (cap + 255) / 256)); CHK_CREATE(dalloc(h, &s.blk_list, (cap + 255) / 256)); CHK_CREATE(dalloc(h, &s.blk_count, 1));
     }
@@ -343,6 +345,9 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.cg_parity = 0;
     CHK_CREATE(dalloc(h, &s.scal, 1)); CHK_CREATE(dalloc(h, &s.pose, 1));
     HIP_CREATE(hipHostMalloc((void **)&h->scal_h, sizeof(DevScalars), hipHostMallocDefault));
+    { int *lc = nullptr; HIP_CREATE(hipHostMalloc((void **)&lc, 64, hipHostMallocDefault)); *lc = 0; s.list_count_pinned = lc; }
+    HIP_CREATE(hipEventCreateWithFlags(&s.list_count_event, hipEventDisableTiming));
+    s.list_count_known = -1;
     memset(h->scal_h, 0, sizeof(DevScalars));
     memset(&h->pose_h, 0, sizeof(h->pose_h));
     for (int o = 0; o < SPH_NOBJ; ++o) { h->pose_h.rot[o][0] = h->pose_h.rot[o][4] = h->pose_h.rot[o][8] = 1.0f; }

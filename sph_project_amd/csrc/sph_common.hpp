@@ -91,12 +91,22 @@ struct SlabDyn {
     int n_btiles;    // pinned mirror only: boundary tiles of the last sort (k_block_prep), sizes the boundary launches of the next steps
     unsigned wseq;   // pinned mirror only: 2 seq + 1 while the settle kernel writes the fields, 2 seq + 2 when they are complete (seqlock)
 };
-struct HaloCtl {            // push transport: header block of one side of a rank's inbox, 256 bytes, written by that neighbour
-    unsigned rec_seq;       // number of the last complete step message (stored last, system-scope release)
-    int rec_count, rec_status, rec_stride;   // its header: records, the sender's status bits, float4 per record
-    unsigned fld_seq;       // number of the last complete field message
-    int pad[59];
+// Header of one step message.  TWO per inbox side, by message parity (round 5): the writer announces message m + 1 as soon as its own
+// step is through -- it only needs the reader's message m for that, which the reader announced BEFORE consuming the writer's m.  With one
+// header per side, a consuming kernel that is held up (a late workgroup; a process time-sliced off the GPU with 8 ranks on one device)
+// met the number m + 1 and took m + 1's record count for the payload of m: records lost, or garbage appended
+// (tests/test_hip_slab.py::test_c4_sharded_over_8_ranks..., 2 failures in ~35 runs, only inside the full suite).  The header of m is now
+// overwritten by m + 2 only, which the lockstep argument of sph_halo.hpp already rules out while m is being consumed.
+struct HaloRecHdr {
+    unsigned seq;           // number of the message this header belongs to (stored last, system-scope release)
+    int count, status, stride;   // records, the sender's status bits, float4 per record
 };
+struct HaloCtl {            // push transport: control block of one side of a rank's inbox, 256 bytes, written by that neighbour
+    HaloRecHdr rec[2];      // step messages: header of message m in rec[m & 1]
+    unsigned fld_seq;       // number of the last complete field message (its sizes are known to both sides: no header)
+    int pad[55];
+};
+static_assert(sizeof(HaloCtl) == 256, "HaloCtl layout");
 #define SLAB_ST_SEND_OVERFLOW 1   /* a face message of mine exceeds the message capacity */
 #define SLAB_ST_PEER 2            /* a neighbour reported a failure in its message header */
 #define SLAB_ST_STRIDE 4          /* the neighbour's record size differs from mine (dynamic rigid body not registered on every rank) */
@@ -245,6 +255,13 @@ struct State {
     unsigned char *lane_perm;  // [ceil(cap / 256) * 256]: lane -> particle map of every 256-particle workgroup (k_lane_perm)
     int *blk_flag, *blk_list, *blk_count;   // per-workgroup 'holds fluid' flag, ascending list of those workgroups, its length (device)
     int list_n;                // particle count the list was built for (-1: none)
+    // Length of the list as the HOST knows it: k_compact_blocks stores it into pinned memory, an event behind it tells when it has landed.
+    // A launch over the list then gets exactly that many workgroups (list_grid, sph_kernels.hip) instead of one per tile of the scene
+    // with all but the listed ones leaving at once: the buckling scene has 8,496 tiles of which ~420 hold fluid, and the 24,000 empty
+    // workgroups of a three-way split A p launch cost 16 % of the walk (round 5: C5 1.63 -> 1.47 ms/step).
+    volatile int *list_count_pinned;
+    hipEvent_t list_count_event;
+    int list_count_known;      // -1: not seen yet (the launches use the full grid until the event has passed)
     int last_pass_listed;      // the last pass with a reduction ran the listed workgroups only: so must the sum of its partials
     int *blk_hdr;              // [ceil(cap / 256)][BLK_HDR_INTS]: cell span and candidate-run windows of every workgroup
     int perm_n;                // particle count blk_hdr / lane_perm were built for (-1: none)

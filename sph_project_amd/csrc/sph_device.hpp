@@ -733,7 +733,7 @@ struct TilePlanOut { int *list_b, *list_i, *cnt; unsigned char *cls; int lo_laye
 __global__ void __launch_bounds__(256)
 k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restrict__ meta,
              const int *__restrict__ cell_start, int *__restrict__ blk_hdr, unsigned char *__restrict__ perm,
-             int *__restrict__ blk_flag, const int *__restrict__ xidx, BlockPrepTables tabs, TilePlanOut plan) {
+             int *__restrict__ blk_flag, const int *__restrict__ xidx, BlockPrepTables tabs, TilePlanOut plan, unsigned *__restrict__ cellw) {
     __shared__ int s_cnt[4][64];
     __shared__ int s_c[2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -767,6 +767,8 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
     }
     const int nvalid = (n - i0) < 256 ? (n - i0) : 256;
     int key = 63;  // slots past the end go last
+    int my_lin = 0, my_dz0 = 0, my_dz = 0;   // this particle's cell, z0 - cz and z1 - z0 (for its cell word, below)
+    unsigned my_dom = 0u;
     if (i < n) {
         if (xidx) {   // slab sharding, push transport: the halo slot tables of this sort (sph_halo.hpp k_halo_tables) ride along
             const int x = xidx[i];
@@ -778,12 +780,18 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
         const int k = (int)((p.x / c.grid_size - (float)cxg) * 62.0f);
         const int cx = cell_coord_x(c, p.x);
         key = k < 0 ? 0 : (k > 62 ? 62 : k);
-        if (tid == 0 || tid == nvalid - 1) {
+        {
             const int cy = cell_coord(p.y, c.grid_size, c.ny);
             const int cz = cell_coord_z(c, p.z);
             const int lin = (cx * c.ny + cy) * c.nz + cz;
             if (tid == 0) s_c[0] = lin;
             if (tid == nvalid - 1) s_c[1] = lin;
+            const int z0 = cz > 0 ? cz - 1 : 0;
+            const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
+            my_lin = lin; my_dz0 = z0 - cz; my_dz = z1 - z0;
+            // bit k = 3 (ox + 1) + (oy + 1): column (cx + ox, cy + oy) lies inside the grid (k_nbr_pass)
+            const unsigned by = (cy > 0 ? 1u : 0u) | 2u | (cy < c.ny - 1 ? 4u : 0u);
+            my_dom = (cx > 0 ? by : 0u) | (by << 3) | (cx < c.nx - 1 ? by << 6 : 0u);
         }
     }
     (&s_cnt[0][0])[tid] = 0;
@@ -801,6 +809,14 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
     const unsigned long long below = (1ull << lane) - 1ull;
     const int rank_in_wave = __popcll(peers & below);
     __syncthreads();
+    if (cellw && i < n) {
+        // The CELL WORD of every particle, for all neighbour passes of this sort epoch (round 5): what a pass needs of its lane's cell --
+        // e0 = window-cache entry of (.., .., z0) in every run (bits 0-7; meaningful while the tile spans <= NBR_CS_SPAN cells), z1 - z0 + 1
+        // (bits 8-10), the nine "column exists" bits (11-19).  Each pass used to derive them from the position: three IEEE divisions
+        // (the cell must agree with the hash kernel's), clamps and range tests, ~100 VALU per wave and pass (profiles/r05_isa_census.txt).
+        const int e0 = (my_lin - s_c[0]) + my_dz0 + 1;
+        cellw[i] = (unsigned)(e0 & 0xff) | ((unsigned)(my_dz + 1) << 8) | (my_dom << 11);
+    }
     if ((peers & below) == 0ull) s_cnt[w][key] = __popcll(peers);
     if (tid < 9) {
         const int cfirst = s_c[0], clast = s_c[1];
@@ -830,7 +846,7 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
 
 // ascending list of the workgroups whose flag is set (one workgroup, fixed order: the list is deterministic)
 __global__ void __launch_bounds__(256)
-k_compact_blocks(const int *__restrict__ flag, int nb, int *__restrict__ list, int *__restrict__ count) {
+k_compact_blocks(const int *__restrict__ flag, int nb, int *__restrict__ list, int *__restrict__ count, volatile int *count_host) {
     __shared__ int s_w[4];
     int carry = 0;
     for (int b0 = 0; b0 < nb; b0 += 256) {
@@ -841,7 +857,7 @@ k_compact_blocks(const int *__restrict__ flag, int nb, int *__restrict__ list, i
         if (f) list[carry + ex] = b;
         carry += tot;
     }
-    if (threadIdx.x == 0) *count = carry;
+    if (threadIdx.x == 0) { *count = carry; if (count_host) *count_host = carry; }   // (pinned host memory: State::list_count_pinned)
 }
 
 // LDS particle slots per staging group.  All instantiations run 4 workgroups per CU (see nbr_waves_per_simd), so each
@@ -1023,6 +1039,10 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     // gets an `s_waitcnt vmcnt(0)` at the end of its block (the merge of its result), which used to serialise the prologue into
     // five memory round trips (permutation -> position -> windows -> begin() -> first staging round).  begin() only reads.
     const int ic = valid ? i : i0;
+#ifndef SPH_NO_CELL_WORD
+    // the lane's cell word (k_block_prep), filed behind the headers of all tiles (mask_stride = particle capacity)
+    const unsigned cw = reinterpret_cast<const unsigned *>(blk_hdr + (size_t)((mask_stride + 255) >> 8) * BLK_HDR_INTS)[ic];
+#endif
     const float4 pi = p.posv[ic];
     Own own;
     bool active = p.begin(c, ic, pi, own) && valid;
@@ -1062,7 +1082,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             }
         }
     }
-    if (cs_lds) {   // uniform; threads past the window re-read its last entry
+    if (cs_lds && tid < NBR_CS_PITCH) {   // uniform per wave (a window has <= 128 entries: the upper two waves have nothing to fetch); threads past the window re-read its last entry
         const int tc = tid < span + 4 ? tid : span + 3;
         int cs_[9];
 #pragma unroll
@@ -1080,6 +1100,11 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     // cx, cy, z0, z1 - z0; the rare path that reads the windows from global memory recomputes the cell from the position).
     int e0, e1;
     unsigned dom = 0u;
+#ifndef SPH_NO_CELL_WORD
+    e0 = (int)(cw & 0xffu);
+    e1 = e0 + (int)((cw >> 8) & 7u);
+    dom = cw >> 11;
+#else
     {
         const int cx = cell_coord_x(c, pi.x);
         const int cy = cell_coord(pi.y, c.grid_size, c.ny);
@@ -1094,6 +1119,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         const unsigned by = (cy > 0 ? 1u : 0u) | 2u | (cy < c.ny - 1 ? 4u : 0u);
         dom = (cx > 0 ? by : 0u) | (by << 3) | (cx < c.nx - 1 ? by << 6 : 0u);
     }
+#endif
     if (skip_tile) return;   // (uniform)
     if (__syncthreads_or(active ? 1 : 0)) {  // workgroup-uniform; also publishes s_cs
         NBR_STAMP(1);

@@ -137,25 +137,25 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
         const int lane = threadIdx.x;
         // my own header first (workgroup 0): a neighbour waiting for it is released before I start waiting for its
         if (blockIdx.x == 0 && lane < 2 && w.out_ctl[lane]) {
-            HaloCtl *ctl = w.out_ctl[lane];
+            HaloRecHdr *hd = &w.out_ctl[lane]->rec[w.seq & 1u];
             const int cnt = w.counts[HC(lane)];
-            halo_store_sys(&ctl->rec_count, cnt);
-            halo_store_sys(&ctl->rec_status, w.dyn_old->status | (cnt > w.halo_cap ? SLAB_ST_SEND_OVERFLOW : 0));
-            halo_store_sys(&ctl->rec_stride, w.stride);
+            halo_store_sys(&hd->count, cnt);
+            halo_store_sys(&hd->status, w.dyn_old->status | (cnt > w.halo_cap ? SLAB_ST_SEND_OVERFLOW : 0));
+            halo_store_sys(&hd->stride, w.stride);
             __threadfence_system();
-            __hip_atomic_store(&ctl->rec_seq, w.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&hd->seq, w.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         int cnt = 0, st = 0;
         if (lane < 2 && w.in_ctl[lane]) {
-            const HaloCtl *ctl = w.in_ctl[lane];
+            const HaloRecHdr *hd = &w.in_ctl[lane]->rec[w.seq & 1u];   // (this message's own header: the next one goes to the other)
             // (after a time-out the exchange is dead: later waits give up at once instead of stacking 30 s each on the stream)
             const long long patience = (w.dyn_old->status & SLAB_ST_TIMEOUT) ? 0 : w.timeout_ticks;
-            if (!halo_poll(&ctl->rec_seq, w.seq, patience)) st |= SLAB_ST_TIMEOUT;
+            if (!halo_poll(&hd->seq, w.seq, patience)) st |= SLAB_ST_TIMEOUT;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: the header and the records behind the number
             if (!st) {
-                cnt = halo_load_sys(&ctl->rec_count);
-                if (halo_load_sys(&ctl->rec_status)) st |= SLAB_ST_PEER;
-                if (halo_load_sys(&ctl->rec_stride) != w.stride) st |= SLAB_ST_STRIDE;
+                cnt = halo_load_sys(&hd->count);
+                if (halo_load_sys(&hd->status)) st |= SLAB_ST_PEER;
+                if (halo_load_sys(&hd->stride) != w.stride) st |= SLAB_ST_STRIDE;
                 if (cnt < 0 || cnt > w.halo_cap) { st |= SLAB_ST_PEER; cnt = 0; }
             }
         }

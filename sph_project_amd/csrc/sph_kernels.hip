@@ -66,8 +66,13 @@ void l_block_prep(State &s) {
         s.tile_plan_n = n;
     }
     hipLaunchKernelGGL(k_block_prep, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.meta.cur(), s.cell_start,
-                       s.blk_hdr, s.lane_perm, lst ? s.blk_flag : nullptr, xi, tabs, plan);
-    if (lst) hipLaunchKernelGGL(k_compact_blocks, dim3(1), dim3(256), 0, s.stream, s.blk_flag, cdiv(n, 256), s.blk_list, s.blk_count);   // (tiles past the live count carry flag 0)
+                       s.blk_hdr, s.lane_perm, lst ? s.blk_flag : nullptr, xi, tabs, plan,
+                       reinterpret_cast<unsigned *>(s.blk_hdr + (size_t)((s.cap + 255) / 256) * BLK_HDR_INTS));   // cell words behind the headers
+    if (lst) {
+        hipLaunchKernelGGL(k_compact_blocks, dim3(1), dim3(256), 0, s.stream, s.blk_flag, cdiv(n, 256), s.blk_list, s.blk_count, s.list_count_pinned);   // (tiles past the live count carry flag 0)
+        s.list_count_known = -1;
+        if (s.list_count_event) hipEventRecord(s.list_count_event, s.stream);
+    }
     s.list_n = lst ? n : -1;
     s.perm_n = n;
 }
@@ -104,6 +109,17 @@ void l_scatter_impl(State &s, bool stable) {
 void l_scatter(State &s) { l_scatter_impl(s, false); }
 void l_scatter_stable(State &s) { l_scatter_impl(s, true); }
 
+// Workgroups a launch over the list of fluid-holding tiles needs: the list's length once the host has seen it (State::list_count_pinned),
+// one per tile of the scene until then (the kernels send the surplus home at their top).  Never zero: a functor whose prologue keeps a
+// solver loop's books needs workgroup (0, 0) even when the list is empty.
+int list_grid(State &s, int nb) {
+    static const bool off = getenv("SPH_NO_LIST_GRID") != nullptr;
+    if (off || !s.list_count_pinned) return nb;
+    if (s.list_count_known < 0 && s.list_count_event && hipEventQuery(s.list_count_event) == hipSuccess) s.list_count_known = *s.list_count_pinned;
+    const int g = s.list_count_known >= 0 ? s.list_count_known : nb;
+    return g < 1 ? 1 : (g > nb ? nb : g);
+}
+
 // mask_mode: 0 compute, 1 compute + store (first pass after a sort), 2 reuse (see process_run)
 template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     const int n = s.c.n;
@@ -125,6 +141,7 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
         if (s.tile_sel == 1) { bl = s.tile_list[0]; bc = s.tile_cnt; nb_launch = s.tile_bound_b > 0 ? s.tile_bound_b : 1; }   // the listed boundary tiles; the grid is a bound
         else skip = s.tile_class;   // every tile, the boundary ones leave
     }
+    if (use_list) nb_launch = list_grid(s, nb);
     if (P::HAS_REDUCE) s.last_pass_listed = use_list ? 1 : 0;   // whose partial sums l_reduce_sum will finish
     unsigned long long *tl = (s.c.force_global == 20 && (size_t)nb * 16 * 8 <= (size_t)s.cap * 4) ? (unsigned long long *)s.tmp_idx : nullptr;
     if (tl) hipMemsetAsync(tl, 0, (size_t)nb * 16 * 8, s.stream);

@@ -140,6 +140,8 @@ static void l_cg_prepare(State &s) {
 #define CG_GLOB (s.slab_active ? &s.scal->red[6] : (const float *)nullptr)
 // the per-particle CG kernels run the workgroups that hold fluid only (same list as the neighbour passes)
 #define CG_LIST (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_list : nullptr, (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_count : nullptr
+// grid of a per-particle CG kernel: the listed workgroups only once the host knows how many there are (list_grid)
+#define CG_GRID(nb) ((!s.c.all_fluid && s.list_n == s.c.n) ? list_grid(s, (nb)) : (nb))
 static void l_cg_ap(State &s) {
     const bool split = s.cg_split && s.cg_part && s.c.n > 0;
     s.split_next_pass = split ? s.cg_split : 0;   // 2 or 3 ways (sph_cg_steps.hpp)
@@ -165,7 +167,7 @@ static void l_cg_ap(State &s) {
         launch_pass(s, p, 2);
     }
     if (split && !nocombine)   // the three parts -> A p and the partials of p . A p (what finish() and the pass's reduction do otherwise)
-        hipLaunchKernelGGL(k_cg_ap_combine, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.meta.cur(), CG_AF, s.cg_part, s.cap, s.cg_p,
+        hipLaunchKernelGGL(k_cg_ap_combine, dim3(CG_GRID(cdiv(s.c.n, 256))), dim3(256), 0, s.stream, s.c, s.meta.cur(), CG_AF, s.cg_part, s.cap, s.cg_p,
                            s.cg_Ap, CG_PART(2), s.loop_flag, CG_LIST, fuse ? s.cg_r : (const float4 *)nullptr, s.cg_p2, s.scal);
     if (fuse) std::swap(s.cg_p, s.cg_p2);   // cg_p is the search direction of the running iteration again
 }
@@ -179,7 +181,7 @@ static void l_cg_alpha(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
     s.cg_parity = 0;
-    hipLaunchKernelGGL(k_cg_dots, dim3(nb), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), CG_AF, s.cg_r, s.cg_p, s.cg_Ap, CG_PART(0), CG_PART(3), (const int *)nullptr, CG_LIST);
+    hipLaunchKernelGGL(k_cg_dots, dim3(CG_GRID(nb)), dim3(256), 0, s.stream, s.c.n, s.meta.cur(), CG_AF, s.cg_r, s.cg_p, s.cg_Ap, CG_PART(0), CG_PART(3), (const int *)nullptr, CG_LIST);
 }
 // slab sharding: this rank's sums of two partial arrays -> scal->red[6], red[7] (which = 0: |r0|^2 after l_cg_alpha,
 // 1: p . Ap after the A p pass -> red[7] only, 2: |new r|^2 and |old r|^2 after the x / r update)
@@ -194,7 +196,7 @@ static void l_cg_update_xr(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
     const bool nc = s.cg_nocombine != 0;   // the A p pass in front of this kernel left three parts and three sets of p . A p partials
-    hipLaunchKernelGGL(k_cg_update_xr2, dim3(nb), dim3(256), 0, s.stream, s.c, s.c.n, nb, s.meta.cur(), CG_AF, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap,
+    hipLaunchKernelGGL(k_cg_update_xr2, dim3(CG_GRID(nb)), dim3(256), 0, s.stream, s.c, s.c.n, nb, s.meta.cur(), CG_AF, s.cg_x, s.cg_r, s.cg_p, s.cg_Ap,
                        CG_PART(s.cg_parity), nc ? CG_PART(4) : CG_PART(2), CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag, CG_LIST, CG_GLOB,
                        (s.cg_fused_loop && s.loop_flag) ? 1 : 0, nc ? s.cg_part : (const float4 *)nullptr, s.cap, s.red_blocks);
     s.cg_nocombine = 0;
@@ -204,7 +206,7 @@ static void l_cg_update_xr(State &s) {
 static void l_cg_update_p(State &s) {
     if (s.c.n == 0) return;
     const int nb = cdiv(s.c.n, 256);
-    hipLaunchKernelGGL(k_cg_update_p2, dim3(nb), dim3(256), 0, s.stream, s.c.n, nb, s.meta.cur(), CG_AF, s.cg_r, s.cg_p,
+    hipLaunchKernelGGL(k_cg_update_p2, dim3(CG_GRID(nb)), dim3(256), 0, s.stream, s.c.n, nb, s.meta.cur(), CG_AF, s.cg_r, s.cg_p,
                        CG_PART(1 - s.cg_parity), CG_PART(3), s.scal, s.loop_flag ? 1 : 0, (float)s.loop_thr, s.loop_flag, CG_LIST, CG_GLOB);
     s.cg_parity = 1 - s.cg_parity;
 }
