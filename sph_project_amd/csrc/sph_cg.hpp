@@ -98,20 +98,40 @@ struct CgPreparePass {
 // count, stop flag).  Partials: rr[2] (|r|^2, ping-pong: the x / r update reads one and writes the other), den (p . Ap, from
 // the A p pass), rold (|r|^2 before the update, the denominator of beta).
 // (stride3 != 0: `part` is three arrays stride3 apart -- the per-group partials of a split A p walk -- added up entry by entry)
+// A launch over the list of fluid-holding tiles files the partial of its k-th LISTED workgroup at slot k (red_slot, sph_device.hpp):
+// the sum runs over the first *blk_count entries, in list order -- the order it always had -- without the list itself (until round 5
+// every reader went count -> list -> partial: three dependent round trips at the top of every workgroup of the next kernel).
 __device__ __forceinline__ float cg_total(const float *part, int nb, const int *blk_list, const int *blk_count, float *s4, int stride3 = 0) {
     float a = 0.f;
+    const int m = blk_list ? *blk_count : nb;
     if (stride3) {
         const float *p1 = part + stride3, *p2 = part + 2 * (size_t)stride3;
-        if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) { const int b = blk_list[k]; a += (part[b] + p1[b]) + p2[b]; } }
-        else for (int k = threadIdx.x; k < nb; k += 256) a += (part[k] + p1[k]) + p2[k];
+        for (int k = threadIdx.x; k < m; k += 256) a += (part[k] + p1[k]) + p2[k];
     }
-    else if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) a += part[blk_list[k]]; }
-    else for (int k = threadIdx.x; k < nb; k += 256) a += part[k];
+    else for (int k = threadIdx.x; k < m; k += 256) a += part[k];
     a = wave_sum(a);
     __syncthreads();   // s4 may still be read from a previous call
     if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = a;
     __syncthreads();
     return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+// two sums in one sweep: the loads of both arrays are in flight together and the workgroup meets at two barriers instead of four
+// (same per-array order of additions as two cg_total calls: bit-identical results)
+__device__ __forceinline__ void cg_total2(const float *pa, const float *pb, int nb, const int *blk_list, const int *blk_count, float *s8,
+                                          float &ra, float &rb, int stride3_b = 0) {
+    float a = 0.f, b = 0.f;
+    const int m = blk_list ? *blk_count : nb;
+    if (stride3_b) {
+        const float *p1 = pb + stride3_b, *p2 = pb + 2 * (size_t)stride3_b;
+        for (int k = threadIdx.x; k < m; k += 256) { a += pa[k]; b += (pb[k] + p1[k]) + p2[k]; }
+    }
+    else for (int k = threadIdx.x; k < m; k += 256) { a += pa[k]; b += pb[k]; }
+    a = wave_sum(a); b = wave_sum(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s8[threadIdx.x >> 6] = a; s8[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    ra = (s8[0] + s8[1]) + (s8[2] + s8[3]);
+    rb = (s8[4] + s8[5]) + (s8[6] + s8[7]);
 }
 
 // base_solver.py:374 compute_Ap (+task :386)
@@ -148,9 +168,9 @@ struct CgApPass {
     __device__ bool prologue(DevScalars *scal) const {
         beta = 0.0f;
         if (!fuse) return true;
-        __shared__ float s4[4];
-        const float num = cg_total(part_num, nb_part, pl_list, pl_count, s4);
-        const float den = cg_total(part_den, nb_part, pl_list, pl_count, s4);
+        __shared__ float s8[8];
+        float num, den;
+        cg_total2(part_num, part_den, nb_part, pl_list, pl_count, s8, num, den);
         beta = den > 1e-18f ? num / den : 0.0f;
         const float err = __builtin_sqrtf(num);
         const bool done = looped && !(err > tol);
@@ -262,7 +282,7 @@ struct CgApPass {
 };
 
 // ---- per-particle vector kernels with fixed-order block reductions -------------------------------
-__device__ __forceinline__ void block_sum2(float a, float b, float *out_a, float *out_b, int blk) {
+__device__ __forceinline__ void block_sum2(float a, float b, float *out_a, float *out_b, int blk) {   // blk: partial-sum slot, < 0: none
     __shared__ float s_a[4], s_b[4];
     a = wave_sum(a); b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
@@ -307,7 +327,7 @@ k_cg_dots(int n, const int *meta, int all_fluid, const float4 *r, const float4 *
         num = rr.x * rr.x + rr.y * rr.y + rr.z * rr.z;
         den = pp.x * a.x + pp.y * a.y + pp.z * a.z;
     }
-    block_sum2(num, den, part_a, part_b, blk);
+    block_sum2(num, den, part_a, part_b, red_slot(blk_list, blk));
 }
 
 // second half of a split A p pass (CgApPass::SPLIT3): adds the three per-group parts, then CgApPass::finish + its partial of p . Ap
@@ -339,7 +359,7 @@ k_cg_ap_combine(const Consts c, const int *meta, int all_fluid, const float4 *pa
     dot = wave_sum(dot);
     if ((threadIdx.x & 63) == 0) s_d[threadIdx.x >> 6] = dot;
     __syncthreads();
-    if (threadIdx.x == 0) part_den[blk] = (s_d[0] + s_d[1]) + (s_d[2] + s_d[3]);
+    if (threadIdx.x == 0) part_den[red_slot(blk_list, blk)] = (s_d[0] + s_d[1]) + (s_d[2] + s_d[3]);
 }
 
 // Slab sharding: the dot products are sums over all ranks.  One workgroup adds up this rank's partials into out[0..1]; the
@@ -380,24 +400,31 @@ k_cg_update_xr2(const Consts c, int n, int nb, const int *meta, int all_fluid, f
     //  list is empty and the books would never be kept: 1000 empty iterations per step)
     const int blk = cg_block(blk_list, blk_count);
     if (blk < 0 && blockIdx.x != 0) return;
-    __shared__ float s4[4];
-    const float num_a = glob ? glob[0] : cg_total(part_rr, nb, blk_list, blk_count, s4);
+    // this particle's operands are requested BEFORE the sums that give alpha (none of them depends on it): one round trip for both
+    const int i = blk * 256 + threadIdx.x;
+    const bool mine = blk >= 0 && i < n && is_fluid(meta, i, all_fluid);
+    const int ic = mine ? i : 0;
+    float4 xx = x[ic];
+    const float4 pp = p[ic], rr = r[ic];
+    float4 a;
+    if (part3) {   // A p of the split walks, added up here (what k_cg_ap_combine did in a launch of its own)
+        const float4 a0 = part3[ic], a1 = part3[(size_t)part_stride + ic], a2 = part3[2 * (size_t)part_stride + ic];
+        float ax = ((a0.x + a1.x) + a2.x) * c.dt, ay = ((a0.y + a1.y) + a2.y) * c.dt, az = ((a0.z + a1.z) + a2.z) * c.dt;
+        ax = fdiv(ax, c.rho0); ay = fdiv(ay, c.rho0); az = fdiv(az, c.rho0);
+        a = make_float4(ax + pp.x, ay + pp.y, az + pp.z, 0.f);
+    } else a = Ap[ic];
+    __shared__ float s8[8];
+    float num_a, den_a;
+#ifdef SPH_NO_EARLY_LOADS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A/B: the operands first, then the sums (two round trips, as before round 5)
+#endif
     // (split walks without a combining kernel: part_den = [3][den_stride], CgApPass::partial)
-    const float den_a = glob ? glob[1] : cg_total(part_den, nb, blk_list, blk_count, s4, part3 ? den_stride : 0);
+    if (glob) { num_a = glob[0]; den_a = glob[1]; }
+    else cg_total2(part_rr, part_den, nb, blk_list, blk_count, s8, num_a, den_a, part3 ? den_stride : 0);
     const float alpha = den_a > 1e-18f ? num_a / den_a : 0.0f;     // :403
     if (blockIdx.x == 0 && threadIdx.x == 0) { scal->red[4] = alpha; if (count_iteration) scal->flags[1] += 1; }   // (fused p update: this kernel ends the iteration)
-    int i = blk * 256 + threadIdx.x;
     float num = 0.f, den = 0.f;
-    if (blk >= 0 && i < n && is_fluid(meta, i, all_fluid)) {
-        float4 xx = x[i];
-        const float4 pp = p[i], rr = r[i];
-        float4 a;
-        if (part3) {   // A p of the split walks, added up here (what k_cg_ap_combine did in a launch of its own)
-            const float4 a0 = part3[i], a1 = part3[(size_t)part_stride + i], a2 = part3[2 * (size_t)part_stride + i];
-            float ax = ((a0.x + a1.x) + a2.x) * c.dt, ay = ((a0.y + a1.y) + a2.y) * c.dt, az = ((a0.z + a1.z) + a2.z) * c.dt;
-            ax = fdiv(ax, c.rho0); ay = fdiv(ay, c.rho0); az = fdiv(az, c.rho0);
-            a = make_float4(ax + pp.x, ay + pp.y, az + pp.z, 0.f);
-        } else a = Ap[i];
+    if (mine) {
         xx.x += alpha * pp.x; xx.y += alpha * pp.y; xx.z += alpha * pp.z;
         x[i] = xx;
         const float4 nr = make_float4(rr.x - alpha * a.x, rr.y - alpha * a.y, rr.z - alpha * a.z, 0.f);
@@ -405,7 +432,7 @@ k_cg_update_xr2(const Consts c, int n, int nb, const int *meta, int all_fluid, f
         den = rr.x * rr.x + rr.y * rr.y + rr.z * rr.z;
         r[i] = nr;
     }
-    block_sum2(num, den, part_rr_next, part_rold, blk);
+    block_sum2(num, den, part_rr_next, part_rold, blk >= 0 ? red_slot(blk_list, blk) : -1);
 }
 
 // :427-431 beta, error + :434 update_p; workgroup 0: loop book-keeping (:445 `while tol > 1e-6`)
@@ -416,9 +443,10 @@ k_cg_update_p2(int n, int nb, const int *meta, int all_fluid, const float4 *r, f
     if (stop_flag && *stop_flag) return;
     const int blk = cg_block(blk_list, blk_count);
     if (blk < 0 && blockIdx.x != 0) return;   // (workgroup 0 keeps the books even when the list is empty, see k_cg_update_xr2)
-    __shared__ float s4[4];
-    const float num = glob ? glob[0] : cg_total(part_rr_next, nb, blk_list, blk_count, s4);
-    const float den = glob ? glob[1] : cg_total(part_rold, nb, blk_list, blk_count, s4);
+    __shared__ float s8[8];
+    float num, den;
+    if (glob) { num = glob[0]; den = glob[1]; }
+    else cg_total2(part_rr_next, part_rold, nb, blk_list, blk_count, s8, num, den);
     const float beta = den > 1e-18f ? num / den : 0.0f;
     int i = blk * 256 + threadIdx.x;
     if (blk >= 0 && i < n && is_fluid(meta, i, all_fluid)) {

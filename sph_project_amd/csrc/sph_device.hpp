@@ -181,6 +181,10 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
     return base + (b >> 3);
 }
 
+// Slot of this workgroup's partial sum (P::HAS_REDUCE passes and the per-particle CG kernels): its tile index, or -- in a launch over the
+// list of fluid-holding tiles -- its position in the list, so that the consumers add up the first *blk_count slots without reading the list.
+__device__ __forceinline__ int red_slot(const int *blk_list, int b) { return blk_list ? (int)blockIdx.x : b; }
+
 __device__ __forceinline__ int wave_incl_scan(int v) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -979,8 +983,13 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
            const int *__restrict__ blk_hdr, const unsigned char *__restrict__ lane_perm,
            unsigned long long *__restrict__ timeline, const int *__restrict__ stop_flag,
            const int *__restrict__ blk_list, const int *__restrict__ blk_count, const unsigned char *__restrict__ tile_skip) {
-    if (stop_flag && *stop_flag) return;   // iteration launched past the convergence of a device-controlled loop
-    if (blk_list && (int)blockIdx.x >= *blk_count) {   // only the workgroups that hold fluid were listed
+    // First round trip: everything that depends on nothing, requested together (the stop flag, the length of the list and this workgroup's
+    // entry used to be three dependent scalar loads; the list has an entry per tile of the scene, so any blockIdx.x reads inside it).
+    const int stop_now = stop_flag ? *stop_flag : 0;
+    const int list_len = blk_list ? *blk_count : INT_MAX;
+    const int b_listed = blk_list ? blk_list[blockIdx.x] : 0;
+    if (stop_now) return;   // iteration launched past the convergence of a device-controlled loop
+    if ((int)blockIdx.x >= list_len) {   // only the workgroups that hold fluid were listed
         // (a functor whose prologue keeps a solver loop's books gets it run by workgroup (0, 0) even when the list is EMPTY --
         //  an emitter scene before its first release has no active fluid particle at all)
         if constexpr (PassPrologue<P>::value) { if (blockIdx.x == 0 && blockIdx.y == 0) p.prologue(scal); }
@@ -1005,31 +1014,42 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
 
     const int tid = threadIdx.x;
     NBR_STAMP(0);
-    if constexpr (PassWrench<P>::value) wrench_init_all(p.pose);   // (published by the prologue's barrier)
-    if constexpr (PassPrologue<P>::value) { if (!p.prologue(scal)) return; }   // workgroup-uniform
-    const int b = blk_list ? blk_list[blockIdx.x] : xcd_remap(blockIdx.x, nblocks);
+    const int b = blk_list ? b_listed : xcd_remap(blockIdx.x, nblocks);
     const int i0 = b * BLOCK;
-    // slab sharding, interior launch of a pass that ran its boundary tiles first: those leave (the flag is requested here and looked at
-    // behind the prologue's loads, so it adds no round trip of its own)
+    // Second round trip, requested BEFORE a functor's prologue (whose barriers keep later loads behind its own: the CG walk's prologue adds
+    // up two arrays of partial sums first): the lane permutation, the header, the skip flag of a slab's interior launch.
+#ifndef SPH_NO_EARLY_LOADS
+    const int who_early = lane_perm ? (int)lane_perm[i0 + tid] : tid;
+    const int *hdr = blk_hdr + (size_t)b * BLK_HDR_INTS;
+    const int cfirst = hdr[0], clast = hdr[1];
     const int skip_tile = tile_skip ? (int)tile_skip[b] : 0;
     const int n_live = live_n(c);
+#endif
+    if constexpr (PassWrench<P>::value) wrench_init_all(p.pose);   // (published by the prologue's barrier)
+    if constexpr (PassPrologue<P>::value) { if (!p.prologue(scal)) return; }   // workgroup-uniform
+#ifdef SPH_NO_EARLY_LOADS
+    const int who_early = lane_perm ? (int)lane_perm[i0 + tid] : tid;
+    const int *hdr = blk_hdr + (size_t)b * BLK_HDR_INTS;
+    const int cfirst = hdr[0], clast = hdr[1];
+    const int skip_tile = tile_skip ? (int)tile_skip[b] : 0;
+    const int n_live = live_n(c);
+#endif
     if (i0 >= n_live) {   // launch bound of an asynchronous slab step: no such tile (its header was never written)
         if constexpr (P::HAS_REDUCE) {
             if (tid == 0) {
-                if constexpr (PassSplit<P>::value) { if (gridDim.y > 1) { if (float *o = p.split_out(split_lo((int)gridDim.y, (int)blockIdx.y))) o[b] = 0.0f; } else p.red_out[b] = 0.0f; }
-                else p.red_out[b] = 0.0f;
+                const int bs = red_slot(blk_list, b);
+                if constexpr (PassSplit<P>::value) { if (gridDim.y > 1) { if (float *o = p.split_out(split_lo((int)gridDim.y, (int)blockIdx.y))) o[bs] = 0.0f; } else p.red_out[bs] = 0.0f; }
+                else p.red_out[bs] = 0.0f;
             }
         }
         return;
     }
     // which particle of the workgroup this lane owns for the whole pass
-    const int who = lane_perm ? (int)lane_perm[i0 + tid] : tid;
+    const int who = who_early;
     const int i = i0 + who;
     const bool valid = i < n_live;
 
-    // workgroup header (uniform)
-    const int *hdr = blk_hdr + (size_t)b * BLK_HDR_INTS;
-    const int cfirst = hdr[0], clast = hdr[1];
+    // workgroup header (uniform; requested above)
     const int span = clast - cfirst;
     bool cs_lds = span >= 0 && span <= NBR_CS_SPAN;
 #pragma unroll
@@ -1396,7 +1416,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         // two-way split: nobody walks "part 1" (its group rides in part 0), but the consumers add up three parts: zeros
         if (split_launch && gridDim.y == 2 && blockIdx.y == 0) {
             if (valid && active) p.partial_zero(i, 1);
-            if (tid == 0) { if (float *o = p.split_out(1)) o[b] = 0.0f; }
+            if (tid == 0) { if (float *o = p.split_out(1)) o[red_slot(blk_list, b)] = 0.0f; }
         }
     }
     if (valid && !split_launch) {
@@ -1420,7 +1440,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             float t = 0.0f;
 #pragma unroll
             for (int k = 0; k < BLOCK / 64; ++k) t += s_red[k];
-            red_to[b] = t;
+            red_to[red_slot(blk_list, b)] = t;
         }
     }
 }
@@ -1433,7 +1453,7 @@ k_reduce_partials(const float *__restrict__ partial, int n, DevScalars *__restri
     if (kind && scal->flags[0]) return;
     __shared__ float s_w[4];
     float t = 0.0f;
-    if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) t += partial[blk_list[k]]; }   // the pass ran these only
+    if (blk_list) { const int m = *blk_count; for (int k = threadIdx.x; k < m; k += 256) t += partial[k]; }   // the pass ran the listed tiles only and filed their sums in list order (red_slot)
     else for (int k = threadIdx.x; k < n; k += 256) t += partial[k];
     t = wave_sum(t);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;

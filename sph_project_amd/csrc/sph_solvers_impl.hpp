@@ -139,15 +139,17 @@ static void l_cg_prepare(State &s) {
 // slab sharding: all-reduced dot products live in scal->red[6..7] (see k_cg_fold)
 #define CG_GLOB (s.slab_active ? &s.scal->red[6] : (const float *)nullptr)
 // the per-particle CG kernels run the workgroups that hold fluid only (same list as the neighbour passes)
-#define CG_LIST (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_list : nullptr, (!s.c.all_fluid && s.list_n == s.c.n) ? s.blk_count : nullptr
+// (the same condition as launch_pass's use_list: the A p pass and the vector kernels must agree on where the partial sums are filed, red_slot)
+#define CG_LISTED (!s.c.all_fluid && s.list_n == s.c.n && s.c.force_global == 0)
+#define CG_LIST CG_LISTED ? s.blk_list : nullptr, CG_LISTED ? s.blk_count : nullptr
 // grid of a per-particle CG kernel: the listed workgroups only once the host knows how many there are (list_grid)
-#define CG_GRID(nb) ((!s.c.all_fluid && s.list_n == s.c.n) ? list_grid(s, (nb)) : (nb))
+#define CG_GRID(nb) (CG_LISTED ? list_grid(s, (nb)) : (nb))
 static void l_cg_ap(State &s) {
     const bool split = s.cg_split && s.cg_part && s.c.n > 0;
     s.split_next_pass = split ? s.cg_split : 0;   // 2 or 3 ways (sph_cg_steps.hpp)
     // s.cg_fuse: this A p pass applies the previous iteration's p update on the fly (CgApPass::fuse), p_old = cg_p, p_new = cg_p2
     const int fuse = s.cg_fuse ? 1 : 0;
-    const bool lst = !s.c.all_fluid && s.list_n == s.c.n;
+    const bool lst = CG_LISTED;
     const int nb = s.c.n > 0 ? cdiv(s.c.n, 256) : 0;
     // inside the unsharded loop with the fused p update the split walks leave their shares of p . A p themselves (CG_PART(4..6)) and the
     // x / r update adds the three parts up: no combining kernel (SPH_CG_COMBINE=1: the round-3 sequence, for A/B)
