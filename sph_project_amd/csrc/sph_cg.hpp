@@ -20,6 +20,12 @@ __device__ __forceinline__ void mat3_inverse(const float *a, float *o) {
 // Bytes / particle: R posv 16 + velm 16 + rho 4 + cg_x 16 -> W dinv 36 + b 16 + p 16 + x 16 + v0 16 (+ zero fills).
 template <bool AF>
 struct CgPreparePass {
+    // Active for fluid only and passive() empty (round 5): launched over the fluid-holding tiles alone.  It used to zero the five solver
+    // vectors of every OTHER particle -- 2.07 M boundary particles x 80 B per step in the buckling scene, for entries nothing reads: the
+    // A p walk skips rigid neighbours before it looks at their search direction (CgApPass::pair), the vector kernels test is_fluid, a
+    // ghost's search direction comes from its owner before every walk.  Those entries now keep what they held (zero from the
+    // allocation, or a former fluid occupant's last value -- the solver state is slot-indexed and not reordered by the sort anyway).
+    static constexpr bool FLUID_BLOCKS_ONLY = true;
     static constexpr int BLOCK = 256, GROUPS = 3;
     static constexpr bool USES_J = !AF;   // pair() looks at j only for rigid neighbours
     static constexpr bool HAS_B = true, COUNT_PAIRS = true, HAS_REDUCE = false;
@@ -86,10 +92,7 @@ struct CgPreparePass {
         cg_Ap[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         return 0.0f;
     }
-    __device__ void passive(const Consts &, int i, const float4 &) const {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        cg_r[i] = z; cg_p[i] = z; cg_v0[i] = z; cg_b[i] = z; cg_Ap[i] = z;
-    }
+    __device__ void passive(const Consts &, int, const float4 &) const {}
 };
 
 // ---- one CG iteration in three launches (A p pass, x / r update, p update) instead of six: the kernels that consume a dot

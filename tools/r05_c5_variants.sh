@@ -1,11 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-for v in new old new old new old; do
-  if [ $v = old ]; then export SPH_HIP_LIB=$PWD/sph_project_amd/variants/libsph_hip_noearly.so; else unset SPH_HIP_LIB; fi
-  python tools/bench_c5.py --no-events --steps 20 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('C5 $v (no events): %.4f ms/step %.1f CG it' % (d['ms_per_step'], d['cg_iterations_per_step']))"
-done
-for v in new old new old; do
-  if [ $v = old ]; then export SPH_HIP_LIB=$PWD/sph_project_amd/variants/libsph_hip_noearly.so; else unset SPH_HIP_LIB; fi
-  python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras --motion-step 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('C2 $v %.4f ms/step' % (d['ms_per_step']))"
-  python bench.py --config c3 --steps 50 --warmup 5 --no-cpu-baseline --no-extras --motion-step 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('C3 2+2 $v %.4f ms/step' % d['ms_per_step'])"
-done
+python -m pytest tests -m gpu -x -q -k "visc or implicit or c5 or golden or solvers or round2 or rigid" 2>&1 | tail -3
+for k in 1 2; do python tools/bench_c5.py --no-events --steps 20 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('C5 (no events): %.4f ms/step %.1f CG it' % (d['ms_per_step'], d['cg_iterations_per_step']))"; done
+python tools/bench_c5.py --steps 20 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('C5 with events: %.4f ms/step, %.2f us per CG iteration' % (d['ms_per_step'], 1e3*d['ms_per_cg_iteration']), d['kernels_ms_per_step'])"
