@@ -265,6 +265,22 @@ def sharded_extra(args, rank, world, device, lib, cfg, workload, suffix):
 
 
 # ----------------------------------------------------------------------------------------------- C3 / C5 at N = 1
+def pmc_figures(config, kernel):
+    """Counter-derived figures of one kernel from profiles/pmc_derived.json (separate rocprofv3 --pmc passes, tools/prof.sh; NOT measured
+    in the running process): HBM traffic per launch (2 FETCH_SIZE + WRITE_SIZE) and what actually bounds the kernel."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_derived.json")))
+        e = d.get(config, {}).get(kernel)
+        if not e:
+            return None
+        src = d.get(config, {}).get("_source") or d.get("_source")
+        return {"traffic": e.get("hbm_bytes_per_launch"), "avg_us_in_that_run": e.get("avg_us"),
+                "secondary": {k: e.get(k) for k in ("valu_issue_frac", "waves_parked_frac", "lds_active_frac", "lds_conflict_frac", "eff_clock_ghz")},
+                "traffic_source": f"{src}: 2*FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes; NOT measured in this run"}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def median(v):
     s_ = sorted(v)
     return s_[len(s_) // 2]
@@ -316,7 +332,9 @@ def extra_c3(args, names):
                                              "achieved": 92 * n / (it_us * 1e-6) / 1e9 if it_us else None,
                                              "frac": 92 * n / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else None},
                         "step_achieved": step_bytes / (el / args.steps) / 1e9,
-                        "step_alg_bytes": step_bytes}}
+                        "step_alg_bytes": step_bytes,
+                        **(pmc_figures("c3", dom) or {"traffic": None, "secondary": None}),
+                        "solver_walks": {k: pmc_figures("c3", k) for k in ("dfsph_rho_adv", "dfsph_correct")}}}
     # the same regime once the column collapses (the state a user spends most of a run in)
     c3_motion = int(os.environ.get("SPH_BENCH_C3_MOTION_STEP", "1000"))
     done = args.warmup + 5 + args.repeats * args.steps
@@ -407,7 +425,9 @@ def extra_c5(args, names):
            "kernels": per_pass,
            "roofline": {"bound": "hbm", "kernel": "cg iteration (cg_ap + cg_vector)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS if ach else None, "alg_bytes_per_launch": 224 * nf, "avg_launch_us": it_us,
-                        "note": "224 B per fluid particle per CG iteration (SURVEY 8d); 106 k rows: launch/dependency latency, not bandwidth"}}
+                        **(pmc_figures("c5", "cg_ap") or {"traffic": None, "secondary": None}),
+                        "note": "224 B per fluid particle per CG iteration (SURVEY 8d); 106 k rows: launch/dependency latency, not bandwidth; "
+                                "traffic / secondary are the A p walk's (cg_ap), one of the iteration's two launches"}}
     eng.close()
     return out
 
@@ -501,6 +521,19 @@ def run_rank(args, rank, world, local_rank):
         for k, (n, ms) in sorted(table.items(), key=lambda kv: -kv[1][1]):
             print(f"  {k:24s} launches {n:5d}  avg {1e3 * ms / n:9.1f} us", file=sys.stderr)
     eng.profile_enable(-1, False)
+    # ... and every kernel that carries algorithmic bytes once more ALONE (one kernel id's events at a time): with all ids enabled the
+    # event pairs of neighbouring launches serialise the stream and inflate a walk by 6-8 %.  `all_kernels` / `runner_up`
+    # quote these solo figures; the all-event one is kept beside them.
+    solo = {}
+    if not os.environ.get("SPH_BENCH_NO_EVENTS"):
+        for k in [k for k in table if k in ALG_BYTES]:
+            eng.profile_enable(names.index(k), True); eng.profile_reset()
+            run(3); steps_done += 3
+            eng.synchronize()
+            solo[k] = eng.profile_read(names.index(k))
+            eng.profile_enable(-1, False)
+    table_all = dict(table)
+    table = {k: (solo[k] if k in solo and solo[k][0] > 0 else v) for k, v in table.items()}
 
     def timed(reps):
         """reps x (fence, K steps, fence); returns the per-repetition max-over-ranks seconds"""
@@ -515,6 +548,7 @@ def run_rank(args, rank, world, local_rank):
 
     eng.profile_enable(names.index(dom), not os.environ.get("SPH_BENCH_NO_EVENTS"))
     eng.profile_reset()
+    timed_from = steps_done   # steps of the scene behind it when the timed region starts
     reps = timed(args.repeats); steps_done += args.repeats * args.steps
     elapsed = median(reps)
     launches, ms = eng.profile_read(names.index(dom))
@@ -560,7 +594,7 @@ def run_rank(args, rank, world, local_rank):
             if e:
                 traffic = e.get("hbm_bytes_per_launch")
                 secondary = {k: e.get(k) for k in ("valu_issue_frac", "waves_parked_frac", "lds_active_frac", "lds_conflict_frac", "eff_clock_ghz")}
-                pmc_source = d.get("_source")
+                pmc_source = d.get(args.config, {}).get("_source") or d.get("_source")
         except Exception:  # noqa: BLE001
             pass
     copy_gbs = None
@@ -588,7 +622,7 @@ def run_rank(args, rank, world, local_rank):
             "deterministic_sort": not args.no_deterministic,
             "parallelism": "single-gpu" if world == 1 else
                            (f"z-slab x{world}, {transport} halo exchange ({scaling} scaling)" if sharded else f"replicas x{world}"),
-            "state": "steps %d..%d from the initial lattice" % (args.presteps + args.warmup + 5, args.presteps + args.warmup + 5 + args.repeats * args.steps),
+            "state": "steps %d..%d from the initial lattice" % (timed_from, timed_from + args.repeats * args.steps),
             "pair_interactions_per_step": int(pairs),
             "pair_interactions_per_s": pairs * args.steps / elapsed,      # every accepted pair once per REFERENCE pass
             "pair_evaluations_per_step": int(evals),
@@ -600,7 +634,7 @@ def run_rank(args, rank, world, local_rank):
         },
         "in_motion": in_motion,
         "value_state": "from rest (steps %d.. of the initial lattice, %s neighbours per particle); `value_in_motion` is the same scene from step %s on"
-                       % (args.presteps + args.warmup + 5, ("%.0f" % (evals / max(n_total, 1) / 2.0)) if method == "wcsph" else "n/a", args.motion_step),
+                       % (timed_from, ("%.0f" % (evals / max(n_total, 1) / 2.0)) if method == "wcsph" else "n/a", args.motion_step),
         "value_in_motion": in_motion["value"] if in_motion else None,
         "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -616,8 +650,10 @@ def run_rank(args, rank, world, local_rank):
             "step_frac_of_measured_copy": (step_bytes / (elapsed / args.steps) / 1e9 / copy_gbs) if copy_gbs else None,
             "secondary": secondary,
             # the two neighbour walks of a WCSPH step are within 2-3 % of each other, so which one is "dominant" can flip between runs --
-            # and with it `frac` (24 vs 96 algorithmic bytes per particle).  Both, from the all-kernel event pre-pass of this run:
-            "all_kernels": {k: {"avg_us": 1e3 * v[1] / v[0], "alg_bytes_per_launch": ALG_BYTES[k] * n_fluid,
+            # and with it `frac` (24 vs 96 algorithmic bytes per particle).  Both, each from an event pass of its own in this run (one kernel id
+            # enabled at a time; `avg_us_with_all_events_on` is the 6-8 % higher figure of the pass with every id enabled):
+            "all_kernels": {k: {"avg_us": 1e3 * v[1] / v[0], "avg_us_with_all_events_on": 1e3 * table_all[k][1] / table_all[k][0],
+                                "alg_bytes_per_launch": ALG_BYTES[k] * n_fluid,
                                 "frac": ALG_BYTES[k] * n_fluid / (v[1] / v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                             for k, v in table.items() if k in ALG_BYTES},
             "runner_up": (lambda ru: None if ru is None else {"kernel": ru, "avg_launch_us": 1e3 * table[ru][1] / table[ru][0],

@@ -21,5 +21,6 @@ for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS S
   timeout 150 rocprofv3 --kernel-trace --pmc $CTRS -d $OUT/pmc$i -o pmc --output-format csv -- $BENCH > $OUT/pmc$i.log 2>&1
 done
 cd $REPO
-python tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+# JSON_ARGS="--json gpurun_out/pmc_derived.json --config c3 --source profiles/<name>.txt" also merges the derived figures into that file
+python tools/prof_summary.py $OUT ${JSON_ARGS:-} > $OUT/summary.txt 2>&1
 tail -60 $OUT/summary.txt

@@ -104,6 +104,7 @@ def main(out, json_path=None, config="c2", source=None):
                 if kid:
                     ent[kid] = {kk: vv for kk, vv in d.items() if vv is not None}
             doc["_source"] = source or out
+            ent["_source"] = source or out   # (per configuration: the passes of C2, C3 and C5 are separate runs with separate summary files)
             doc["_note"] = ("per launch, from separate rocprofv3 --pmc passes of `bench.py` (tools/prof.sh), condensed by tools/prof_summary.py; "
                             "formulas in the summary file named by _source")
             json.dump(doc, open(json_path, "w"), indent=1, sort_keys=True)
