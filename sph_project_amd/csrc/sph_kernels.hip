@@ -115,7 +115,11 @@ void l_scatter_stable(State &s) { l_scatter_impl(s, true); }
 int list_grid(State &s, int nb) {
     static const bool off = getenv("SPH_NO_LIST_GRID") != nullptr;
     if (off || !s.list_count_pinned) return nb;
-    if (s.list_count_known < 0 && s.list_count_event && hipEventQuery(s.list_count_event) == hipSuccess) s.list_count_known = *s.list_count_pinned;
+    if (s.list_count_known < 0 && s.list_count_event) {
+        const hipError_t q = hipEventQuery(s.list_count_event);
+        if (q == hipSuccess) s.list_count_known = *s.list_count_pinned;
+        else if (q == hipErrorNotReady && hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();   // "not yet" is no launch failure (check_async, sph_api.hip)
+    }
     const int g = s.list_count_known >= 0 ? s.list_count_known : nb;
     return g < 1 ? 1 : (g > nb ? nb : g);
 }
