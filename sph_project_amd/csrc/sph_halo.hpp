@@ -118,6 +118,7 @@ struct HaloStep {
     const HaloCtl *in_ctl[2];     // my inbox control blocks
     const float4 *recv[2];        // my step-message regions for this message
     unsigned seq;
+    unsigned hdr_bank_mask;       // 1: header of message m in rec[m & 1] (normal); 0: one header for all messages (SPH_TEST_SINGLE_HEADER: the pre-round-5 protocol, for the A/B that pins the race)
     int stride, cap, halo_cap;
     int n_old;                    // particle count before the exchange when the host knows it exactly, else -1: last step's n_live
     int bound_app, bound_live;    // launch bounds of an asynchronous step (0: the host launches exact grids afterwards)
@@ -137,7 +138,7 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
         const int lane = threadIdx.x;
         // my own header first (workgroup 0): a neighbour waiting for it is released before I start waiting for its
         if (blockIdx.x == 0 && lane < 2 && w.out_ctl[lane]) {
-            HaloRecHdr *hd = &w.out_ctl[lane]->rec[w.seq & 1u];
+            HaloRecHdr *hd = &w.out_ctl[lane]->rec[w.seq & w.hdr_bank_mask];
             const int cnt = w.counts[HC(lane)];
             halo_store_sys(&hd->count, cnt);
             halo_store_sys(&hd->status, w.dyn_old->status | (cnt > w.halo_cap ? SLAB_ST_SEND_OVERFLOW : 0));
@@ -147,7 +148,7 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
         }
         int cnt = 0, st = 0;
         if (lane < 2 && w.in_ctl[lane]) {
-            const HaloRecHdr *hd = &w.in_ctl[lane]->rec[w.seq & 1u];   // (this message's own header: the next one goes to the other)
+            const HaloRecHdr *hd = &w.in_ctl[lane]->rec[w.seq & w.hdr_bank_mask];   // (this message's own header: the next one goes to the other)
             // (after a time-out the exchange is dead: later waits give up at once instead of stacking 30 s each on the stream)
             const long long patience = (w.dyn_old->status & SLAB_ST_TIMEOUT) ? 0 : w.timeout_ticks;
             if (!halo_poll(&hd->seq, w.seq, patience)) st |= SLAB_ST_TIMEOUT;

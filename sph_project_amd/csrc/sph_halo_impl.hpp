@@ -71,6 +71,8 @@ static void l_halo_unpack2(State &s, int n_old, int bound_app, int bound_live, i
         w.in_ctl[side] = s.push.peer[side] ? inbox_ctl(s.push.inbox, side) : nullptr;
         w.recv[side] = (const float4 *)inbox_rec(s, s.push.inbox, side, seq);
     }
+    static const unsigned bank_mask = getenv("SPH_TEST_SINGLE_HEADER") ? 0u : 1u;
+    w.hdr_bank_mask = bank_mask;
     w.seq = seq; w.stride = s.orig.cur() ? 4 : 3; w.cap = s.cap; w.halo_cap = s.push.rec_cap;
     w.n_old = n_old; w.bound_app = bound_app; w.bound_live = bound_live; w.timeout_ticks = s.push.timeout_ticks;
     w.counts = s.halo_counts + HC_BANK * (seq & 1u); w.counts_next = s.halo_counts + HC_BANK * ((seq + 1) & 1u);
