@@ -18,5 +18,6 @@ done
 cp gpurun_out/pmc_derived.json $O/pmc_derived.json
 timeout 200 python bench.py --presteps 2500 --steps 100 --warmup 10 --no-cpu-baseline --no-extras --all-kernels > $O/motion.json 2> $O/motion.err; grep -v "No rigid" $O/motion.err | head -8
 timeout 200 python tools/bench_c5.py --no-events --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/bench_c5.json; cat $O/bench_c5.json | cut -c1-300
+timeout 200 python bench.py --config c4 --steps 50 --warmup 5 --no-cpu-baseline --no-extras --motion-step 0 2>/dev/null | tail -1 | cut -c1-260 > $O/bench_c4_one_gpu.json; cat $O/bench_c4_one_gpu.json; echo
 timeout 200 python tools/slab_size_probe.py --steps 200 > $O/slab_size_probe.json 2>/dev/null; cat $O/slab_size_probe.json
 SPH_COMM_TRANSPORT=shm+ipc timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 20 --warmup 5 > $O/torchrun_two_ranks.json 2> $O/torchrun_two_ranks.err; tail -c 600 $O/torchrun_two_ranks.json; echo; tail -3 $O/torchrun_two_ranks.err
