@@ -175,3 +175,28 @@ def test_oracle_matches_reference_source(path):
         for k, v in w.items():
             assert v < lim.get(k, 2e-3), (cp, k, v, w)
     print(os.path.basename(path), report)
+
+
+def test_oracle_wrench_is_the_serial_sum_for_any_thread_count():
+    """Round 5: the oracle's rigid_body_forces / _torques used to be added under a lock in whatever order the OpenMP threads arrived (f32
+    addition does not commute in the last bits), while the product's wrench is bit-reproducible.  Now every thread logs its pairs and
+    flush_rigid_wrench adds them in (particle, walk order): 1 and 7 threads must give the same BITS -- those of the reference's serial semantics."""
+    import ctypes
+    gomp = ctypes.CDLL("libgomp.so.1")
+    before = int(gomp.omp_get_max_threads())
+    path = [p for p in GOLDEN if os.path.basename(p) == "rigid_wcsph.npz"][0]
+    z, cfg = _load(path)
+    out = []
+    try:
+        for threads in (1, 7):
+            gomp.omp_set_num_threads(threads)
+            sim, _ = _oracle_from_fixture(z, cfg)
+            sim.prepare()
+            H.oracle_step(sim, 4)
+            out.append((sim.field("rigid_body_forces").copy(), sim.field("rigid_body_torques").copy(), sim.field("particle_positions").copy()))
+            sim.close()
+    finally:
+        gomp.omp_set_num_threads(before)
+    assert np.abs(out[0][0]).max() > 0, "the scene exerts a force on its dynamic body"
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
