@@ -145,6 +145,11 @@ struct HaloSend {
     const int *pid; const unsigned *color; const float4 *orig;
 };
 
+// What the WCSPH force pass needs to be the NEXT step's k_hash_count as well (round 5): it knows every particle's new position when it
+// stores it, so it files the new cell id, takes the histogram atomic (one per run of equal cells among the tile's particles in sorted
+// order, like k_hash_count) and leaves the arrival rank.  on = 0: the next step hashes as usual.
+struct NextHash { int on; int *cellid, *rank, *cell_count; };
+
 // ... and what the WCSPH density pass needs to store (rho_raw, rho, p, p / rho^2) of its boundary particles straight into the field
 // message of the neighbours' inboxes (the message k_halo_pack2<2> would gather afterwards): out[side] = that message's region, xidx = the
 // exchange tags of this sort, dyn = this step's counts (the echo part of a message starts behind its n_send records)
@@ -238,6 +243,8 @@ struct State {
     HaloSend presend;    // on != 0: the next wcsph_forces launch classifies its particles and sends the next step message itself
     HaloFieldSend fieldsend;   // on != 0: the next WCSPH density launch stores its boundary values into the field message itself
     int preclassified;   // ... and has done so: the next step's exchange starts with the hash alone
+    NextHash nexthash;   // on != 0: the next wcsph_forces launch hashes the particles for the next step's sort itself
+    int prehashed;       // ... and has done so: the next step's sort starts with the scan (l_hash_count returns at once)
     int halo_cap;        // particles per message buffer
     int halo_longest;    // longest halo message of the running step, in particles (sent or received)
     int slab_active, z_lo, z_hi, has_down, has_up;

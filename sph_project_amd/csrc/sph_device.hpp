@@ -510,6 +510,10 @@ __device__ __forceinline__ void wrench_init_all(const RigidPose *pose);
 __device__ __forceinline__ void wrench_flush_all(DevScalars *scal);
 template <class P, class = void> struct PassStatW { static constexpr bool value = false; };
 template <class P> struct PassStatW<P, decltype((void)P::STAT_W)> { static constexpr bool value = P::STAT_W; };
+// P::NEXT_HASH: the functor's finish() leaves the particle's NEW cell in Own::lin_new and carries a NextHash `nh`: when nh.on, the kernel's
+// epilogue does for the next step's sort what k_hash_count would do (WcsphForcePass)
+template <class P, class = void> struct PassNextHash { static constexpr bool value = false; };
+template <class P> struct PassNextHash<P, decltype((void)P::NEXT_HASH)> { static constexpr bool value = P::NEXT_HASH; };
 template <class P, class = void> struct PassPrologue { static constexpr bool value = false; };
 template <class P> struct PassPrologue<P, decltype((void)P::HAS_PROLOGUE)> { static constexpr bool value = P::HAS_PROLOGUE; };
 
@@ -1424,6 +1428,25 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         else p.passive(c, i, pi);
     }
     NBR_STAMP(15);
+    if constexpr (PassNextHash<P>::value) {
+        if (p.nh.on) {   // (uniform) this pass is the next step's k_hash_count: cell ids, histogram, arrival ranks from the positions just stored
+            // The lanes own the tile's particles in permuted order; the histogram wants them in SORTED order, where the particles of a cell
+            // are neighbours and one atomic serves a whole run: through LDS (the tile is dead: barrier at the end of the last group).
+            int *const s_lin = reinterpret_cast<int *>(sT);
+            __syncthreads();   // (workgroups that skipped the group loop have no barrier behind their last tile access)
+            s_lin[who] = (valid && active) ? own.lin_new : -1 - who;   // all-fluid, unsharded: every valid particle is active
+            __syncthreads();
+            const int lane = tid & 63;
+            const bool v2 = i0 + tid < n_live;
+            const int lin = v2 ? s_lin[tid] : -1 - lane;
+            bool head; int hl, len;
+            wave_runs(lin, lane, head, hl, len);
+            int base = 0;
+            if (head && v2) base = atomicAdd(&p.nh.cell_count[lin], len);
+            base = __shfl(base, hl, 64);
+            if (v2) { p.nh.cellid[i0 + tid] = lin; p.nh.rank[i0 + tid] = base + (lane - hl); }
+        }
+    }
     if (split_launch && !red_to) return;   // uniform; the combining kernel reduces
     if constexpr (P::HAS_REDUCE) {
         // deterministic per-workgroup partial sum: particle order and a fixed tree (whatever the lane permutation),

@@ -26,6 +26,11 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 void l_hash_count(State &s) {
     const int n = s.c.n;
+    if (s.prehashed) {   // the last step's force pass has hashed for this sort (NextHash): cell ids, histogram and ranks are in place
+        s.prehashed = 0;
+        s.cell_count_clean = 0;
+        return;
+    }
     if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + SPH_NGRAVE + 1), s.stream);
     s.cell_count_clean = 0;
     if (n == 0) return;
@@ -254,29 +259,35 @@ void l_pressure_integrate(State &s) {
 
 // WCSPH.py:30-36, 45 as one pass (see WcsphForcePass); same buffer choreography as the two passes it replaces
 void l_wcsph_forces(State &s) {
+    // this pass as the next step's k_hash_count (NextHash): only where the histogram is clean (the scan cleared it behind itself) and
+    // every particle is an active fluid particle of an unsharded scene (wcsph_step decides whether another step follows untouched)
+    NextHash nh{0, s.cellid, s.rank, s.cell_count};
+    if (s.nexthash.on && s.c.all_fluid && !s.slab_active && s.cell_count_clean && s.density_books_forces && s.c.n > 0) nh.on = 1;
+    s.nexthash.on = 0;
     if (!s.density_books_forces) {   // launched outside wcsph_step's density + forces pair: nobody has booked this walk's pairs
         if (s.c.all_fluid) {
-            WcsphForcePass<true, false, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend};
+            WcsphForcePass<true, false, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};
             launch_pass(s, p, 2);
         } else {
-            WcsphForcePass<false, false, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend};
+            WcsphForcePass<false, false, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};
             launch_pass(s, p, 2);
         }
     } else
 #if SPH_FAST
     if (s.c.all_fluid && s.uniform_mass && !s.slab_active) {   // one fluid mass in the whole scene: the instantiation with the mass products hoisted (same sums)
-        WcsphForcePass<true, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend};
+        WcsphForcePass<true, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};
         launch_pass(s, p, 2);
     } else
 #endif
     if (s.c.all_fluid) {
-        WcsphForcePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend};
+        WcsphForcePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};
         launch_pass(s, p, 2);
     } else {
-        WcsphForcePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend};
+        WcsphForcePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};
         launch_pass(s, p, 2);
     }
     if (s.presend.on) { s.presend.on = 0; s.preclassified = 1; }
+    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; }
     s.velm.flip();
     s.posv.flip();
     s.masks_valid = 0;  // positions moved

@@ -390,10 +390,16 @@ struct WcsphForcePass {
         float pt, p, rho2, px, py, pz, x, y, z, m0;                // pressure part (PressurePass::Own)
         float cvm, cstm;                                           // UM: c.cv m and (st / m rho0) m, the same roundings as per pair
         int dyn;
+        int lin_new;                                               // cell of the position finish() / passive() stored (NEXT_HASH)
     };
+    static constexpr bool NEXT_HASH = AF;   // the all-fluid instantiations can hash for the next step (k_nbr_pass epilogue); `nh.on` decides per launch
     const float4 *posv, *velm; const int *meta; const float *rho_raw, *ptm, *prs, *rho;
     float4 *vel_out, *acc, *posv_out; DevScalars *scal; const RigidPose *pose; float rho0;
     HaloSend hs;   // slab sharding: classify + send the next step message from here (sph_halo_defs.hpp); hs.on = 0 otherwise
+    NextHash nh;   // unsharded all-fluid steps with another step queued behind them: this pass is the next step's k_hash_count (nh.on)
+    __device__ int cell_of(const Consts &c, float x, float y, float z) const {   // k_hash_count's cell (IEEE division in both builds)
+        return (cell_coord_x(c, x) * c.ny + cell_coord(y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, z);
+    }
 
     __device__ float4 loadA(int j) const { return posv[j]; }
     __device__ float4 stage(const Consts &, int j, BT &bj, CT &cj) const {
@@ -530,6 +536,7 @@ struct WcsphForcePass {
             acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             posv_out[i] = pi;
             if (hs.on) halo_presend(c, hs, i, pi, make_float4(vx, vy, vz, o.m), rho[i]);
+            if (NEXT_HASH && nh.on) o.lin_new = cell_of(c, pi.x, pi.y, pi.z);
             return 0.0f;
         }
         // pressure update, advection, boundary (:136, :643, :652, :575)
@@ -540,6 +547,7 @@ struct WcsphForcePass {
         posv_out[i] = make_float4(x, y, z, pi.w);
         vel_out[i] = make_float4(vx, vy, vz, o.m);
         if (hs.on) halo_presend(c, hs, i, make_float4(x, y, z, pi.w), make_float4(vx, vy, vz, o.m), rho[i]);
+        if (NEXT_HASH && nh.on) o.lin_new = cell_of(c, x, y, z);
         return 0.0f;
     }
     __device__ void passive(const Consts &c, int i, const float4 &pi) const {

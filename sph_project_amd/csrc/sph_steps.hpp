@@ -116,6 +116,11 @@ static int wcsph_step(SphHandle *h) {
         if (s.slab_active && s.push.on && h->steps_to_follow > 0 && !rebalance_next && !s.has_emitter && !h->any_rigid_object &&
             !h->sort_dirty && !getenv("SPH_NO_SLAB_PRESEND"))
             h->L->halo_presend_begin(s);
+        // Unsharded, all fluid, another step of this call queued right behind (nothing can touch the particles in between): the force pass
+        // hashes the positions it stores for the next step's sort (NextHash) -- one launch less per step.
+        static const bool no_nexthash = getenv("SPH_NO_NEXT_HASH") != nullptr;
+        s.nexthash.on = (!no_nexthash && !s.slab_active && s.c.all_fluid && h->steps_to_follow > 0 && !s.has_emitter && !h->any_rigid_object &&
+                         !h->sort_dirty) ? 1 : 0;
         ProfScope p(h, SPH_K_WCSPH_FORCES); h->L->wcsph_forces(s);            // :30-31 + :34-36, :45 in one neighbour walk
         return SPH_OK;
     }
