@@ -251,3 +251,60 @@ def test_bench_secondary_bound_is_recomputable_from_the_committed_profile():
                 checked += 1
     assert set(doc) >= {"c2", "c3", "c5"} and "density" in doc["c2"] and "wcsph_forces" in doc["c2"] and "cg_ap" in doc["c5"]
     assert checked >= 14
+
+
+def test_run_record_stable_rank_model():
+    """The deterministic sort of round 5 (csrc/sph_device.hpp k_scatter_index / k_scatter<true>) as a numpy model, against a stable argsort:
+    the histogram hands every RUN (consecutive source particles of a wave with the same cell -- and, for the records, consecutive SLOTS) a
+    block of its cell's slots in whatever order the atomics land; the stable rank of a particle is (lengths of the cell's runs that start at a
+    lower source index) + (its position inside its run).  Includes what broke the first version on the GPU: particles that took their slots one
+    by one (the arrivals a slab step appends) and happen to sit next to each other in the source order."""
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        n_cells = int(rng.integers(3, 40))
+        n_old = int(rng.integers(1, 600))
+        n_new = int(rng.integers(0, 80))                      # arrivals: appended behind, one atomic each
+        # last step's sorted order with a few particles that changed cell
+        cell = np.sort(rng.integers(0, n_cells, n_old))
+        move = rng.random(n_old) < 0.15
+        cell[move] = np.clip(cell[move] + rng.integers(-1, 2, move.sum()), 0, n_cells - 1)
+        cell = np.concatenate([cell, rng.integers(0, n_cells, n_new)]).astype(np.int64)
+        n = n_old + n_new
+        # k_hash_count: runs of equal cell inside waves of 64 source particles (old particles only), one "atomic" per run, in a random order
+        wave = np.arange(n) // 64
+        head_hash = np.ones(n, bool)
+        head_hash[1:n_old] = (cell[1:n_old] != cell[:n_old - 1]) | (wave[1:n_old] != wave[:n_old - 1])
+        heads = np.nonzero(head_hash[:n_old])[0]
+        lens = np.diff(np.concatenate([heads, [n_old]]))
+        count = np.zeros(n_cells, np.int64)
+        slot = np.zeros(n, np.int64)
+        for k in rng.permutation(len(heads)):                 # the order the atomics are served in
+            h, L = heads[k], lens[k]
+            slot[h:h + L] = count[cell[h]] + np.arange(L)
+            count[cell[h]] += L
+        for i in rng.permutation(np.arange(n_old, n)):        # k_halo_unpack2: the arrivals, one atomic each, after the hash
+            slot[i] = count[cell[i]]; count[cell[i]] += 1
+        start = np.concatenate([[0], np.cumsum(count)])
+        # k_scatter_index: a record (first index, length) per run, filed at the run's first slot; runs must be contiguous in cell AND slot
+        head = np.ones(n, bool)
+        head[1:] = (cell[1:] != cell[:-1]) | (slot[1:] != slot[:-1] + 1) | (wave[1:] != wave[:-1])
+        hs = np.nonzero(head)[0]
+        ls = np.diff(np.concatenate([hs, [n]]))
+        rec = {}
+        for h, L in zip(hs, ls):
+            rec[start[cell[h]] + slot[h]] = (h, L)
+        # k_scatter<true>: the head walks its cell's records by jumping over their lengths
+        dest = np.empty(n, np.int64)
+        for h, L in zip(hs, ls):
+            c = cell[h]
+            r0, p = 0, start[c]
+            while p < start[c + 1]:
+                assert p in rec, "the walk must land on run starts only"
+                first, length = rec[p]
+                if first < h:
+                    r0 += length
+                p += length
+            dest[h:h + L] = start[c] + r0 + np.arange(L)
+        want = np.empty(n, np.int64)
+        want[np.argsort(cell, kind="stable")] = np.arange(n)
+        np.testing.assert_array_equal(dest, want)
