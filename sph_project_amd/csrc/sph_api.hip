@@ -788,7 +788,12 @@ extern "C" int sph_step_async(SphHandle *h, int nsteps) {
         h->steps_to_follow = nsteps - 1 - k;   // (a sharded WCSPH step may start the next step's halo message behind its own force pass)
         int rc = step_once(h, false);
         h->steps_to_follow = 0;
-        if (rc) return rc;
+        if (rc) {
+            // a failed step may leave a hash its force pass made for a successor that will not come (NextHash): the next sort, whoever
+            // asks for it, must hash for itself on a clean histogram
+            if (h->st.prehashed) { h->st.prehashed = 0; h->st.cell_count_clean = 0; }
+            return rc;
+        }
     }
     return check_async(h);
 }
