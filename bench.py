@@ -30,8 +30,9 @@ the host cores, a bounded sample of the same workload, swept over thread counts;
 Extra objects of the line (never `value`): N = 1: `extras.c3` (BASELINE configs[2]: DFSPH, 2+2 iterations, per-walk
 microseconds, 92 B/particle/iteration roofline) and `extras.c5` (configs[4]: the implicit-viscosity buckling scene with the
 solvers' stop tests, CG iterations per step, microseconds per CG iteration, 224 B/particle/iteration roofline); N > 1:
-`c2_strong_scaling` (the metric as BASELINE.json words it: the 1.23 M scene itself over the N ranks) and
-`c4_strong_scaling` (configs[3]), each on a communicator of its own, with the halo transport in effect.
+the headline itself is the metric as BASELINE.json words it -- the 1.23 M scene split over the N ranks (`scaling: strong`);
+`c2_weak_scaling` (one C2 block per rank) and `c4_strong_scaling` (configs[3]) follow on communicators of their own, with the
+halo transport in effect.
 """
 import argparse
 import json
@@ -77,8 +78,10 @@ def parse_args(argv=None):
     ap.add_argument("--motion-step", type=int, default=2500,
                     help="after the headline measurement advance the scene to this step and time again (`in_motion`); 0: skip")
     ap.add_argument("--all-kernels", action="store_true", help="also print the per-kernel HIP-event table (stderr)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = every z-slab gets one C2 block (N x 1.23 M particles); strong = the 1.23 M scene is split")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N>1: strong (default) = BASELINE.json's metric as written: the 1.23 M scene itself split over the N ranks; "
+                         "weak = every z-slab gets one C2 block (N x 1.23 M particles) -- without this flag weak scaling is the extra "
+                         "object `c2_weak_scaling` of the line")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent copies instead of z-slab sharding")
     ap.add_argument("--no-c4", action="store_true", help="N>1: skip the extra C4 (4 M particles, strong scaling) measurement")
     ap.add_argument("--no-extras", action="store_true",
@@ -170,6 +173,13 @@ def cpu_baseline(cfg, steps):
     Threads are bound (OMP_PROC_BIND=spread over OMP_PLACES=cores, set before libgomp is loaded) and the oracle first-touches
     its arrays page-interleaved over the threads, so that a two-socket box is not limited by the memory of one node."""
     import ctypes
+    # hardware threads this PROCESS may run on, read before libgomp exists: OMP_PROC_BIND binds the calling thread to its own place
+    # (one core = 2 hardware threads) as soon as the runtime starts, after which sched_getaffinity(0) of this thread says 2 -- the
+    # figure rounds 4-5 printed as `affinity_threads` beside a 14x speed-up
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = None
     os.environ.setdefault("OMP_PROC_BIND", "spread")
     os.environ.setdefault("OMP_PLACES", "cores")
     from tests import helpers as H
@@ -210,21 +220,18 @@ def cpu_baseline(cfg, steps):
         quota = None if a == "max" else float(a) / float(b_)
     except (OSError, ValueError):
         pass
-    try:
-        affinity = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        affinity = None
     return dict(value=table[best], cores=best, secs=best_dt, pairs_per_s=pairs * steps / best_dt, sweep=table, model=model, ncpu=ncpu,
                 cpu_quota_cores=quota, affinity_threads=affinity,
                 speedup_over_1_thread=table[best] / table[1] if 1 in table else None)
 
 
 # ----------------------------------------------------------------------------------------------- fixed scenes on N GPUs
-def sharded_extra(args, rank, world, device, lib, cfg, workload, suffix):
-    """One FIXED scene z-slab sharded over the N ranks of this job (strong scaling), measured after the headline with a
-    communicator of its own and reported as an extra object of the JSON line, never as `value`:
-      * `c2_strong_scaling`: BASELINE.json's metric as written ("at 1.23M particles, 1/2/4/8 GPU"): the C2 scene itself;
-      * `c4_strong_scaling`: BASELINE configs[3], the 4,000,000-particle WCSPH dam break."""
+def sharded_extra(args, rank, world, device, lib, cfg, workload, suffix, scaling="strong"):
+    """One more scene z-slab sharded over the N ranks of this job, measured after the headline with a communicator of its
+    own and reported as an extra object of the JSON line, never as `value`:
+      * `c4_strong_scaling`: BASELINE configs[3], the 4,000,000-particle WCSPH dam break;
+      * `c2_weak_scaling`: one C2 block per rank (N x 1,231,200 particles) -- a workload BASELINE.json does not name;
+      * `c2_strong_scaling` (only with --scaling weak, where the headline is the weak one): the C2 scene itself."""
     import numpy as np
     from sph_project_amd import product as P, slab
     uid = exchange_unique_id(lib, rank, suffix=suffix)
@@ -258,7 +265,7 @@ def sharded_extra(args, rank, world, device, lib, cfg, workload, suffix):
         except OSError:
             pass
     eng.close()
-    return {"workload": workload, "scaling": "strong", "particles": n_global, "n_gpus": world,
+    return {"workload": workload, "scaling": scaling, "particles": n_global, "n_gpus": world,
             "ms_per_step": 1e3 * el / args.steps, "value": n_global * args.steps / el, "unit": "particle-updates/s",
             "pair_interactions_per_s": pairs * args.steps / el, "slab_cuts": [int(c) for c in cuts], "owned_per_rank": owned,
             "halo_transport": transport, "steps": args.steps, "warmup": args.warmup}
@@ -554,11 +561,20 @@ def run_rank(args, rank, world, local_rank):
     eng.profile_enable(names.index(dom), not os.environ.get("SPH_BENCH_NO_EVENTS"))
     eng.profile_reset()
     timed_from = steps_done   # steps of the scene behind it when the timed region starts
+    st_before = solver.stats()
     reps = timed(args.repeats); steps_done += args.repeats * args.steps
     elapsed = median(reps)
     launches, ms = eng.profile_read(names.index(dom))
     eng.profile_enable(-1, False)
     stats = solver.stats()
+    # Which sort path did the timed region take?  Inside one sph_step_async(K) of an unsharded all-fluid WCSPH scene the force pass of
+    # every step but the last is also the next step's init_grid (NextHash): it then moves the hash's 16 B per particle as well, and
+    # its algorithmic bytes are 96 + 16 = 112 (the step's 204 B are unchanged: the hash kernel's 16 B moved, they did not vanish).
+    prehashed = int(stats.get("prehashed_sorts", 0) - st_before.get("prehashed_sorts", 0))
+    hashed = int(stats.get("hash_launches", 0) - st_before.get("hash_launches", 0))
+    alg_bytes = dict(ALG_BYTES)
+    if prehashed > 0 and prehashed + hashed > 0:
+        alg_bytes["wcsph_forces"] = ALG_BYTES["wcsph_forces"] + ALG_BYTES["hash_count"] * prehashed / (prehashed + hashed)
     pairs, evals = stats["pair_interactions"], stats["pair_evaluations"]
     if sharded or force_slab:
         n_total = n_global  # every fluid particle is owned by exactly one rank
@@ -571,7 +587,7 @@ def run_rank(args, rank, world, local_rank):
     # (a sharded step may run a pass as two launches -- boundary tiles, then interior tiles: per-launch figures are then per PASS)
     passes = args.repeats * args.steps if launches > 1.5 * args.repeats * args.steps else launches
     avg_s = (ms / max(passes, 1)) * 1e-3
-    achieved = ALG_BYTES[dom] * n_fluid / avg_s / 1e9 if launches else None
+    achieved = alg_bytes[dom] * n_fluid / avg_s / 1e9 if launches else None
 
     in_motion = None
     fixed_work = method == "wcsph" or not args.measured_iterations   # (measured-iteration loops: ms/step is the iteration count's)
@@ -647,7 +663,12 @@ def run_rank(args, rank, world, local_rank):
             "traffic_source": (f"{pmc_source}: 2*FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes; NOT measured in this run"
                                if traffic else None),
             "launches": int(launches), "avg_launch_us": 1e6 * avg_s,
-            "alg_bytes_per_launch": ALG_BYTES[dom] * n_fluid,
+            "alg_bytes_per_launch": alg_bytes[dom] * n_fluid,
+            "alg_bytes_per_particle": alg_bytes[dom],
+            "sort_path": {"steps_timed": args.repeats * args.steps, "hash_kernel_launches": hashed, "hashed_by_the_force_pass": prehashed,
+                          "note": "NextHash: inside one sph_step_async(K) the force pass also files cell id / histogram / arrival rank of the next "
+                                  "sort (16 B per particle on top of its 96); tests/test_hip_wcsph.py::test_c2_full_size_20_steps runs this "
+                                  "path against the oracle and asserts these counters"},
             "step_achieved": step_bytes / (elapsed / args.steps) / 1e9, "step_alg_bytes": step_bytes,
             "step_frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,   # whole step: does not depend on which kernel is "dominant"
             "measured_copy_gbs": copy_gbs,
@@ -658,11 +679,11 @@ def run_rank(args, rank, world, local_rank):
             # and with it `frac` (24 vs 96 algorithmic bytes per particle).  Both, each from an event pass of its own in this run (one kernel id
             # enabled at a time; `avg_us_with_all_events_on` is the 6-8 % higher figure of the pass with every id enabled):
             "all_kernels": {k: {"avg_us": 1e3 * v[1] / v[0], "avg_us_with_all_events_on": 1e3 * table_all[k][1] / table_all[k][0],
-                                "alg_bytes_per_launch": ALG_BYTES[k] * n_fluid,
-                                "frac": ALG_BYTES[k] * n_fluid / (v[1] / v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                "alg_bytes_per_launch": alg_bytes[k] * n_fluid,
+                                "frac": alg_bytes[k] * n_fluid / (v[1] / v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                             for k, v in table.items() if k in ALG_BYTES},
             "runner_up": (lambda ru: None if ru is None else {"kernel": ru, "avg_launch_us": 1e3 * table[ru][1] / table[ru][0],
-                                                               "frac": ALG_BYTES[ru] * n_fluid / (table[ru][1] / table[ru][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                               "frac": alg_bytes[ru] * n_fluid / (table[ru][1] / table[ru][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                                "note": "second kernel by time; when it is within a few per cent of `kernel`, which of the two "
                                                                        "is 'dominant' -- and with it `frac` (their algorithmic bytes differ 4x) -- can flip between runs"})(
                 max((k for k in table if k in ALG_BYTES and k != dom), key=lambda k: table[k][1], default=None)),
@@ -681,7 +702,8 @@ def run_rank(args, rank, world, local_rank):
             "pair_interactions_per_s": cb["pairs_per_s"], "cpu": cb["model"], "hardware_threads": cb["ncpu"],
             "threads_sweep": {str(k): v for k, v in cb["sweep"].items()},
             "speedup_over_1_thread": cb["speedup_over_1_thread"],
-            "cgroup_cpu_quota_cores": cb["cpu_quota_cores"], "affinity_threads": cb["affinity_threads"],
+            "cgroup_cpu_quota_cores": cb["cpu_quota_cores"],
+            "affinity_threads": cb["affinity_threads"],   # of the process, before OpenMP bound the calling thread to its own core
             "thread_binding": "OMP_PROC_BIND=%s OMP_PLACES=%s, arrays first-touched page-interleaved over the threads" % (
                 os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
         }
@@ -691,9 +713,13 @@ def run_rank(args, rank, world, local_rank):
     if multi and sharded and extras_ok:
         eng.comm_barrier()
         eng.close()
-        if args.scaling == "weak":   # BASELINE.json's metric as written: the 1.23 M scene itself over the N ranks
+        if args.scaling == "weak":   # (the headline was the weak one: BASELINE.json's metric as written rides along)
             out["c2_strong_scaling"] = sharded_extra(args, rank, world, device, lib, P.c2_scene("wcsph"),
                                                      "C2 1,231,200-particle dam break, WCSPH", ".c2s")
+        else:                        # the headline IS the metric as written; one C2 block per rank as an extra
+            out["c2_weak_scaling"] = sharded_extra(args, rank, world, device, lib, P.c2_scene("wcsph", scale_z=world),
+                                                   "C2 1,231,200-particle dam break x%d in z (one block per rank), WCSPH" % world, ".c2w",
+                                                   scaling="weak")
         if not args.no_c4:
             out["c4_strong_scaling"] = sharded_extra(args, rank, world, device, lib, P.c4_scene("wcsph"),
                                                      "C4 4,000,000-particle dam break, WCSPH", ".c4")

@@ -123,6 +123,10 @@ typedef struct {
     int64_t pair_evaluations;    /* the same accepted pairs counted once per neighbour walk the library actually makes
                                     (a fused kernel that does the work of k reference passes adds k to
                                     pair_interactions and 1 here), last step */
+    int64_t hash_launches;       /* launches of the cell-id / histogram kernel (init_grid, base_container.py:496) since create */
+    int64_t prehashed_sorts;     /* sorts since create whose init_grid was done by the force pass of the step before (inside one
+                                    sph_step_async(n) call of an unsharded all-fluid WCSPH scene): hash_launches + prehashed_sorts
+                                    = sorts.  Lets a test assert which path a timed region really took. */
 } SphStats;
 
 /* Kernel ids for the HIP-event profiler (sph_profile_*). */

@@ -314,7 +314,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.lane_perm = nullptr; s.perm_n = -1;
     s.loop_flag = nullptr; s.loop_slot = 0; s.loop_kind = 0; s.loop_denom = 1.0f; s.loop_thr = 0.0;
     CHK_CREATE(dalloc(h, &s.blk_hdr, (cap + 255) / 256 * (20 + 256)));   // headers of all tiles, then one cell word per particle slot (k_block_prep)
-    s.blk_flag = s.blk_list = s.blk_count = nullptr; s.list_n = -1; s.last_pass_listed = 0; s.list_count_pinned = nullptr; s.list_count_event = nullptr; s.list_count_known = -1; s.nexthash = NextHash{0, nullptr, nullptr, nullptr}; s.prehashed = 0;
+    s.blk_flag = s.blk_list = s.blk_count = nullptr; s.list_n = -1; s.last_pass_listed = 0; s.list_count_pinned = nullptr; s.list_count_event = nullptr; s.list_count_known = -1; s.nexthash = NextHash{0, nullptr, nullptr, nullptr}; s.prehashed = 0; s.n_hash_launches = s.n_prehashed_sorts = 0;
     if (!getenv("SPH_NO_BLOCK_LIST")) {
         CHK_CREATE(dalloc(h, &s.blk_flag, (cap + 255) / 256)); CHK_CREATE(dalloc(h, &s.blk_list, (cap + 255) / 256)); CHK_CREATE(dalloc(h, &s.blk_count, 1));
     }
@@ -851,6 +851,8 @@ extern "C" int sph_get_stats(SphHandle *h, SphStats *out) {
     h->last.particle_num = h->n;
     h->last.fluid_particle_num = h->n_fluid;
     h->last.total_time = h->total_time;
+    h->last.hash_launches = h->st.n_hash_launches;
+    h->last.prehashed_sorts = h->st.n_prehashed_sorts;
     *out = h->last;
     return SPH_OK;
 }

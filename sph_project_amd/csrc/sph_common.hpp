@@ -245,6 +245,7 @@ struct State {
     int preclassified;   // ... and has done so: the next step's exchange starts with the hash alone
     NextHash nexthash;   // on != 0: the next wcsph_forces launch hashes the particles for the next step's sort itself
     int prehashed;       // ... and has done so: the next step's sort starts with the scan (l_hash_count returns at once)
+    long long n_hash_launches, n_prehashed_sorts;   // k_hash_count launches / sorts that started from a NextHash hash, since create (SphStats)
     int halo_cap;        // particles per message buffer
     int halo_longest;    // longest halo message of the running step, in particles (sent or received)
     int slab_active, z_lo, z_hi, has_down, has_up;

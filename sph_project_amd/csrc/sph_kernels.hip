@@ -29,11 +29,13 @@ void l_hash_count(State &s) {
     if (s.prehashed) {   // the last step's force pass has hashed for this sort (NextHash): cell ids, histogram and ranks are in place
         s.prehashed = 0;
         s.cell_count_clean = 0;
+        s.n_prehashed_sorts++;
         return;
     }
     if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + SPH_NGRAVE + 1), s.stream);
     s.cell_count_clean = 0;
     if (n == 0) return;
+    s.n_hash_launches++;
     hipLaunchKernelGGL(k_hash_count, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.cellid,
                        s.rank, s.cell_count, s.slab_active ? s.meta.cur() : nullptr);
 }

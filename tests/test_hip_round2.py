@@ -184,13 +184,18 @@ def test_run_simulation_driver_writes_the_reference_frames(gpu, tmp_path):
 
 
 # --------------------------------------------------------------------------------------------- BASELINE configs
-def _full_size_vs_oracle(cfg, steps, fixed, tol, pair_rtol=0.0):
+def _full_size_vs_oracle(cfg, steps, fixed, tol, pair_rtol=0.0, advance=False):
     container, solver = H.build_product(cfg, fast_math=1, **({"fixed_iterations": fixed} if fixed else {}))
     solver.prepare()
     ref = H.build_oracle(cfg, fixed_iterations=fixed)
     ref.prepare()
-    for _ in range(steps):
-        solver.step()
+    if advance:   # ONE sph_step_async(steps), the call bench.py times (WCSPH: the force pass is the next step's init_grid, NextHash)
+        p0 = solver.stats()["prehashed_sorts"]
+        solver.advance(steps)
+        assert solver.stats()["prehashed_sorts"] - p0 == steps - 1, solver.stats()
+    else:
+        for _ in range(steps):
+            solver.step()
     ref.step(steps)
     e = container.engine
     ids = e.download(L.F_PARTICLE_ID)
@@ -219,8 +224,9 @@ def test_c3_full_size_dfsph(gpu):
 
 
 def test_c4_full_size_wcsph_one_gpu(gpu):
-    """BASELINE configs[3]'s scene (4,000,000 particles, WCSPH) on ONE GPU, 5 steps (its 8-GPU sharding is the driver's)."""
-    _full_size_vs_oracle(P.c4_scene(), 5, 0, 1e-4)
+    """BASELINE configs[3]'s scene (4,000,000 particles, WCSPH) on ONE GPU, 5 steps in one advance(5) -- the timed path, with the
+    force pass hashing for the next sort (its 8-GPU sharding: tests/test_hip_slab.py, 8 ranks on one GPU; real devices: the driver's)."""
+    _full_size_vs_oracle(P.c4_scene(), 5, 0, 1e-4, advance=True)
 
 
 def _large_block(side):
@@ -490,14 +496,23 @@ def test_bench_spawns_two_ranks_without_torch(gpu):
 
 
 def test_bench_eight_ranks_share_one_gpu(gpu):
-    """The driver's 8-rank job (weak scaling: 8 x 1,231,200 particles, every rank topology: two edge ranks, six with both neighbours) with all
-    ranks on this box's ONE GPU -- push transport, asynchronous steps, 8-way control plane.  Round 3 found here that workgroups spinning on a
+    """The driver's 8-rank job -- BASELINE.json's metric as written: the 1,231,200-particle scene itself split over the 8 ranks (strong
+    scaling; every rank topology: two edge ranks, six with both neighbours; 5-7 cell layers per rank) -- and the same job with one C2 block
+    per rank (--scaling weak, 8 x 1,231,200 particles), with all ranks on this box's ONE GPU -- push transport, asynchronous steps, 8-way control plane.  Round 3 found here that workgroups spinning on a
     neighbour's message hold their CU slots: with every workgroup of the consuming kernels polling, 8 ranks filled the chip with pollers and
     the kernels that had to produce the awaited messages were never scheduled (all waits timed out); the waiting kernels are capped at 64
     workgroups now.  Oversubscription only -- one rank per GPU cannot starve itself -- but a hang is a hang."""
-    out = _bench(["--gpus", "8", "--steps", "5", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline", "--motion-step", "0", "--no-extras"],
-                 {"SPH_COMM_TRANSPORT": "shm+ipc", "SPH_COMM_TIMEOUT_S": "60"}, timeout=900)
+    common = ["--gpus", "8", "--steps", "5", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline", "--motion-step", "0", "--no-extras"]
+    env = {"SPH_COMM_TRANSPORT": "shm+ipc", "SPH_COMM_TIMEOUT_S": "60"}
+    out = _bench(common, env, timeout=900)
+    assert out["n_gpus"] == 8 and out["config"]["particles"] == 1231200 and out["scaling"] == "strong"
+    assert out["config"]["workload"] == "C2 1,231,200-particle dam break"   # the N = 1 line's workload, byte for byte
+    assert out["config"]["parallelism"].startswith("z-slab x8, ipc-push+shm") and out["value"] > 0
+    # ~26 lattice neighbours (+ some of the 6 at exactly h, decided by rounding; fewer at the block's faces) x 4 reference passes
+    assert 4 * 24 * 1231200 < out["config"]["pair_interactions_per_step"] < 4 * 33 * 1231200
+    out = _bench(common + ["--scaling", "weak"], env, timeout=900)
     assert out["n_gpus"] == 8 and out["config"]["particles"] == 8 * 1231200 and out["scaling"] == "weak"
+    assert out["config"]["workload"] == "C2 1,231,200-particle dam break x8 in z"
     assert out["config"]["parallelism"].startswith("z-slab x8, ipc-push+shm") and out["value"] > 0
 
 
@@ -632,10 +647,12 @@ def test_bench_under_torch_distributed_run(gpu):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-3000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["particles"] == 2 * 1231200 and out["scaling"] == "weak"
-    assert out["config"]["parallelism"].startswith("z-slab x2")
+    # the headline is BASELINE.json's metric as written: the 1.23 M scene itself over the N ranks
+    assert out["n_gpus"] == 2 and out["config"]["particles"] == 1231200 and out["scaling"] == "strong"
+    assert out["config"]["workload"] == "C2 1,231,200-particle dam break" and out["config"]["parallelism"].startswith("z-slab x2")
     c4 = out["c4_strong_scaling"]
     assert c4["particles"] == 4000000 and c4["n_gpus"] == 2 and c4["scaling"] == "strong" and c4["value"] > 0
     assert sum(c4["owned_per_rank"]) == 4000000 and c4["halo_transport"] == "ipc-push+shm"
-    c2s = out["c2_strong_scaling"]   # BASELINE.json's metric as written: the 1.23 M scene itself over the N ranks
-    assert c2s["particles"] == 1231200 and c2s["scaling"] == "strong" and sum(c2s["owned_per_rank"]) == 1231200 and c2s["value"] > 0
+    c2w = out["c2_weak_scaling"]     # one C2 block per rank: an extra, never `value`
+    assert c2w["particles"] == 2 * 1231200 and c2w["scaling"] == "weak" and sum(c2w["owned_per_rank"]) == 2 * 1231200 and c2w["value"] > 0
+    assert "c2_strong_scaling" not in out
