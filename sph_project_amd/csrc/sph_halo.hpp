@@ -47,6 +47,19 @@ __device__ __forceinline__ bool halo_poll(const unsigned *word, unsigned seq, lo
     }
 }
 
+// Test hooks (-DSPH_TEST_HOOKS: libsph_hip_testhooks.so only, never the production library; csrc/Makefile).  halo_test_delay stalls a
+// consumer between its own announce and its poll (workgroup 0) or before its poll (the others, staggered by workgroup): what time
+// slicing of several ranks on one GPU does at random, on demand.  With the pre-round-5 single header (SPH_TEST_SINGLE_HEADER) the stall
+// makes the race of tests/test_halo_protocol_model.py deterministic; with the header per message parity nothing may change.
+__device__ __forceinline__ void halo_test_delay(long long ticks) {
+#ifdef SPH_TEST_HOOKS
+    if (ticks <= 0) return;
+    const long long d = blockIdx.x == 0 ? ticks : ticks * (long long)(1 + (blockIdx.x % 3)) / 4;
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(64);
+#endif
+}
+
 // In place: nothing is compacted or copied.  Particles that are no longer this rank's business (last step's ghosts,
 // migrants beyond the neighbour's boundary layer) get the DEAD bit; the sort that follows files them into the
 // graveyard cell G behind every live particle, and the live count shrinks by counts[2].
@@ -120,6 +133,7 @@ struct HaloStep {
     unsigned seq;
     unsigned hdr_bank_mask;       // 1: header of message m in rec[m & 1] (normal); 0: one header for all messages (SPH_TEST_SINGLE_HEADER: the pre-round-5 protocol, for the A/B that pins the race)
     int stride, cap, halo_cap;
+    long long test_delay_ticks;   // test-hook build only (halo_test_delay), else 0
     int n_old;                    // particle count before the exchange when the host knows it exactly, else -1: last step's n_live
     int bound_app, bound_live;    // launch bounds of an asynchronous step (0: the host launches exact grids afterwards)
     long long timeout_ticks;      // of the 100 MHz wall clock
@@ -146,6 +160,7 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
             __threadfence_system();
             __hip_atomic_store(&hd->seq, w.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        halo_test_delay(w.test_delay_ticks);
         int cnt = 0, st = 0;
         if (lane < 2 && w.in_ctl[lane]) {
             const HaloRecHdr *hd = &w.in_ctl[lane]->rec[w.seq & w.hdr_bank_mask];   // (this message's own header: the next one goes to the other)
@@ -355,6 +370,7 @@ struct HaloFld {
     const HaloCtl *in_ctl[2];
     unsigned seq;
     long long timeout_ticks;
+    long long test_delay_ticks;   // test-hook build only (halo_test_delay), else 0
     volatile SlabDyn *mirror;
     float *f0, *f1, *f2, *f3;   // KIND 0: f0; KIND 2: rho_raw, rho, prs, ptm
     float4 *v;                  // KIND 1
@@ -376,7 +392,7 @@ __global__ void __launch_bounds__(256) k_halo_pack2(HaloFld a) {
 }
 // announce my field message (workgroup 0), then wait for the neighbours' (every workgroup); false after a time-out
 __device__ __forceinline__ bool halo_fld_handshake(HaloCtl *const out_ctl[2], const HaloCtl *const in_ctl[2], unsigned seq,
-                                                   long long timeout_ticks, SlabDyn *dyn, volatile SlabDyn *mirror) {
+                                                   long long timeout_ticks, SlabDyn *dyn, volatile SlabDyn *mirror, long long test_delay_ticks = 0) {
     __shared__ int s_ok;
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
@@ -384,6 +400,7 @@ __device__ __forceinline__ bool halo_fld_handshake(HaloCtl *const out_ctl[2], co
             __threadfence_system();
             __hip_atomic_store(&out_ctl[lane]->fld_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        halo_test_delay(test_delay_ticks);
         int st = 0;
         const long long patience = (dyn->status & SLAB_ST_TIMEOUT) ? 0 : timeout_ticks;   // fail fast once the exchange is dead
         if (lane < 2 && in_ctl[lane] && !halo_poll(&in_ctl[lane]->fld_seq, seq, patience)) st = SLAB_ST_TIMEOUT;
@@ -400,7 +417,7 @@ __device__ __forceinline__ bool halo_fld_handshake(HaloCtl *const out_ctl[2], co
 // message from `side`: [ its records = my n_recv (ghost table) | my n_send records (echo-ghost table) ]
 template <int KIND>
 __global__ void __launch_bounds__(256) k_halo_unpack2f(HaloFld a) {
-    if (!halo_fld_handshake(a.out_ctl, a.in_ctl, a.seq, a.timeout_ticks, a.dyn, a.mirror)) return;   // stale payload is not scattered
+    if (!halo_fld_handshake(a.out_ctl, a.in_ctl, a.seq, a.timeout_ticks, a.dyn, a.mirror, a.test_delay_ticks)) return;   // stale payload is not scattered
     const int ns0 = a.dyn->n_send[0], nr0 = a.dyn->n_recv[0], ns1 = a.dyn->n_send[1], nr1 = a.dyn->n_recv[1];
     const int t0 = a.in[0] ? ns0 + nr0 : 0, t1 = a.in[1] ? ns1 + nr1 : 0;
     const int stride = (int)(gridDim.x * 256);

@@ -48,6 +48,25 @@ static void l_halo_presend_begin(State &s) {
     hs.pid = s.pid.cur(); hs.color = s.color.cur(); hs.orig = s.orig.cur();
 }
 
+// Test hooks: compiled into libsph_hip_testhooks.so only (-DSPH_TEST_HOOKS, csrc/Makefile).  The production library has neither the
+// pre-round-5 single step-message header (a protocol with a known race: tests/test_halo_protocol_model.py) nor the consumer delay.
+static unsigned halo_hdr_bank_mask() {
+#ifdef SPH_TEST_HOOKS
+    static const unsigned m = getenv("SPH_TEST_SINGLE_HEADER") ? 0u : 1u;
+    return m;
+#else
+    return 1u;
+#endif
+}
+static long long halo_test_delay_ticks() {   // SPH_TEST_HALO_DELAY_US -> ticks of the 100 MHz wall clock
+#ifdef SPH_TEST_HOOKS
+    static const long long t = getenv("SPH_TEST_HALO_DELAY_US") ? 100ll * atoll(getenv("SPH_TEST_HALO_DELAY_US")) : 0ll;
+    return t;
+#else
+    return 0;
+#endif
+}
+
 static int halo_grid(int count_hint) {   // grid-stride kernels: enough workgroups for the hint, at least one, never a huge launch
     int g = cdiv(count_hint > 0 ? count_hint : 1, 256);
     return g > 2048 ? 2048 : g;
@@ -71,8 +90,8 @@ static void l_halo_unpack2(State &s, int n_old, int bound_app, int bound_live, i
         w.in_ctl[side] = s.push.peer[side] ? inbox_ctl(s.push.inbox, side) : nullptr;
         w.recv[side] = (const float4 *)inbox_rec(s, s.push.inbox, side, seq);
     }
-    static const unsigned bank_mask = getenv("SPH_TEST_SINGLE_HEADER") ? 0u : 1u;
-    w.hdr_bank_mask = bank_mask;
+    w.hdr_bank_mask = halo_hdr_bank_mask();
+    w.test_delay_ticks = halo_test_delay_ticks();
     w.seq = seq; w.stride = s.orig.cur() ? 4 : 3; w.cap = s.cap; w.halo_cap = s.push.rec_cap;
     w.n_old = n_old; w.bound_app = bound_app; w.bound_live = bound_live; w.timeout_ticks = s.push.timeout_ticks;
     w.counts = s.halo_counts + HC_BANK * (seq & 1u); w.counts_next = s.halo_counts + HC_BANK * ((seq + 1) & 1u);
@@ -95,6 +114,7 @@ static HaloFld halo_fld_args(State &s, unsigned seq, float *f0, float4 *v) {
         a.in_ctl[side] = s.push.peer[side] ? inbox_ctl(s.push.inbox, side) : nullptr;
     }
     a.seq = seq; a.timeout_ticks = s.push.timeout_ticks; a.mirror = (volatile SlabDyn *)s.push.mirror;
+    a.test_delay_ticks = halo_test_delay_ticks();
     a.f0 = f0; a.f1 = s.rho.cur(); a.f2 = s.prs; a.f3 = s.ptm; a.v = v;
     return a;
 }

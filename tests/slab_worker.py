@@ -9,6 +9,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+# test-hook library only (SPH_HIP_LIB=libsph_hip_testhooks.so): the consumer stall is applied on ONE rank, so that its neighbour runs ahead
+if os.environ.get("SPH_WORKER_DELAY_RANK") not in (None, "", "all", sys.argv[1]):
+    os.environ.pop("SPH_TEST_HALO_DELAY_US", None)
+
 from sph_project_amd import _lib as L  # noqa: E402
 from sph_project_amd import scene, slab  # noqa: E402
 from sph_project_amd.SPH.utils import SimConfig  # noqa: E402

@@ -56,6 +56,16 @@ int main(void) {
     assert [int(x) for x in out] == got
 
 
+def test_test_hooks_live_in_their_own_library():
+    """the pre-round-5 single halo header (a protocol with a known race) and the consumer stall are compiled into
+    libsph_hip_testhooks.so only (-DSPH_TEST_HOOKS); the production library does not even contain the switches' names."""
+    here = os.path.join(ROOT, "sph_project_amd")
+    prod = open(os.path.join(here, "libsph_hip.so"), "rb").read()
+    hooks = open(os.path.join(here, "libsph_hip_testhooks.so"), "rb").read()
+    for name in (b"SPH_TEST_SINGLE_HEADER", b"SPH_TEST_HALO_DELAY_US"):
+        assert name not in prod and name in hooks
+
+
 @pytest.mark.skipif(_has_gpu(), reason="only meaningful on a machine without a GPU")
 def test_no_cpu_fallback():
     with pytest.raises(L.SphError, match="no HIP device"):
