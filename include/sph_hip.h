@@ -93,6 +93,13 @@ typedef enum {
     SPH_F_CG_X = 21,             /* f32[n][3] base_solver.py:46 */
     SPH_F_ORIG_POSITION = 22,    /* f32[n][3] rigid_particle_original_positions */
     SPH_F_GHOST = 23,            /* i32[n]    1 for ghost copies of a neighbour slab's particles (multi-GPU), else 0 */
+    /* solver scratch the per-term checks of tests/test_hip_solvers.py need (not fields of the reference: DFSPH.py:133 / :218 recompute
+       kappa from density_star / density_derivative + alpha right before every correction; this library computes it in the pass that
+       produces them and hands it to the next correction): */
+    SPH_F_DFSPH_KAPPA_NEXT = 24,   /* f32[n] (rho*_i - 1) alpha_i / dt of the LAST density_star pass (pairs with SPH_F_DENSITY_STAR) */
+    SPH_F_DFSPH_KAPPA_V_NEXT = 25, /* f32[n] D rho_i / Dt * alpha_i of the LAST density_derivative pass (pairs with SPH_F_DENSITY_DERIV) */
+    SPH_F_DEBUG_CAPTURE = 26,      /* f32[n] libsph_hip_testhooks.so only: PCISPH pressure BEFORE the last executed update_pressure
+                                      (PCISPH.py:66-73); the production library leaves the density pass's scratch there */
     SPH_F_COUNT_
 } SphField;
 

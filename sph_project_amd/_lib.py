@@ -21,7 +21,7 @@ METHOD = {"wcsph": 0, "dfsph": 1, "pcisph": 2}
 (F_POSITION, F_VELOCITY, F_ACCELERATION, F_DENSITY, F_PRESSURE, F_REST_VOLUME, F_MASS, F_MATERIAL,
  F_OBJECT_ID, F_IS_DYNAMIC, F_COLOR, F_PARTICLE_ID, F_GRID_ID, F_DFSPH_ALPHA, F_DFSPH_KAPPA,
  F_DFSPH_KAPPA_V, F_DENSITY_STAR, F_DENSITY_DERIV, F_PRESSURE_ACCEL, F_PREDICTED_VEL, F_PREDICTED_POS,
- F_CG_X, F_ORIG_POSITION, F_GHOST) = range(24)
+ F_CG_X, F_ORIG_POSITION, F_GHOST, F_DFSPH_KAPPA_NEXT, F_DFSPH_KAPPA_V_NEXT, F_DEBUG_CAPTURE) = range(27)
 
 _FIELD_SPEC = {  # field -> (dtype, components)
     F_POSITION: (np.float32, 3), F_VELOCITY: (np.float32, 3), F_ACCELERATION: (np.float32, 3),
@@ -32,6 +32,7 @@ _FIELD_SPEC = {  # field -> (dtype, components)
     F_DFSPH_KAPPA_V: (np.float32, 1), F_DENSITY_STAR: (np.float32, 1), F_DENSITY_DERIV: (np.float32, 1),
     F_PRESSURE_ACCEL: (np.float32, 3), F_PREDICTED_VEL: (np.float32, 3), F_PREDICTED_POS: (np.float32, 3),
     F_CG_X: (np.float32, 3), F_ORIG_POSITION: (np.float32, 3), F_GHOST: (np.int32, 1),
+    F_DFSPH_KAPPA_NEXT: (np.float32, 1), F_DFSPH_KAPPA_V_NEXT: (np.float32, 1), F_DEBUG_CAPTURE: (np.float32, 1),
 }
 
 # enum SphPhase

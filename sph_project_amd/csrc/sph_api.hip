@@ -881,6 +881,9 @@ static const float *scalar_field(SphHandle *h, int field) {
         case SPH_F_DFSPH_KAPPA_V: return s.kappa_v;
         case SPH_F_DENSITY_STAR: return s.rho_star;
         case SPH_F_DENSITY_DERIV: return s.rho_deriv;
+        case SPH_F_DFSPH_KAPPA_NEXT: return s.kappa_next;
+        case SPH_F_DFSPH_KAPPA_V_NEXT: return s.kappa_v_next;
+        case SPH_F_DEBUG_CAPTURE: return s.rho_raw;   // (test-hook build: PcisphRhoStarPass::cap_prev points here)
         default: return nullptr;
     }
 }

@@ -310,6 +310,9 @@ struct PcisphRhoStarPass {
     struct Own { float px, py, pz, sum; };
     const float4 *posv, *ppos; const int *meta; const float *rho;
     float *rho_star, *prs, *ptm; float *red_out;
+#ifdef SPH_TEST_HOOKS
+    float *cap_prev;   // test-hook library: the pressure this update started from (SPH_F_DEBUG_CAPTURE); a launch past the stop of a device loop writes nothing
+#endif
 
     __device__ float4 loadA(int j) const { return posv[j]; }
     __device__ float4 stage(const Consts &, int j, BT &bj) const {
@@ -334,6 +337,9 @@ struct PcisphRhoStarPass {
     __device__ float finish(const Consts &c, int i, const float4 &, Own &o) const {
         const float star = o.sum * c.rho0;
         rho_star[i] = star;
+#ifdef SPH_TEST_HOOKS
+        if (cap_prev) cap_prev[i] = prs[i];
+#endif
         float p = prs[i] + c.pcisph_k * (c.rho0 - star);
         if (p < 0.0f) p = 0.0f;
         prs[i] = p;

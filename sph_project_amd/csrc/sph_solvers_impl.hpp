@@ -104,10 +104,18 @@ static void l_pcisph_init(State &s) {
 
 static void l_pcisph_rho_star(State &s) {
     if (s.c.all_fluid) {
-        PcisphRhoStarPass<true> p{s.posv.cur(), s.ppos, s.meta.cur(), s.rho.cur(), s.rho_star, s.prs, s.ptm, s.red_partial};
+        PcisphRhoStarPass<true> p{s.posv.cur(), s.ppos, s.meta.cur(), s.rho.cur(), s.rho_star, s.prs, s.ptm, s.red_partial
+#ifdef SPH_TEST_HOOKS
+                                  , s.rho_raw   // (PCISPH reads rho_raw nowhere after the density pass)
+#endif
+        };
         launch_pass(s, p, 2);
     } else {
-        PcisphRhoStarPass<false> p{s.posv.cur(), s.ppos, s.meta.cur(), s.rho.cur(), s.rho_star, s.prs, s.ptm, s.red_partial};
+        PcisphRhoStarPass<false> p{s.posv.cur(), s.ppos, s.meta.cur(), s.rho.cur(), s.rho_star, s.prs, s.ptm, s.red_partial
+#ifdef SPH_TEST_HOOKS
+                                   , s.rho_raw
+#endif
+        };
         launch_pass(s, p, 2);
     }
     // the partial sums are finished by l_pcisph_pressure_accel: the criterion (PCISPH.py:122) is tested after the whole

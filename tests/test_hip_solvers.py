@@ -69,3 +69,56 @@ def test_fixed_iterations_async(gpu, method):
     s2.prepare()
     with pytest.raises(L.SphError):
         c2.engine.step_async(1)  # data-dependent stopping needs the synchronous entry point
+
+
+@pytest.mark.parametrize("fast_math", [0, 1])
+def test_dfsph_kappa_per_term(gpu, fast_math):
+    """kappa and kappa_v from the product's OWN inputs (the fitted 1e-3 guards of tests/test_hip_golden.py pinned neither).
+    DFSPH.py:218-222: kappa_i = (rho*_i - 1) alpha_i / dt; DFSPH.py:133-137: kappa_v_i = (D rho_i / Dt) alpha_i.  The library computes
+    both in the pass that produces rho* / D rho / Dt and hands them to the next correction (kappa_next / kappa_v_next): right after a
+    density solve (sph_step_begin) the LAST pass's rho*, the alpha it used and its kappa are all still in place; after the step's
+    divergence solve the same holds for D rho / Dt.  Inputs are pinned elsewhere (rho*, alpha: parity limits against the fixtures;
+    D rho / Dt: float64 per-term check), the formulas here -- to the rounding of two f32 multiplications."""
+    cfg = H.dam_break_scene(method="dfsph", end=(0.3, 0.3, 0.3), dt=6e-4, velocity=(0.0, -0.5, 0.0), particleSpacing=0.0185)
+    container, solver = H.build_product(cfg, jitter=0.002, seed=5, fast_math=fast_math)
+    solver.prepare()
+    e = container.engine
+    dt = np.float32(cfg["Configuration"]["timeStepSize"])
+    seen_compressed = 0
+    for step in range(10):
+        e.step_begin()                      # DFSPH.py:299-303: non-pressure forces, density solve, advection
+        fl = e.download(L.F_MATERIAL) == 1
+        star, alpha, kn = (e.download(f)[fl] for f in (L.F_DENSITY_STAR, L.F_DFSPH_ALPHA, L.F_DFSPH_KAPPA_NEXT))
+        assert star.min() >= 1.0            # :113 max(rho*, 1)
+        want = (star.astype(np.float64) - 1.0) * alpha.astype(np.float64) / float(dt)
+        err = np.abs(kn.astype(np.float64) - want)
+        # rho* - 1 is exact (Sterbenz); two multiplications and the rounding of 1 / dt: 3 u = 1.8e-7 of the value itself
+        assert (err <= 3e-7 * np.abs(want) + 1e-30).all(), (step, float((err / (np.abs(want) + 1e-30)).max()))
+        assert ((star > 1.0) == (kn != 0.0)).all()
+        seen_compressed += int((star > 1.0).sum())
+        e.step_end()                        # :316-319: sort, density + alpha, divergence solve
+        fl = e.download(L.F_MATERIAL) == 1
+        adv, alpha, kvn = (e.download(f)[fl] for f in (L.F_DENSITY_DERIV, L.F_DFSPH_ALPHA, L.F_DFSPH_KAPPA_V_NEXT))
+        np.testing.assert_array_equal(kvn, adv * alpha)     # ONE f32 multiplication: bit for bit
+        assert (adv >= 0).all()
+    assert seen_compressed > 1000, seen_compressed
+
+
+def test_pcisph_pressure_update_per_term(gpu):
+    """PCISPH.py:66-73 p += k (rho0 - rho*), clamped at 0, from the product's own inputs: the test-hook library keeps the pressure the
+    LAST executed update started from (a launch past the stop of the device loop writes nothing), rho* is in place, k is the oracle's:
+    bit for bit in the strict build.  Retires the fitted 2e-3 'pressures' guard for PCISPH in tests/test_hip_golden.py to a regression
+    guard on a quantity whose formula and inputs are both pinned."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hooks = os.path.join(root, "sph_project_amd", "libsph_hip_testhooks.so")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "pcisph_capture_probe.py")], env=dict(os.environ, SPH_HIP_LIB=hooks),
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("[")][-1])
+    print(out)
+    assert len(out) == 8 and all(o["mismatch"] == 0 for o in out), out
+    assert max(o["pressurised"] for o in out) > 1000 and max(o["iterations"] for o in out) >= 2, out
