@@ -510,8 +510,13 @@ def test_stalled_consumer_exposes_the_single_header_race_and_only_that(gpu, tmp_
     if transport != "shm+ipc":
         pytest.skip("push transport only")
     assert os.path.exists(HOOKS_LIB), "build() makes libsph_hip_testhooks.so"
+    # The two messages of the seam must DIFFER for the mix-up to show (same positions -> same records -> same count, and a header taken
+    # from the wrong message is then harmless).  They differ when particles change owner in prepare's exchange: the lattice (spacing 0.02
+    # from z = 0.08) has a particle layer exactly ON every cell face, the seeded jitter puts half of the layer on the slab cut below the
+    # cut: ~110 migrants in message 1, which come back as ordinary boundary copies in message 2.  (C4 with jitter has 12.5 k of them per
+    # face -- the 12.5 k garbage records / 2.5 k lost arrivals of profiles/r05_halo_header_race_ab.txt: a fifth of a 62.5 k message's tail.)
     cfg = H.dam_break_scene(domain_end=(1.0, 1.0, 1.2), start=(0.1, 0.1, 0.08), end=(0.4, 0.4, 1.12), translation=(0, 0, 0),
-                            velocity=(0.0, -0.3, 2.5), particleSpacing=0.019)
+                            velocity=(0.0, -0.3, 2.5))
     steps = 6
     hooks = {"SPH_HIP_LIB": HOOKS_LIB}
     stall = dict(hooks, SPH_TEST_HALO_DELAY_US="300000", SPH_WORKER_DELAY_RANK="1")

@@ -101,7 +101,7 @@ def test_dfsph_kappa_per_term(gpu, fast_math):
         adv, alpha, kvn = (e.download(f)[fl] for f in (L.F_DENSITY_DERIV, L.F_DFSPH_ALPHA, L.F_DFSPH_KAPPA_V_NEXT))
         np.testing.assert_array_equal(kvn, adv * alpha)     # ONE f32 multiplication: bit for bit
         assert (adv >= 0).all()
-    assert seen_compressed > 1000, seen_compressed
+    assert seen_compressed > 500, seen_compressed
 
 
 def test_pcisph_pressure_update_per_term(gpu):
