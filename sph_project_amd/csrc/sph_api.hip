@@ -41,6 +41,7 @@ struct SphHandle {
     bool any_rigid_object = false;   // a non-fluid object was registered (slab sharding: its particles may live on another rank)
     int64_t steps = 0;
     int steps_to_follow = 0;       // sph_step_async(n): steps of this call still to come after the running one
+    bool whole_step = false;       // both halves of the running step are ONE call (step_once): nothing on the host happens between them
     double total_time = 0.0;
     bool prepared = false;
     bool pose_dirty = false;
@@ -304,7 +305,12 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     CHK_CREATE(dalloc(h, &s.cellid, cap)); CHK_CREATE(dalloc(h, &s.rank, cap)); CHK_CREATE(dalloc(h, &s.tmp_idx, 2 * cap));   // (int2 run records of the stable sort)
     s.scan_blocks = (int)((G + SPH_NGRAVE + 2047) / 2048);
     if (s.scan_blocks < SPH_STAT_SLOTS / 256) s.scan_blocks = SPH_STAT_SLOTS / 256;   // k_scan_final also clears the statistics slots
-    CHK_CREATE(dalloc(h, &s.scan_partial, (size_t)s.scan_blocks + 1));
+    CHK_CREATE(dalloc(h, &s.scan_partial, 2 * ((size_t)s.scan_blocks + 1) * 8));   // two banks of tile sums, SCAN_PARTIAL_STRIDE ints apart (State::scan_bank)
+    s.scan_bank = 0; s.tile_sums_ready = 0; s.skip_residual = 0;
+    // split launches (SplitPass): 27 floats per particle (3 groups x up to 9 accumulators) for launches of up to 1 M particles -- the
+    // launches that do not fill the chip are far smaller
+    s.split_cap = (int)std::min<size_t>(cap, (size_t)1 << 20);
+    CHK_CREATE(dalloc(h, &s.split_part, (size_t)27 * s.split_cap));
     s.cell_count_clean = 1;
     CHK_CREATE(dalloc(h, &s.rho_raw, cap)); CHK_CREATE(dalloc(h, &s.prs, cap)); CHK_CREATE(dalloc(h, &s.ptm, cap));
     CHK_CREATE(dalloc(h, &s.acc, cap));
@@ -753,8 +759,14 @@ static int step_second_half(SphHandle *h, bool allow_readback) {
 }
 
 static int step_once(SphHandle *h, bool allow_readback) {
-    int rc = step_first_half(h, allow_readback); if (rc) return rc;
-    return step_second_half(h, allow_readback);
+    h->whole_step = true;
+    int rc = step_first_half(h, allow_readback);
+    h->whole_step = false;
+    if (!rc) rc = step_second_half(h, allow_readback);
+    // a failed step may leave a hash made for a sort that will not come (NextHash: the WCSPH force pass for the next step's sort, the
+    // DFSPH position update for this step's): the next sort, whoever asks for it, must hash for itself on a clean histogram
+    if (rc && h->st.prehashed) { h->st.prehashed = 0; h->st.cell_count_clean = 0; }
+    return rc;
 }
 
 extern "C" int sph_step_begin(SphHandle *h) {
@@ -788,12 +800,7 @@ extern "C" int sph_step_async(SphHandle *h, int nsteps) {
         h->steps_to_follow = nsteps - 1 - k;   // (a sharded WCSPH step may start the next step's halo message behind its own force pass)
         int rc = step_once(h, false);
         h->steps_to_follow = 0;
-        if (rc) {
-            // a failed step may leave a hash its force pass made for a successor that will not come (NextHash): the next sort, whoever
-            // asks for it, must hash for itself on a clean histogram
-            if (h->st.prehashed) { h->st.prehashed = 0; h->st.cell_count_clean = 0; }
-            return rc;
-        }
+        if (rc) return rc;   // (step_once drops a hash made for a sort that will not come)
     }
     return check_async(h);
 }

@@ -225,7 +225,10 @@ struct CgApPass {
         if (fuse) { const float4 r = cg_r[j]; q.x = r.x + beta * q.x; q.y = r.y + beta * q.y; q.z = r.z + beta * q.z; }
         const float m = velm[j].w;
         const bool fl = AF || META_MAT(meta[j]) == 1;
-        bj = make_float4(q.x, q.y, q.z, fl ? rho[j] : -1.0f);
+        // a rigid particle or a ghost of one carries no solver vectors (CgPreparePass runs over the fluid tiles only and its passive() is
+        // empty, round 5): whatever cg_p / cg_r hold at its slot -- stale values of an earlier occupant -- must never reach the arithmetic.
+        // pair() drops such a neighbour by bj.w < 0; its search direction is staged as zero so that nothing depends on that alone.
+        bj = fl ? make_float4(q.x, q.y, q.z, rho[j]) : make_float4(0.f, 0.f, 0.f, -1.0f);
         return make_float4(p.x, p.y, p.z, m);
     }
     __device__ float4 loadA(int j) const { BT b; return stage_impl(j, b); }

@@ -148,7 +148,7 @@ struct HaloSend {
 // What the WCSPH force pass needs to be the NEXT step's k_hash_count as well (round 5): it knows every particle's new position when it
 // stores it, so it files the new cell id, takes the histogram atomic (one per run of equal cells among the tile's particles in sorted
 // order, like k_hash_count) and leaves the arrival rank.  on = 0: the next step hashes as usual.
-struct NextHash { int on; int *cellid, *rank, *cell_count; };
+struct NextHash { int on; int *cellid, *rank, *cell_count, *tile_sum; };
 
 // ... and what the WCSPH density pass needs to store (rho_raw, rho, p, p / rho^2) of its boundary particles straight into the field
 // message of the neighbours' inboxes (the message k_halo_pack2<2> would gather afterwards): out[side] = that message's region, xidx = the
@@ -178,8 +178,17 @@ struct State {
     int *cell_start;     // G+1 (exclusive scan, cell_start[G] = n)
     int *cellid, *rank;  // per particle (pre-sort)
     int *tmp_idx;        // stable-sort scratch: int2 (first source index, length) per run, filed at the run's first slot (2 x cap ints)
-    int *scan_partial;   // block sums
+    // Sums of the histogram over the scan's tiles of SCAN_TILE cells, two banks of scan_blocks + 1 ints.  Round 6: whoever takes the
+    // histogram atomics (k_hash_count, the NextHash epilogue of the force pass, the slab kernels) adds its particles to the tile sums of
+    // bank `scan_bank` as well -- one more atomic per WAVE, its lanes' cells lie in one tile nearly always -- so the scan is ONE launch:
+    // k_scan_final reads that bank and clears the other one for the next histogram (like cell_count, which it clears behind itself).
+    int *scan_partial;
     int scan_blocks;
+    int scan_bank;       // bank the hashers of the coming sort add to / the coming scan reads
+    float *split_part;   // [3 * NACC][split_cap]: per-group shares of the accumulators of a split launch (SplitPass, sph_passes.hpp)
+    int split_cap;       // particles the array holds (a launch over more is never split)
+    int skip_residual;   // fixed-iteration solves (no stop test, nobody reads the residual): the walks leave their partial sums, k_reduce_partials is not launched
+    int tile_sums_ready; // ... and they did (else l_scan launches k_scan_reduce first: SPH_NO_SCAN_FOLD)
     int cell_count_clean;              // cell_count is all zero (the scan clears it behind itself)
     // per-step scratch
     float *rho_raw, *prs, *ptm;

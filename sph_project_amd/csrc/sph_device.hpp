@@ -218,12 +218,32 @@ __device__ __forceinline__ void wave_runs(int key, int lane, bool &head, int &hl
     len = above ? __ffsll(above) : 64 - lane;
 }
 
+// Tile sums of the scan (State::scan_partial): every valid lane's particle counts once into the tile of SCAN_TILE cells its cell lies
+// in.  One atomic per wave and DISTINCT tile among its lanes (one at rest: the lanes are consecutive particles of last step's sorted
+// order; a handful where the fluid moves: a step in x is 5 tiles away), and the counters sit SCAN_PARTIAL_STRIDE ints apart: atomics on
+// one 128-byte line are served one at a time (lesson 1 of round 4) -- the first version of this fold (one atomic per run, counters packed
+// 32 to a line) cost the force pass 88 us in motion (profiles/r06_scanfold_ab.txt).
+#define SCAN_TILE_SHIFT 11
+#define SCAN_PARTIAL_STRIDE 8
+__device__ __forceinline__ void tile_sum_add(int *tile_sum, int lin, bool valid) {
+    const int lane = threadIdx.x & 63;
+    const int t = lin >> SCAN_TILE_SHIFT;
+    unsigned long long rem = __ballot(valid);
+    while (rem) {   // wave-uniform
+        const int src = __ffsll((long long)rem) - 1;
+        const int t0 = __shfl(t, src, 64);
+        const unsigned long long same = __ballot(valid && t == t0);
+        if (lane == src) atomicAdd(&tile_sum[t0 * SCAN_PARTIAL_STRIDE], __popcll(same));
+        rem &= ~same;
+    }
+}
+
 // ------------------------------------------------------------------ grid build
 // base_container.py:496 init_grid: cell id + histogram.  The atomic's return value is the
 // particle's arrival rank inside its cell, which replaces the second atomic pass of :515.
 __global__ void __launch_bounds__(256)
 k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ cellid,
-             int *__restrict__ rank, int *__restrict__ cell_count, const int *__restrict__ meta_dead) {
+             int *__restrict__ rank, int *__restrict__ cell_count, const int *__restrict__ meta_dead, int *__restrict__ tile_sum) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = i < live_n(c);
@@ -245,6 +265,7 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
     if (head && valid) base = atomicAdd(&cell_count[lin], len);
     base = __shfl(base, hl, 64);
     if (valid) rank[i] = base + (lane - hl);
+    if (tile_sum) tile_sum_add(tile_sum, lin, valid);
 }
 
 // base_container.py:546 PrefixSumExecutor.run -- here an exclusive scan into cell_start[0..G],
@@ -252,6 +273,7 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
 #define SCAN_TPB 256
 #define SCAN_IPT 8
 #define SCAN_TILE (SCAN_TPB * SCAN_IPT)
+static_assert(SCAN_TILE == 1 << SCAN_TILE_SHIFT, "tile_sum_add and the scan kernels must agree on the tile");
 
 __device__ __forceinline__ int block_excl_scan_256(int v, int *s_w, int &total) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -291,15 +313,16 @@ k_scan_reduce(const int *__restrict__ in, int n, int *__restrict__ partial) {
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (threadIdx.x == 0) partial[blockIdx.x * SCAN_PARTIAL_STRIDE] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
 __global__ void __launch_bounds__(SCAN_TPB)
 k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *__restrict__ out,
-             int total_particles, DevScalars *__restrict__ scal, int clear_bank, const int *__restrict__ total_dev) {
+             int total_particles, DevScalars *__restrict__ scal, int clear_bank, const int *__restrict__ total_dev, int *__restrict__ partial_next) {
     // side jobs of the kernel that runs every step: clears cell_count behind itself (the next histogram starts from
     // zero without a memset) and clears the statistics bank of the next step
     __shared__ int s_w[SCAN_TPB / 64];
+    if (partial_next && threadIdx.x == 0) partial_next[blockIdx.x * SCAN_PARTIAL_STRIDE] = 0;   // the OTHER bank of tile sums: nobody reads it in this launch; the next histogram adds to it
     if (blockIdx.x * SCAN_TPB + threadIdx.x < SPH_STAT_SLOTS) {   // first SPH_STAT_SLOTS / SCAN_TPB workgroups (the grid is never smaller)
         scal->pairs[clear_bank][blockIdx.x * SCAN_TPB + threadIdx.x] = 0ull;
         scal->evals[clear_bank][blockIdx.x * SCAN_TPB + threadIdx.x] = 0ull;
@@ -310,7 +333,7 @@ k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *
     // offset of this tile = sum of the tile sums before it (every workgroup adds them up itself: a few thousand ints
     // out of L2 instead of a third launch)
     int before = 0;
-    for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_TPB) before += partial[k];
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_TPB) before += partial[k * SCAN_PARTIAL_STRIDE];
     int tot0, tot1, btot;
     block_excl_scan_256(before, s_w, btot);
     const int sa = (a.x + a.y) + (a.z + a.w), sb = (b.x + b.y) + (b.z + b.w);
@@ -1042,7 +1065,13 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
         if constexpr (P::HAS_REDUCE) {
             if (tid == 0) {
                 const int bs = red_slot(blk_list, b);
-                if constexpr (PassSplit<P>::value) { if (gridDim.y > 1) { if (float *o = p.split_out(split_lo((int)gridDim.y, (int)blockIdx.y))) o[bs] = 0.0f; } else p.red_out[bs] = 0.0f; }
+                if constexpr (PassSplit<P>::value) {
+                    if (gridDim.y > 1) {
+                        if (float *o = p.split_out(split_lo((int)gridDim.y, (int)blockIdx.y))) o[bs] = 0.0f;
+                        // two-way split: nobody walks "part 1", but the consumers add up three parts (the normal path zeroes it, this one did not)
+                        if (gridDim.y == 2 && blockIdx.y == 0) { if (float *o = p.split_out(1)) o[bs] = 0.0f; }
+                    } else p.red_out[bs] = 0.0f;
+                }
                 else p.red_out[bs] = 0.0f;
             }
         }
@@ -1445,6 +1474,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             if (head && v2) base = atomicAdd(&p.nh.cell_count[lin], len);
             base = __shfl(base, hl, 64);
             if (v2) { p.nh.cellid[i0 + tid] = lin; p.nh.rank[i0 + tid] = base + (lane - hl); }
+            if (p.nh.tile_sum) tile_sum_add(p.nh.tile_sum, lin, v2);
         }
     }
     if (split_launch && !red_to) return;   // uniform; the combining kernel reduces

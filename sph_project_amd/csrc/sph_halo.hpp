@@ -68,7 +68,7 @@ __device__ __forceinline__ void halo_test_delay(long long ticks) {
 // hash != null (push transport): the kernel is also this step's k_hash_count for the particles that are here already (cell id,
 // histogram, arrival rank; the dead ones into the graveyard cell G) -- both read the same positions, and the arrivals are hashed
 // by k_halo_unpack2 when they land.
-struct HaloHash { int *cellid, *rank, *cell_count; };
+struct HaloHash { int *cellid, *rank, *cell_count, *tile_sum; };
 __global__ void __launch_bounds__(256)
 k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z_lo, int z_hi, int has_down, int has_up, HaloArrays a,
                 float4 *send_down, float4 *send_up, int cap, int *counts, HaloHash hash) {
@@ -107,6 +107,7 @@ k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z
         if (head && i < n) base = atomicAdd(&hash.cell_count[lin], len);
         base = __shfl(base, hl, 64);
         if (i < n) hash.rank[i] = base + (lane - hl);
+        if (hash.tile_sum) tile_sum_add(hash.tile_sum, lin, i < n);
     }
     if (i >= n) return;
     if (side >= 0) {
@@ -245,6 +246,7 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
             const int lin = (cell_coord_x(c, p.x) * c.ny + cell_coord(p.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, p.z);
             hash.cellid[d] = lin;
             hash.rank[d] = atomicAdd(&hash.cell_count[lin], 1);
+            if (hash.tile_sum) atomicAdd(&hash.tile_sum[(lin >> SCAN_TILE_SHIFT) * SCAN_PARTIAL_STRIDE], 1);   // (arrivals: a few thousand per step, spread over the ghost layers' tiles)
         }
     }
     const int longest = s_v[3];

@@ -13,12 +13,13 @@ static void l_halo_classify_pack(State &s, int n) {
     float4 *dst[2] = {s.sendbuf[0], s.sendbuf[1]};
     int *counts = s.halo_counts;
     const int *n_dev = nullptr;
-    HaloHash hash{nullptr, nullptr, nullptr};
+    HaloHash hash{nullptr, nullptr, nullptr, nullptr};
     if (s.push.on) {
         // this kernel and k_halo_unpack2 are the step's k_hash_count as well (ph_sort_hashed follows instead of ph_neighbor_search)
-        if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + SPH_NGRAVE + 1), s.stream);
+        if (!s.cell_count_clean) clear_histogram(s);
         s.cell_count_clean = 0;
-        hash = HaloHash{s.cellid, s.rank, s.cell_count};
+        hash = HaloHash{s.cellid, s.rank, s.cell_count, tile_sum_bank(s)};
+        s.tile_sums_ready = hash.tile_sum != nullptr;   // (k_halo_unpack2 adds the arrivals' share)
         const unsigned seq = ++s.push.rec_seq;
         for (int side = 0; side < 2; ++side)
             if (s.push.peer[side]) dst[side] = (float4 *)inbox_rec(s, s.push.peer[side], 1 - side, seq);   // I am the neighbour's OTHER side
@@ -99,7 +100,7 @@ static void l_halo_unpack2(State &s, int n_old, int bound_app, int bound_live, i
     w.mirror = (volatile SlabDyn *)s.push.mirror;
     s.dyn_cur = s.dyn + (seq & 1u);
     hipLaunchKernelGGL(k_halo_unpack2, dim3(halo_grid_wait(count_hint)), dim3(256), 0, s.stream, s.c, w, s.z_lo, s.z_hi, s.posv.cur(), s.velm.cur(),
-                       s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(), s.xidx[s.xcur], s.orig.cur(), t, HaloHash{s.cellid, s.rank, s.cell_count});
+                       s.meta.cur(), s.pid.cur(), s.color.cur(), s.rho.cur(), s.xidx[s.xcur], s.orig.cur(), t, HaloHash{s.cellid, s.rank, s.cell_count, tile_sum_bank(s)});
 }
 
 static HaloFld halo_fld_args(State &s, unsigned seq, float *f0, float4 *v) {

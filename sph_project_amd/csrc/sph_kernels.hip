@@ -24,30 +24,48 @@ namespace SPH_NS {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// tile sums of the coming scan (State::scan_partial): the bank the hashers add to, or null (SPH_NO_SCAN_FOLD: k_scan_reduce computes them)
+static int *tile_sum_bank(State &s) {
+    static const bool off = getenv("SPH_NO_SCAN_FOLD") != nullptr;
+    return off ? nullptr : s.scan_partial + (size_t)s.scan_bank * (s.scan_blocks + 1) * SCAN_PARTIAL_STRIDE;
+}
+// the histogram is about to be taken on a cell_count that is not known to be clean: clear it, and the tile sums with it
+static void clear_histogram(State &s) {
+    hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + SPH_NGRAVE + 1), s.stream);
+    hipMemsetAsync(s.scan_partial + (size_t)s.scan_bank * (s.scan_blocks + 1) * SCAN_PARTIAL_STRIDE, 0, sizeof(int) * (size_t)(s.scan_blocks + 1) * SCAN_PARTIAL_STRIDE, s.stream);
+}
+
 void l_hash_count(State &s) {
     const int n = s.c.n;
     if (s.prehashed) {   // the last step's force pass has hashed for this sort (NextHash): cell ids, histogram and ranks are in place
         s.prehashed = 0;
         s.cell_count_clean = 0;
         s.n_prehashed_sorts++;
-        return;
+        return;   // (tile_sums_ready was set by l_wcsph_forces)
     }
-    if (!s.cell_count_clean) hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(s.c.G + SPH_NGRAVE + 1), s.stream);
+    if (!s.cell_count_clean) clear_histogram(s);
     s.cell_count_clean = 0;
+    int *ts = tile_sum_bank(s);
+    s.tile_sums_ready = ts != nullptr;
     if (n == 0) return;
     s.n_hash_launches++;
     hipLaunchKernelGGL(k_hash_count, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.cellid,
-                       s.rank, s.cell_count, s.slab_active ? s.meta.cur() : nullptr);
+                       s.rank, s.cell_count, s.slab_active ? s.meta.cur() : nullptr, ts);
 }
 
 void l_scan(State &s) {
     const int G = s.c.G + (s.slab_active ? SPH_NGRAVE : 0);   // + graveyard cells
     int nb = cdiv(G, SCAN_TILE);                      // <= s.scan_blocks (sized for the global grid)
     if (nb < SPH_STAT_SLOTS / SCAN_TPB) nb = SPH_STAT_SLOTS / SCAN_TPB;   // k_scan_final also clears the statistics slots
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial);
-    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, s.scan_partial,
-                       s.cell_start, s.c.n, s.scal, 1 - s.c.stat_bank, s.c.n_dev);
-    s.cell_count_clean = 1;
+    int *part = s.scan_partial + (size_t)s.scan_bank * (s.scan_blocks + 1) * SCAN_PARTIAL_STRIDE;
+    int *part_next = s.scan_partial + (size_t)(1 - s.scan_bank) * (s.scan_blocks + 1) * SCAN_PARTIAL_STRIDE;
+    // the tile sums: left by whoever took the histogram (one launch less per sort, round 6), else by k_scan_reduce
+    if (!s.tile_sums_ready) hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, part);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, part,
+                       s.cell_start, s.c.n, s.scal, 1 - s.c.stat_bank, s.c.n_dev, part_next);
+    s.cell_count_clean = 1;   // ... and so is the bank of tile sums the next histogram adds to
+    s.scan_bank = 1 - s.scan_bank;
+    s.tile_sums_ready = 0;
 }
 
 // per-workgroup header + lane permutation of the neighbour passes (k_block_prep); valid until the order changes
@@ -197,11 +215,32 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     }
 }
 
+// Split launches (SplitPass, sph_passes.hpp): a pass over fewer tiles than SPH_SPLIT_TILES (default: 1536 for a slab-sharded rank -- the
+// chip's workgroup slots at six workgroups per CU --, 0 = never for an unsharded scene, whose sums stay the oracle's bit for bit) runs
+// three workgroups per tile, one per x-offset group, and a combining kernel.
+static bool want_split(State &s) {
+    static const int env = getenv("SPH_SPLIT_TILES") ? atoi(getenv("SPH_SPLIT_TILES")) : -1;
+    const int thr = env >= 0 ? env : (s.slab_active ? 1536 : 0);
+    const int n = s.c.n;
+    return thr > 0 && n > 0 && cdiv(n, NBR_BLOCK) < thr && n <= s.split_cap && s.split_part && s.tile_sel == 0 && s.c.force_global == 0 && s.nbr_mask;
+}
+template <class P> static void launch_split(State &s, const P &p, int mask_mode) {
+    SplitPass<P> sp{p, s.split_part, s.split_cap};
+    s.split_next_pass = 3;
+    launch_pass(s, sp, mask_mode);
+    hipLaunchKernelGGL(k_nbr_combine<P>, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, sp);
+}
+
 void l_density(State &s, int eos) {
     HaloFieldSend fs = s.fieldsend;
     if (!eos) fs.on = 0;
     s.fieldsend.on = 0;
     const int sp = s.density_books_forces ? 1 + 3 : 1, se = s.density_books_forces ? 2 : 1;   // (WcsphForcePass: PAIR_WEIGHT 3, one evaluation per pair)
+    if (eos && want_split(s)) {   // (the WCSPH form; the solvers' density passes without EOS stay as they are)
+        if (s.c.all_fluid) { DensityPass<true, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_split(s, p, 1); }
+        else { DensityPass<false, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_split(s, p, 1); }
+        return;
+    }
     if (s.c.all_fluid) {
         if (eos) { DensityPass<true, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_pass(s, p, 1); }
         else { DensityPass<true, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_pass(s, p, 1); }
@@ -263,9 +302,19 @@ void l_pressure_integrate(State &s) {
 void l_wcsph_forces(State &s) {
     // this pass as the next step's k_hash_count (NextHash): only where the histogram is clean (the scan cleared it behind itself) and
     // every particle is an active fluid particle of an unsharded scene (wcsph_step decides whether another step follows untouched)
-    NextHash nh{0, s.cellid, s.rank, s.cell_count};
-    if (s.nexthash.on && s.c.all_fluid && !s.slab_active && s.cell_count_clean && s.density_books_forces && s.c.n > 0) nh.on = 1;
+    NextHash nh{0, s.cellid, s.rank, s.cell_count, tile_sum_bank(s)};
+    const bool split = s.density_books_forces && want_split(s);   // (finish() then runs in the combining kernel: no epilogue hash)
+    if (s.nexthash.on && s.c.all_fluid && !s.slab_active && s.cell_count_clean && s.density_books_forces && s.c.n > 0 && !split) nh.on = 1;
     s.nexthash.on = 0;
+    if (split) {
+        if (s.c.all_fluid) {
+            WcsphForcePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};
+            launch_split(s, p, 2);
+        } else {
+            WcsphForcePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};
+            launch_split(s, p, 2);
+        }
+    } else
     if (!s.density_books_forces) {   // launched outside wcsph_step's density + forces pair: nobody has booked this walk's pairs
         if (s.c.all_fluid) {
             WcsphForcePass<true, false, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};
@@ -289,7 +338,7 @@ void l_wcsph_forces(State &s) {
         launch_pass(s, p, 2);
     }
     if (s.presend.on) { s.presend.on = 0; s.preclassified = 1; }
-    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; }
+    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; s.tile_sums_ready = nh.tile_sum != nullptr; }
     s.velm.flip();
     s.posv.flip();
     s.masks_valid = 0;  // positions moved

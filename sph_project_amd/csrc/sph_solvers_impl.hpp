@@ -3,35 +3,61 @@
 #pragma once
 
 // DFSPH position update: base_solver.py:652 update_fluid_position + :575 enforce_domain_boundary_3D
+// nh.on (round 6, all-fluid unsharded scenes inside a whole-step call): the kernel is also the k_hash_count of the sort that follows in
+// the same step (DFSPH.py:316) -- it holds every particle's final position, its threads own the particles in sorted order like
+// k_hash_count's: cell id, histogram atomic per run of equal cells, arrival rank, tile sums of the scan.  One launch less per step.
 __global__ void __launch_bounds__(256)
-k_advect_boundary(const Consts c, float4 *posv, float4 *velm, int *meta, const RigidPose *pose, int all_fluid) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= live_n(c)) return;
-    float4 p = posv[i], v = velm[i];
-    const int m = all_fluid ? META_PACK(0, 1, 1) : meta[i];
-    if (META_MAT(m) == 1) {
-        p.x += c.dt * v.x; p.y += c.dt * v.y; p.z += c.dt * v.z;
-        if (META_DYN(m)) enforce_boundary(c, p.x, p.y, p.z, v.x, v.y, v.z);
-        posv[i] = p; velm[i] = v;
-    } else if (up_coord(c, p) > c.g_upper) {  // emitter branch :660-666
-        const int obj = META_OBJ(m);
-        if (obj >= 0 && pose->material[obj] == 1) {
+k_advect_boundary(const Consts c, float4 *posv, float4 *velm, int *meta, const RigidPose *pose, int all_fluid, const NextHash nh) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < live_n(c);
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+        p = posv[i];
+        float4 v = velm[i];
+        const int m = all_fluid ? META_PACK(0, 1, 1) : meta[i];
+        if (META_MAT(m) == 1) {
             p.x += c.dt * v.x; p.y += c.dt * v.y; p.z += c.dt * v.z;
-            if (up_coord(c, p) <= c.g_upper) {
-                meta[i] = META_SET_MAT(m, 1);
-                if (META_DYN(m)) enforce_boundary(c, p.x, p.y, p.z, v.x, v.y, v.z);
-                velm[i] = v;
+            if (META_DYN(m)) enforce_boundary(c, p.x, p.y, p.z, v.x, v.y, v.z);
+            posv[i] = p; velm[i] = v;
+        } else if (up_coord(c, p) > c.g_upper) {  // emitter branch :660-666
+            const int obj = META_OBJ(m);
+            if (obj >= 0 && pose->material[obj] == 1) {
+                p.x += c.dt * v.x; p.y += c.dt * v.y; p.z += c.dt * v.z;
+                if (up_coord(c, p) <= c.g_upper) {
+                    meta[i] = META_SET_MAT(m, 1);
+                    if (META_DYN(m)) enforce_boundary(c, p.x, p.y, p.z, v.x, v.y, v.z);
+                    velm[i] = v;
+                }
+                posv[i] = p;
             }
-            posv[i] = p;
         }
+    }
+    if (nh.on) {   // (uniform)
+        const int lane = threadIdx.x & 63;
+        int lin = -1 - lane;
+        if (valid) {
+            lin = (cell_coord_x(c, p.x) * c.ny + cell_coord(p.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, p.z);
+            nh.cellid[i] = lin;
+        }
+        bool head; int hl, len;
+        wave_runs(lin, lane, head, hl, len);
+        int base = 0;
+        if (head && valid) base = atomicAdd(&nh.cell_count[lin], len);
+        base = __shfl(base, hl, 64);
+        if (valid) nh.rank[i] = base + (lane - hl);
+        if (nh.tile_sum) tile_sum_add(nh.tile_sum, lin, valid);
     }
 }
 
 static void l_advect_boundary(State &s) {
+    NextHash nh{0, s.cellid, s.rank, s.cell_count, tile_sum_bank(s)};
+    if (s.nexthash.on && s.c.all_fluid && !s.slab_active && s.cell_count_clean && s.c.n > 0) nh.on = 1;
+    s.nexthash.on = 0;
     if (s.c.n == 0) return;
     s.masks_valid = 0;  // positions move
     hipLaunchKernelGGL(k_advect_boundary, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(),
-                       s.velm.cur(), s.meta.cur(), s.pose, s.c.all_fluid);
+                       s.velm.cur(), s.meta.cur(), s.pose, s.c.all_fluid, nh);
+    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; s.tile_sums_ready = nh.tile_sum != nullptr; }
 }
 
 static void l_reduce_sum(State &s, int slot, int nblocks) {
@@ -64,7 +90,7 @@ template <int MODE> static void dfsph_rho_adv_t(State &s, int slot) {
         DfsphRhoAdvPass<false, MODE> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho.cur(), s.alpha, out_adv, out_k, s.red_partial};
         launch_pass(s, p, 2);
     }
-    if (s.c.n > 0) l_reduce_sum(s, slot, cdiv(s.c.n, NBR_BLOCK));
+    if (s.c.n > 0 && !s.skip_residual) l_reduce_sum(s, slot, cdiv(s.c.n, NBR_BLOCK));
 }
 static void l_dfsph_rho_adv(State &s, int mode) { if (mode == 0) dfsph_rho_adv_t<0>(s, 0); else dfsph_rho_adv_t<1>(s, 1); }
 
@@ -130,7 +156,7 @@ static void l_pcisph_pressure_accel(State &s) {
         PcisphPressureAccelPass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.ptm, s.acc_np, s.velm.alt(), s.pacc, s.pvel, s.ppos, s.c.rho0, s.red_partial};
         launch_pass(s, p, 2);
     }
-    if (s.c.n > 0) l_reduce_sum(s, 2, cdiv(s.c.n, NBR_BLOCK));   // density error of this iteration's rho* pass
+    if (s.c.n > 0 && !s.skip_residual) l_reduce_sum(s, 2, cdiv(s.c.n, NBR_BLOCK));   // density error of this iteration's rho* pass
 }
 
 // ---- implicit viscosity

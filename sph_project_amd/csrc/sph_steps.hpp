@@ -129,9 +129,23 @@ static int wcsph_step(SphHandle *h) {
     return SPH_OK;
 }
 
+// A solve with a FIXED iteration count (SphParams::fixed_iterations: bench mode, sph_step_async) has no stop test, and nothing reads
+// the residual of an iteration (SphStats::err_* report 0 in this mode): the walks still leave their per-workgroup partial sums, but the
+// one-workgroup kernel that adds them up -- 5 us and a launch boundary per iteration, 2.4 % of a C3 step -- is not launched.  Unsharded
+// only (a sharded solve all-reduces the residual either way).  SPH_FIXED_KEEP_RESIDUAL=1: launch it as before (A/B).
+struct SkipResidual {
+    State &s;
+    SkipResidual(SphHandle *h) : s(h->st) {
+        static const bool keep = getenv("SPH_FIXED_KEEP_RESIDUAL") != nullptr;
+        s.skip_residual = (h->prm.fixed_iterations > 0 && !s.slab_active && !keep) ? 1 : 0;
+    }
+    ~SkipResidual() { s.skip_residual = 0; }
+};
+
 // DFSPH.py:139 correct_divergence_error
 static int dfsph_divergence(SphHandle *h, bool allow_readback, bool first_derivative_done = false) {
     State &s = h->st;
+    SkipResidual skip(h);
     const int fixed = h->prm.fixed_iterations;
     const int max_itr = fixed > 0 ? fixed : 1000;
     // DFSPH.py:140 compute_density_derivative before the loop (dfsph_step_end has it fused into the density + alpha walk)
@@ -178,6 +192,7 @@ static int dfsph_divergence(SphHandle *h, bool allow_readback, bool first_deriva
 // DFSPH.py:225 correct_density_error
 static int dfsph_density(SphHandle *h, bool allow_readback) {
     State &s = h->st;
+    SkipResidual skip(h);
     const int fixed = h->prm.fixed_iterations;
     const int max_itr = fixed > 0 ? fixed : 1000;
     { ProfScope p(h, SPH_K_DFSPH_RHO_ADV); h->L->dfsph_rho_adv(s, 1); }
@@ -234,6 +249,10 @@ static int dfsph_step_begin(SphHandle *h, bool allow_readback) {
     int rc = run_non_pressure(h); if (rc) return rc;                          // DFSPH.py:299-300
     if (s.slab_active) { rc = slab_exchange_vel(h); if (rc) return rc; }      // the density solver reads v_j of the ghosts
     rc = dfsph_density(h, allow_readback); if (rc) return rc;                 // :301
+    // the sort of this step's second half follows at once when the whole step is one call (step_once): the position update hashes for it
+    static const bool no_nexthash = getenv("SPH_NO_NEXT_HASH") != nullptr;
+    s.nexthash.on = (!no_nexthash && h->whole_step && !s.slab_active && s.c.all_fluid && !s.has_emitter && !h->any_rigid_object &&
+                     !h->sort_dirty && !h->pose_dirty) ? 1 : 0;
     { ProfScope p(h, SPH_K_MISC); h->L->advect_boundary(s); }                 // :303, :311-314 (boundary fused: it only looks at the particle itself)
     return SPH_OK;
 }
@@ -256,6 +275,7 @@ static int dfsph_step_end(SphHandle *h, bool allow_readback) {
 // iteration and their predicted positions after it; the density error is summed over the ranks.
 static int pcisph_refine(SphHandle *h, bool allow_readback) {
     State &s = h->st;
+    SkipResidual skip(h);
     const int fixed = h->prm.fixed_iterations;
     const int max_itr = fixed > 0 ? fixed : 1000;
     int itr = 0;

@@ -1,0 +1,48 @@
+"""Run with SPH_SPLIT_TILES=<large> (tests/test_hip_wcsph.py does): unsharded WCSPH scenes through the SPLIT form of the density and force
+passes (SplitPass, csrc/sph_passes.hpp: three workgroups per tile + a combining kernel) against the CPU oracle.  One JSON line."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sph_project_amd import _lib as L  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+
+def run(cfg, fast, steps, jitter):
+    container, solver = H.build_product(cfg, fast_math=fast, jitter=jitter, seed=4)
+    solver.prepare()
+    ref = H.build_oracle(cfg, jitter=jitter, seed=4)
+    ref.prepare()
+    e = container.engine
+    e.step_async(steps); e.synchronize()
+    ref.step(steps)
+    ids = e.download(L.F_PARTICLE_ID)
+    x = H.by_id(ids, e.download(L.F_POSITION))
+    xr = H.by_id(H.oracle_ids(ref), ref.field("particle_positions").copy())
+    rho = H.by_id(ids, e.download(L.F_DENSITY))
+    rr = H.by_id(H.oracle_ids(ref), ref.field("particle_densities").copy())
+    fl = H.by_id(ids, e.download(L.F_MATERIAL)) == 1
+    st = solver.stats()
+    out = {"n": int(len(ids)), "fast": fast, "drift": float(H.drift(x, xr, container.dh).max()),
+           "rho_rel": float((np.abs(rho - rr)[fl] / rr[fl]).max()), "pairs": int(st["pair_interactions"]), "pairs_oracle": int(ref.last_pairs),
+           "prehashed_sorts": int(st["prehashed_sorts"])}
+    e.close(); ref.close()
+    return out
+
+
+def main():
+    out = []
+    block = H.dam_break_scene(end=(0.3, 0.4, 0.3), velocity=(0.4, -1.5, 0.3))
+    box = H.dam_break_scene(domain_end=(0.6, 0.6, 0.6), end=(0.2, 0.2, 0.2), translation=(0.06, 0.06, 0.06), add_domain_box=True)
+    for fast in (0, 1):
+        out.append(dict(run(block, fast, 30, 0.003), scene="all-fluid block, 30 steps"))
+        out.append(dict(run(box, fast, 20, 0.0), scene="block inside a sampled domain box (rigid neighbours), 20 steps"))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -216,5 +216,5 @@ def test_wrench_is_bit_reproducible_and_cheap(gpu):
         import warnings
         warnings.warn("wrench accumulation: force pass %.1f us with a dynamic plate vs %.1f us static (x%.2f; round 4 measured x1.3)" % (
             k_dyn["wcsph_forces"], k_sta["wcsph_forces"], ratio))
-    assert ratio <= 3.0, (k_dyn["wcsph_forces"], k_sta["wcsph_forces"])
+    assert ratio <= 2.0, (k_dyn["wcsph_forces"], k_sta["wcsph_forces"])   # (3.0 let a 2x regression of the dynamic-body pass through)
     eng_dyn.close(); eng_sta.close()

@@ -122,3 +122,23 @@ def test_pcisph_pressure_update_per_term(gpu):
     print(out)
     assert len(out) == 8 and all(o["mismatch"] == 0 for o in out), out
     assert max(o["pressurised"] for o in out) > 1000 and max(o["iterations"] for o in out) >= 2, out
+
+
+@pytest.mark.parametrize("fast_math", [0, 1])
+def test_dfsph_position_update_hashes_for_the_sort_that_follows(gpu, fast_math):
+    """Round 6: inside a whole-step call of an all-fluid unsharded DFSPH scene the position update (k_advect_boundary) is also the
+    k_hash_count of the sort in the same step (DFSPH.py:316).  Same scene stepped as whole steps (hash folded: counted in
+    SphStats::prehashed_sorts) and as sph_step_begin / sph_step_end pairs (the host could act in between: k_hash_count launched as
+    before): ids, positions, velocities, densities bit for bit, iteration counts equal."""
+    cfg = H.dam_break_scene(method="dfsph", end=(0.3, 0.3, 0.3), dt=6e-4, velocity=(0.3, -1.5, 0.2))
+    a_c, a_s = H.build_product(cfg, jitter=0.003, seed=2, fast_math=fast_math); a_s.prepare()
+    b_c, b_s = H.build_product(cfg, jitter=0.003, seed=2, fast_math=fast_math); b_s.prepare()
+    p0 = a_s.stats()["prehashed_sorts"]
+    for step in range(12):
+        a_c.engine.step(1)
+        b_c.engine.step_begin(); b_c.engine.step_end()
+        sa, sb = a_s.stats(), b_s.stats()
+        assert (sa["iter_density"], sa["iter_divergence"]) == (sb["iter_density"], sb["iter_divergence"])
+    assert a_s.stats()["prehashed_sorts"] - p0 == 12 and b_s.stats()["prehashed_sorts"] == 0
+    for f in (L.F_PARTICLE_ID, L.F_POSITION, L.F_VELOCITY, L.F_DENSITY, L.F_DFSPH_ALPHA):
+        np.testing.assert_array_equal(a_c.engine.download(f), b_c.engine.download(f))
