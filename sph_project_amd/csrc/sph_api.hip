@@ -307,10 +307,6 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     if (s.scan_blocks < SPH_STAT_SLOTS / 256) s.scan_blocks = SPH_STAT_SLOTS / 256;   // k_scan_final also clears the statistics slots
     CHK_CREATE(dalloc(h, &s.scan_partial, 2 * ((size_t)s.scan_blocks + 1) * 8));   // two banks of tile sums, SCAN_PARTIAL_STRIDE ints apart (State::scan_bank)
     s.scan_bank = 0; s.tile_sums_ready = 0; s.skip_residual = 0;
-    // split launches (SplitPass): 27 floats per particle (3 groups x up to 9 accumulators) for launches of up to 1 M particles -- the
-    // launches that do not fill the chip are far smaller
-    s.split_cap = (int)std::min<size_t>(cap, (size_t)1 << 20);
-    CHK_CREATE(dalloc(h, &s.split_part, (size_t)27 * s.split_cap));
     s.cell_count_clean = 1;
     CHK_CREATE(dalloc(h, &s.rho_raw, cap)); CHK_CREATE(dalloc(h, &s.prs, cap)); CHK_CREATE(dalloc(h, &s.ptm, cap));
     CHK_CREATE(dalloc(h, &s.acc, cap));

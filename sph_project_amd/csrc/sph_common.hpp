@@ -185,8 +185,6 @@ struct State {
     int *scan_partial;
     int scan_blocks;
     int scan_bank;       // bank the hashers of the coming sort add to / the coming scan reads
-    float *split_part;   // [3 * NACC][split_cap]: per-group shares of the accumulators of a split launch (SplitPass, sph_passes.hpp)
-    int split_cap;       // particles the array holds (a launch over more is never split)
     int skip_residual;   // fixed-iteration solves (no stop test, nobody reads the residual): the walks leave their partial sums, k_reduce_partials is not launched
     int tile_sums_ready; // ... and they did (else l_scan launches k_scan_reduce first: SPH_NO_SCAN_FOLD)
     int cell_count_clean;              // cell_count is all zero (the scan clears it behind itself)

@@ -215,32 +215,11 @@ template <class P> void launch_pass(State &s, const P &p, int mask_mode = 0) {
     }
 }
 
-// Split launches (SplitPass, sph_passes.hpp): a pass over fewer tiles than SPH_SPLIT_TILES (default: 1536 for a slab-sharded rank -- the
-// chip's workgroup slots at six workgroups per CU --, 0 = never for an unsharded scene, whose sums stay the oracle's bit for bit) runs
-// three workgroups per tile, one per x-offset group, and a combining kernel.
-static bool want_split(State &s) {
-    static const int env = getenv("SPH_SPLIT_TILES") ? atoi(getenv("SPH_SPLIT_TILES")) : -1;
-    const int thr = env >= 0 ? env : (s.slab_active ? 1536 : 0);
-    const int n = s.c.n;
-    return thr > 0 && n > 0 && cdiv(n, NBR_BLOCK) < thr && n <= s.split_cap && s.split_part && s.tile_sel == 0 && s.c.force_global == 0 && s.nbr_mask;
-}
-template <class P> static void launch_split(State &s, const P &p, int mask_mode) {
-    SplitPass<P> sp{p, s.split_part, s.split_cap};
-    s.split_next_pass = 3;
-    launch_pass(s, sp, mask_mode);
-    hipLaunchKernelGGL(k_nbr_combine<P>, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, sp);
-}
-
 void l_density(State &s, int eos) {
     HaloFieldSend fs = s.fieldsend;
     if (!eos) fs.on = 0;
     s.fieldsend.on = 0;
     const int sp = s.density_books_forces ? 1 + 3 : 1, se = s.density_books_forces ? 2 : 1;   // (WcsphForcePass: PAIR_WEIGHT 3, one evaluation per pair)
-    if (eos && want_split(s)) {   // (the WCSPH form; the solvers' density passes without EOS stay as they are)
-        if (s.c.all_fluid) { DensityPass<true, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_split(s, p, 1); }
-        else { DensityPass<false, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_split(s, p, 1); }
-        return;
-    }
     if (s.c.all_fluid) {
         if (eos) { DensityPass<true, true> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_pass(s, p, 1); }
         else { DensityPass<true, false> p{s.posv.cur(), s.meta.cur(), s.rho_raw, s.rho.cur(), s.prs, s.ptm, fs, sp, se}; launch_pass(s, p, 1); }
@@ -303,18 +282,8 @@ void l_wcsph_forces(State &s) {
     // this pass as the next step's k_hash_count (NextHash): only where the histogram is clean (the scan cleared it behind itself) and
     // every particle is an active fluid particle of an unsharded scene (wcsph_step decides whether another step follows untouched)
     NextHash nh{0, s.cellid, s.rank, s.cell_count, tile_sum_bank(s)};
-    const bool split = s.density_books_forces && want_split(s);   // (finish() then runs in the combining kernel: no epilogue hash)
-    if (s.nexthash.on && s.c.all_fluid && !s.slab_active && s.cell_count_clean && s.density_books_forces && s.c.n > 0 && !split) nh.on = 1;
+    if (s.nexthash.on && s.c.all_fluid && !s.slab_active && s.cell_count_clean && s.density_books_forces && s.c.n > 0) nh.on = 1;
     s.nexthash.on = 0;
-    if (split) {
-        if (s.c.all_fluid) {
-            WcsphForcePass<true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};
-            launch_split(s, p, 2);
-        } else {
-            WcsphForcePass<false> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};
-            launch_split(s, p, 2);
-        }
-    } else
     if (!s.density_books_forces) {   // launched outside wcsph_step's density + forces pair: nobody has booked this walk's pairs
         if (s.c.all_fluid) {
             WcsphForcePass<true, false, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};

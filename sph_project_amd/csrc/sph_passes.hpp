@@ -128,10 +128,6 @@ struct DensityPass {
         return 0.0f;
     }
     __device__ void passive(const Consts &, int, const float4 &) const {}
-    // split launch (SplitPass below): the accumulators a workgroup of one x-offset group leaves / the combining kernel adds up
-    static constexpr int NACC = 1;
-    __device__ void acc_get(const Own &o, float (&a)[NACC]) const { a[0] = o.sum; }
-    __device__ void acc_add(Own &o, const float (&a)[NACC]) const { o.sum += a[0]; }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -561,68 +557,7 @@ struct WcsphForcePass {
         posv_out[i] = pi;
         if (hs.on) halo_presend(c, hs, i, pi, v, rho[i]);   // (last step's ghosts die here; a static particle in a boundary layer is copied)
     }
-    // split launch (SplitPass below).  The fast build keeps surface tension + viscosity in ONE accumulator (o.ax..): six floats
-    static constexpr int NACC = SPH_FAST ? 6 : 9;
-    __device__ void acc_get(const Own &o, float (&a)[NACC]) const {
-        a[0] = o.ax; a[1] = o.ay; a[2] = o.az; a[3] = o.px; a[4] = o.py; a[5] = o.pz;
-        if constexpr (NACC == 9) { a[6] = o.sx; a[7] = o.sy; a[8] = o.sz; }
-    }
-    __device__ void acc_add(Own &o, const float (&a)[NACC]) const {
-        o.ax += a[0]; o.ay += a[1]; o.az += a[2]; o.px += a[3]; o.py += a[4]; o.pz += a[5];
-        if constexpr (NACC == 9) { o.sx += a[6]; o.sy += a[7]; o.sz += a[8]; }
-    }
 };
-
-// ---------------------------------------------------------------------------------------
-// SplitPass<P>: P launched with one workgroup per (tile, x-offset group) -- k_nbr_pass's SPLIT3 form, gridDim.y = 3 -- for launches
-// with fewer tiles than the chip has workgroup slots (round 6).  A rank of a strong-scaled scene holds a few hundred tiles (the 1.23 M
-// scene on 8 ranks: ~600 + ghosts on 1024-1536 slots): every pass takes ONE workgroup lifetime whatever its size, lane = particle
-// cannot go faster, and half the chip idles (profiles/r05_final_slab_size_probe.json).  Three workgroups per tile walk a third of the
-// candidates each: three times the waves in flight, ~a third of the lifetime.  A workgroup leaves its group's share of every accumulator
-// (P::acc_get -> part[(g NACC + a) stride + i], coalesced), k_nbr_combine<P> adds the three shares in group order (P::acc_add on a fresh
-// begin()) and runs P::finish / P::passive -- with everything they carry (EOS + field send, integration + boundary + presend).  The
-// sums differ from the unsplit walk's by association only ((g0 + g1) + g2 instead of one running sum): not the oracle's bits, well
-// inside its tolerance -- which is why only sharded ranks take this path by default (State::split_tiles; SPH_SPLIT_TILES).
-// A separate instantiation of k_nbr_pass: the unsplit kernels are the ones they were.
-template <class P>
-struct SplitPass : P {
-    static constexpr bool SPLIT3 = true;
-    static constexpr bool NEXT_HASH = false;   // finish() runs in the combining kernel: no epilogue hash here
-    float *part; int part_stride;
-    __device__ float *split_out(int) const { return nullptr; }
-    __device__ void partial_zero(int, int) const {}
-    __device__ float partial(const Consts &, int i, int g, const typename P::Own &o) const {
-        float a[P::NACC];
-        P::acc_get(o, a);
-#pragma unroll
-        for (int k = 0; k < P::NACC; ++k) part[(size_t)(g * P::NACC + k) * part_stride + i] = a[k];
-        return 0.0f;
-    }
-};
-
-template <class P>
-__global__ void __launch_bounds__(256)
-k_nbr_combine(const Consts c, const SplitPass<P> p) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int n = live_n(c);
-    if (n <= 0) return;
-    const bool valid = i < n;
-    const int ic = valid ? i : n - 1;
-    const float4 pi = p.posv[ic];
-    typename P::Own own;
-    const bool active = p.begin(c, ic, pi, own) && valid;
-    if (!valid) return;
-    if (active) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            float a[P::NACC];
-#pragma unroll
-            for (int k = 0; k < P::NACC; ++k) a[k] = p.part[(size_t)(g * P::NACC + k) * p.part_stride + i];
-            p.acc_add(own, a);
-        }
-        p.finish(c, i, pi, own);
-    } else p.passive(c, i, pi);
-}
 
 // ---------------------------------------------------------------------------------------
 // base_solver.py:106 compute_rigid_particle_volume (+task :117).  i rigid, j same object.
