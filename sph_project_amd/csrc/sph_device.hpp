@@ -482,6 +482,10 @@ __device__ __forceinline__ void lds_load_half_imm(unsigned a, v2f (&xy)[4], floa
 #ifndef SPH_P1_CHUNK
 #define SPH_P1_CHUNK 4   // candidates per LDS round trip of the unrolled phase 1 (8: r01 layout, 4: fits 96 VGPRs)
 #endif
+#ifndef SPH_P1_TRIP
+#define SPH_P1_TRIP 4    // candidates per wave-uniform trip of phase 1.  8 (until round 6): two LDS round trips of 4 per loop test; 4: one -- 3.6 % / 6.9 % fewer
+                         // tests from rest / in motion (tools/analysis/zbin_estimate.py) for one more loop test per 8: C2 +-0 from rest, -1.1 % in motion (profiles/r06_p1_trip4_ab.txt)
+#endif
 typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
 typedef __attribute__((address_space(3))) const int lds_ci32;
 __device__ __forceinline__ int lds_ld_i32(const int *p) { return *(lds_ci32 *)p; }
@@ -605,7 +609,7 @@ __device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int
             }
         } else {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < SPH_P1_TRIP / 4; ++hh) {
                 v2f xy[4];
                 float zz[4];
                 lds_load_half_imm<ZW_OFF>(lds_addr(&sXY[base + t0 + 4 * hh]), xy, zz);
@@ -618,7 +622,7 @@ __device__ __forceinline__ unsigned phase1_mask(const float2 *sXY, int base, int
                 }
             }
         }
-        t0 += 8;
+        t0 += SPH_P1_CHUNK == 8 ? 8 : SPH_P1_TRIP;
     } while (__any(t0 < m));
     S = t0;
     unsigned nm = S > 0 ? __brev(mask) >> (32 - S) : 0u;   // bit t = slot t
