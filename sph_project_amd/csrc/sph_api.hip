@@ -195,6 +195,7 @@ static void fill_consts(SphHandle *h) {
     c.V0 = (float)p.V0;
     c.force_global = p.force_global;
     c.stat_bank = 0;
+    c.run_grouping = 0;
     c.ghosts = 0;
 }
 
@@ -203,6 +204,13 @@ static void refresh_counts(SphHandle *h) {
     h->st.has_emitter = h->prm.g_upper < 9999.0;
     h->st.c.all_fluid = (h->n_nonfluid == 0 && !h->st.has_emitter && !(h->st.slab_active && h->any_rigid_object)) ? 1 : 0;
     h->st.c.ghosts = h->st.slab_active ? 1 : 0;
+    // staging groups of the neighbour passes (sph_device.hpp run_of): outer runs mixed in the fast build on unsharded grids that are not thin
+    // (a slab's runs overlap and are staged once, nbr_plan "chain": x-offset groups there); SPH_RUN_GROUPING=0|1 overrides (A/B)
+    {
+        static const int env = getenv("SPH_RUN_GROUPING") ? atoi(getenv("SPH_RUN_GROUPING")) : -1;
+        const int want = (h->prm.fast_math && !h->st.slab_active && h->st.c.nz >= 40) ? 1 : 0;
+        h->st.c.run_grouping = (env >= 0 ? (env != 0) : want) && h->prm.fast_math ? 1 : 0;
+    }
     h->st.has_rigid = h->n_nonfluid > 0;
     h->st.uniform_mass = (h->st.c.all_fluid && h->fluid_mass_uniform && !h->st.slab_active && !getenv("SPH_NO_UNIFORM_MASS")) ? 1 : 0;
 }

@@ -939,23 +939,40 @@ template <class P> constexpr int nbr_tile_cap() {
     // leaves room for SPH_NBR_WAVES_LIGHT workgroups per CU (1280 slots = 23.7 KB: six; 1232 = 22.9 KB: seven)
     return slots > SPH_NBR_LIGHT_CAP ? SPH_NBR_LIGHT_CAP : slots / 8 * 8;
 }
+// Which of the tile's nine candidate runs (k = 3 (ox + 1) + (oy + 1)) form staging group g?  (Consts::run_grouping)
+//   0: the three runs of x offset g - 1, oy ascending -- the reference's order of accumulation (strict build, always), and the one whose
+//      runs overlap on thin grids (nbr_plan "chain": slab-sharded ranks);
+//   1 (round 6, fast build, unsharded grids with nz >= 40): the middle group as before, the outer two MIXED:
+//        g = 0: (-1,-1) (-1,+1) (+1, 0)      g = 2: (-1, 0) (+1,-1) (+1,+1)
+//      A lattice particle in the low-x half of its cell has 9 / 17 / 0 accepted neighbours in the x-offset groups, one in the high-x half
+//      0 / 17 / 9: waves sorted by x (lane permutation) are uniform inside, but the four waves of a workgroup meet at a barrier behind every
+//      group (the tile is restaged), so the workgroup's clock sees 9 + 17 + 9 = 35 merged-loop trips for 26 per wave.  With the outer runs
+//      mixed every particle has 3 or 6 in either outer group: 6 + 17 + 6 = 29.  On real states (tools/analysis/grouping.py): per-workgroup
+//      trips 34.0 -> 28.3 at rest, 73.4 -> 62.9 in motion, per-wave trips unchanged; best of all partitions into three groups of three.
+//      The sums change by association only (the fast build does not keep the reference's order anyway).
+__device__ __forceinline__ int run_of(int grouping, int g, int q) {
+    const int i = g * 3 + q;
+    return grouping ? (int)((0x861543720ull >> (4 * i)) & 15ull) : i;
+}
+
 // Staging plan of one round of one x-offset group (workgroup-uniform; see the group loop of k_nbr_pass): which of the group's three
 // runs go into the tile (bit q of rm), at which tile offset (lo_[q] = offset - run start; INT_MIN: not staged), how many slots in all.
 template <int CAP>
 __device__ __forceinline__ void nbr_plan(const int *__restrict__ hdr, int g, int qa, int fg, int (&rs_)[3], int (&ln_)[3], int (&lo_)[3],
-                                         int &total, int &qb, unsigned &rm, bool &overflow) {
+                                         int &total, int &qb, unsigned &rm, bool &overflow, int grouping) {
     total = 0; qb = 3; rm = 7u; overflow = false;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        rs_[q] = hdr[2 + g * 3 + q];
-        ln_[q] = hdr[11 + g * 3 + q] > 0 ? hdr[11 + g * 3 + q] : 0;
+        const int k = run_of(grouping, g, q);
+        rs_[q] = hdr[2 + k];
+        ln_[q] = hdr[11 + k] > 0 ? hdr[11 + k] : 0;
     }
     // Thin grids (nz <= the workgroup's cell span + 2: small scenes, and the slabs of a sharded scene -- C4 on 8 ranks has 12
     // layers per rank): the three runs of a group are windows of one and the same stretch of the sorted arrays, nz cells apart,
     // and overlap.  Stage that stretch ONCE (all three runs share one tile offset) instead of three overlapping copies:
     // 34 + 2 nz cells instead of 102 -- at nz = 12 40 % less staging traffic and LDS, and piled-up groups fit more often.
     const int ulen = rs_[2] + ln_[2] - rs_[0];
-    const bool chain = ln_[0] > 0 && ln_[1] > 0 && ln_[2] > 0 && rs_[1] >= rs_[0] && rs_[1] <= rs_[0] + ln_[0] &&
+    const bool chain = !grouping && ln_[0] > 0 && ln_[1] > 0 && ln_[2] > 0 && rs_[1] >= rs_[0] && rs_[1] <= rs_[0] + ln_[0] &&
                        rs_[2] >= rs_[1] && rs_[2] <= rs_[1] + ln_[1] && ulen >= ln_[2];
     if (qa == 0 && chain && ulen <= CAP && fg != 1 && fg != 5) {
         lo_[0] = lo_[1] = lo_[2] = -rs_[0];
@@ -1107,7 +1124,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     if (MASKMODE == 2 && pass_mask_pipe<P>()) {
         const int g0 = (PassSplit<P>::value && gridDim.y > 1) ? split_lo((int)gridDim.y, (int)blockIdx.y) : 0;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) mk0[q] = nbr_mask[(size_t)(g0 * 3 + q) * mask_stride + i];   // (the array has a tile of slack)
+        for (int q = 0; q < 3; ++q) mk0[q] = nbr_mask[(size_t)run_of(c.run_grouping, g0, q) * mask_stride + i];   // (the array has a tile of slack)
     }
     // -DSPH_PRESTAGE (off): the first staging round depends on the header alone, so its global loads can go out HERE and be written to
     // the tile after the prologue's barrier; the records sit in registers only across the prologue, where little else is live.  One
@@ -1125,7 +1142,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
     int ptotal = 0;
     if constexpr (PRESTAGE) {
         int rs_[RPG], ln_[RPG], lo_[RPG], qb; unsigned rm; bool overflow;
-        nbr_plan<CAP>(hdr, g_first, 0, c.force_global, rs_, ln_, lo_, ptotal, qb, rm, overflow);
+        nbr_plan<CAP>(hdr, g_first, 0, c.force_global, rs_, ln_, lo_, ptotal, qb, rm, overflow, c.run_grouping);
         if (c.force_global == 10 || c.force_global == 11) ptotal = 0;
         const int n0 = lo_[0] != INT_MIN ? ln_[0] : 0;
         const int n01 = n0 + (lo_[1] != INT_MIN ? ln_[1] : 0);
@@ -1211,7 +1228,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             int total, qb;
             unsigned rm;                 // runs of this round (bit q)
             bool overflow;
-            nbr_plan<CAP>(hdr, g, qa, c.force_global, rs_, ln_, lo_, total, qb, rm, overflow);
+            nbr_plan<CAP>(hdr, g, qa, c.force_global, rs_, ln_, lo_, total, qb, rm, overflow, c.run_grouping);
 #define NBR_IN_ROUND(q) ((rm >> (q)) & 1u)
             if (tid < RPG) {
                 s_loff[g * RPG + tid] = tid == 0 ? lo_[0] : (tid == 1 ? lo_[1] : lo_[2]);
@@ -1228,7 +1245,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                 for (int q = 0; q < RPG; ++q) mk[q] = mkn[q];
             } else {
 #pragma unroll
-                for (int q = 0; q < RPG; ++q) mk[q] = nbr_mask[(size_t)(g * RPG + q) * mask_stride + i];
+                for (int q = 0; q < RPG; ++q) mk[q] = nbr_mask[(size_t)run_of(c.run_grouping, g, q) * mask_stride + i];
             }
             // stage the runs that fit; consecutive t -> consecutive j: coalesced.  SB slots per batch: all of them where the
             // registers allow it (the medium functors' 96-VGPR budget and the strict build's wide records do not).
@@ -1252,7 +1269,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             if (MASKMODE == 2 && pass_mask_pipe<P>()) {   // first mask words of the NEXT round's group ([run][particle] layout)
                 const int gn = qb >= RPG ? (g + 1 < GROUPS ? g + 1 : g) : g;
 #pragma unroll
-                for (int q = 0; q < RPG; ++q) mkn[q] = nbr_mask[(size_t)(gn * RPG + q) * mask_stride + i];
+                for (int q = 0; q < RPG; ++q) mkn[q] = nbr_mask[(size_t)run_of(c.run_grouping, gn, q) * mask_stride + i];
             }
             // candidate sub-ranges of this lane's particle in the three runs (from the cached cell_start windows)
             bool inr[RPG];
@@ -1260,7 +1277,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             bool wide = false, longrun = false;
 #pragma unroll
             for (int q = 0; q < RPG; ++q) {
-                const int k = g * RPG + q;
+                const int k = run_of(c.run_grouping, g, q);
                 inr[q] = NBR_IN_ROUND(q) && active && ((dom >> k) & 1u);
                 js_[q] = 0; m_[q] = 0;
                 if (inr[q]) {
@@ -1273,7 +1290,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                     } else {   // (a workgroup spanning more cells than the window cache holds: sparse spray)
                         float px = pi.x, py = pi.y, pz = pi.z;
                         asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));   // keeps the recomputation IN this branch (it is loop-invariant: hoisted, it would hold four registers for every workgroup)
-                        const int xx = cell_coord_x(c, px) + g - 1, yy = cell_coord(py, c.grid_size, c.ny) + q - 1;
+                        const int xx = cell_coord_x(c, px) + k / 3 - 1, yy = cell_coord(py, c.grid_size, c.ny) + k % 3 - 1;
                         const int cz = cell_coord_z(c, pz);
                         const int z0 = cz > 0 ? cz - 1 : 0;
                         const int z1 = cz < c.nz - 1 ? cz + 1 : c.nz - 1;
@@ -1331,7 +1348,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             // one, wave-uniformly
             if (overflow) {
                 // (workgroup-uniform) this round is ONE run, and it does not fit the tile: through the tile in chunks (process_chunk)
-                const int k = g * RPG + qa;
+                const int k = run_of(c.run_grouping, g, qa);
                 const int rsq = qa == 0 ? rs_[0] : (qa == 1 ? rs_[1] : rs_[2]);
                 const int lnq = qa == 0 ? ln_[0] : (qa == 1 ? ln_[1] : ln_[2]);
                 const bool in = qa == 0 ? inr[0] : (qa == 1 ? inr[1] : inr[2]);
@@ -1364,7 +1381,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                 // its registers.
 #pragma unroll 1
                 for (int q = 0; q < RPG; ++q) {
-                    const int k = g * RPG + q;
+                    const int k = run_of(c.run_grouping, g, q);
                     const bool in = q == 0 ? inr[0] : (q == 1 ? inr[1] : inr[2]);
                     const int js = in ? (q == 0 ? js_[0] : (q == 1 ? js_[1] : js_[2])) : 0;
                     const int m = in ? (q == 0 ? m_[0] : (q == 1 ? m_[1] : m_[2])) : 0;
@@ -1384,7 +1401,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
                 unsigned ab[RPG];
 #pragma unroll
                 for (int q = 0; q < RPG; ++q) {
-                    const int k = g * RPG + q;
+                    const int k = run_of(c.run_grouping, g, q);
                     const int base = inr[q] ? js_[q] + lo_[q] : 0;
                     unsigned nm, nh = 0u;
                     if (MASKMODE == 2) {
