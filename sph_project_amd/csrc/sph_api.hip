@@ -766,6 +766,14 @@ static int step_once(SphHandle *h, bool allow_readback) {
     h->whole_step = true;
     int rc = step_first_half(h, allow_readback);
     h->whole_step = false;
+#ifdef SPH_TEST_HOOKS
+    // test-hook library only: SPH_TEST_FAIL_STEP=k makes the step with h->steps == k fail between its halves, ONCE -- what a device or
+    // exchange error in the middle of a sph_step_async(n) looks like to the state machine (a hash made for a sort that will not come)
+    {
+        static int fail_at = getenv("SPH_TEST_FAIL_STEP") ? atoi(getenv("SPH_TEST_FAIL_STEP")) : -1;
+        if (!rc && fail_at >= 0 && h->steps == fail_at) { fail_at = -1; h->in_step = false; rc = fail(h, SPH_ERR_INVALID, "SPH_TEST_FAIL_STEP: injected failure"); }
+    }
+#endif
     if (!rc) rc = step_second_half(h, allow_readback);
     // a failed step may leave a hash made for a sort that will not come (NextHash: the WCSPH force pass for the next step's sort, the
     // DFSPH position update for this step's): the next sort, whoever asks for it, must hash for itself on a clean histogram

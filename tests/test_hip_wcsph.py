@@ -464,3 +464,30 @@ def test_two_fluid_masses_against_the_oracle(gpu, fast_math):
     assert d.max() <= 1e-5, d.max()
     np.testing.assert_allclose(a["v"], b["v"], rtol=0, atol=5e-5 * float(np.abs(b["v"]).max()))
 
+
+
+def test_a_failed_step_drops_the_hash_made_for_its_successor(gpu, tmp_path):
+    """NextHash relies on every failure path clearing `prehashed` / `cell_count_clean`.  The test-hook library fails step 4 of a
+    sph_step_async(10) between its halves -- after the force pass has hashed for step 5 -- once; the call reports the error, the next call
+    steps on, and the state after 10 steps' worth of device work equals that of an undisturbed run bit for bit (ids, positions, velocities):
+    the abandoned histogram was cleared, the next sort hashed for itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hooks = os.path.join(root, "sph_project_amd", "libsph_hip_testhooks.so")
+    out = {}
+    for tag, env in (("plain", {}), ("failed", {"SPH_TEST_FAIL_STEP": "4"})):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "failed_step_probe.py"), "wcsph", str(tmp_path / (tag + ".npz"))],
+                           env=dict(os.environ, SPH_HIP_LIB=hooks, **env), capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        out[tag] = (json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), np.load(tmp_path / (tag + ".npz")))
+    print(out["plain"][0], out["failed"][0])
+    assert out["plain"][0]["failed"] == "" and "injected failure" in out["failed"][0]["failed"]
+    assert out["failed"][0]["steps_after_failure"] == 4
+    # one hash kernel more than the undisturbed run's two calls need: the sort after the failure could not use the abandoned hash
+    assert out["failed"][0]["hash_launches"] == out["plain"][0]["hash_launches"] + 1, (out["plain"][0], out["failed"][0])
+    for k in ("ids", "pos", "vel"):
+        np.testing.assert_array_equal(out["plain"][1][k], out["failed"][1][k])
+    assert out["plain"][0]["pairs"] == out["failed"][0]["pairs"]
