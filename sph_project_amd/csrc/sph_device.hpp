@@ -225,9 +225,14 @@ __device__ __forceinline__ void wave_runs(int key, int lane, bool &head, int &hl
 // 32 to a line) cost the force pass 88 us in motion (profiles/r06_scanfold_ab.txt).
 #define SCAN_TILE_SHIFT 11
 #define SCAN_PARTIAL_STRIDE 8
-__device__ __forceinline__ void tile_sum_add(int *tile_sum, int lin, bool valid) {
+// The sum of the LAST tile is never read (a tile needs the sums of the tiles before it): particles of its cells are not added.  That is
+// where the graveyard cells of a slab-sharded rank sit (G .. G + SPH_NGRAVE - 1): every wave of the classifying kernels holds a few dead
+// lanes -- last step's ghosts sit at both ends of every z column -- and their atomics would all land on that ONE counter (measured:
+// +17 % on a two-rank step, profiles/r06_two_ranks_scanfold_ab.txt; lesson 1 a third time).
+__device__ __forceinline__ void tile_sum_add(int *tile_sum, int lin, bool valid, int cells_total) {
     const int lane = threadIdx.x & 63;
     const int t = lin >> SCAN_TILE_SHIFT;
+    valid = valid && t != ((cells_total - 1) >> SCAN_TILE_SHIFT);
     unsigned long long rem = __ballot(valid);
     while (rem) {   // wave-uniform
         const int src = __ffsll((long long)rem) - 1;
@@ -265,7 +270,7 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
     if (head && valid) base = atomicAdd(&cell_count[lin], len);
     base = __shfl(base, hl, 64);
     if (valid) rank[i] = base + (lane - hl);
-    if (tile_sum) tile_sum_add(tile_sum, lin, valid);
+    if (tile_sum) tile_sum_add(tile_sum, lin, valid, c.G + (meta_dead ? SPH_NGRAVE : 0));
 }
 
 // base_container.py:546 PrefixSumExecutor.run -- here an exclusive scan into cell_start[0..G],
@@ -1495,7 +1500,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             if (head && v2) base = atomicAdd(&p.nh.cell_count[lin], len);
             base = __shfl(base, hl, 64);
             if (v2) { p.nh.cellid[i0 + tid] = lin; p.nh.rank[i0 + tid] = base + (lane - hl); }
-            if (p.nh.tile_sum) tile_sum_add(p.nh.tile_sum, lin, v2);
+            if (p.nh.tile_sum) tile_sum_add(p.nh.tile_sum, lin, v2, c.G);   // (unsharded only: no graveyard cells)
         }
     }
     if (split_launch && !red_to) return;   // uniform; the combining kernel reduces

@@ -107,7 +107,7 @@ k_halo_classify(const Consts c, int n_host, const int *__restrict__ n_dev, int z
         if (head && i < n) base = atomicAdd(&hash.cell_count[lin], len);
         base = __shfl(base, hl, 64);
         if (i < n) hash.rank[i] = base + (lane - hl);
-        if (hash.tile_sum) tile_sum_add(hash.tile_sum, lin, i < n);
+        if (hash.tile_sum) tile_sum_add(hash.tile_sum, lin, i < n, c.G + SPH_NGRAVE);
     }
     if (i >= n) return;
     if (side >= 0) {
@@ -246,7 +246,8 @@ k_halo_unpack2(const Consts c, HaloStep w, int z_lo, int z_hi, float4 *posv, flo
             const int lin = (cell_coord_x(c, p.x) * c.ny + cell_coord(p.y, c.grid_size, c.ny)) * c.nz + cell_coord_z(c, p.z);
             hash.cellid[d] = lin;
             hash.rank[d] = atomicAdd(&hash.cell_count[lin], 1);
-            if (hash.tile_sum) atomicAdd(&hash.tile_sum[(lin >> SCAN_TILE_SHIFT) * SCAN_PARTIAL_STRIDE], 1);   // (arrivals: a few thousand per step, spread over the ghost layers' tiles)
+            if (hash.tile_sum && (lin >> SCAN_TILE_SHIFT) != ((c.G + SPH_NGRAVE - 1) >> SCAN_TILE_SHIFT))   // (the last tile's sum is never read: tile_sum_add)
+                atomicAdd(&hash.tile_sum[(lin >> SCAN_TILE_SHIFT) * SCAN_PARTIAL_STRIDE], 1);   // arrivals: a few thousand per step, spread over the ghost layers' tiles
         }
     }
     const int longest = s_v[3];

@@ -24,10 +24,14 @@ namespace SPH_NS {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// tile sums of the coming scan (State::scan_partial): the bank the hashers add to, or null (SPH_NO_SCAN_FOLD: k_scan_reduce computes them)
+// tile sums of the coming scan (State::scan_partial): the bank the hashers add to, or null (k_scan_reduce computes them: SPH_NO_SCAN_FOLD, and
+// every slab-sharded rank -- there the fold LOSES: the arrivals take one more atomic each in a waiting kernel of 64 workgroups and a thin slab's
+// waves straddle tiles; two ranks on one GPU +1.4 ... +2.3 %, eight ranks +19 %, profiles/r06_two_ranks_scanfold_ab.txt)
 static int *tile_sum_bank(State &s) {
     static const bool off = getenv("SPH_NO_SCAN_FOLD") != nullptr;
-    return off ? nullptr : s.scan_partial + (size_t)s.scan_bank * (s.scan_blocks + 1) * SCAN_PARTIAL_STRIDE;
+    static const bool force = getenv("SPH_SCAN_FOLD_SLAB") != nullptr;
+    if (off || (s.slab_active && !force)) return nullptr;
+    return s.scan_partial + (size_t)s.scan_bank * (s.scan_blocks + 1) * SCAN_PARTIAL_STRIDE;
 }
 // the histogram is about to be taken on a cell_count that is not known to be clean: clear it, and the tile sums with it
 static void clear_histogram(State &s) {

@@ -45,7 +45,7 @@ k_advect_boundary(const Consts c, float4 *posv, float4 *velm, int *meta, const R
         if (head && valid) base = atomicAdd(&nh.cell_count[lin], len);
         base = __shfl(base, hl, 64);
         if (valid) nh.rank[i] = base + (lane - hl);
-        if (nh.tile_sum) tile_sum_add(nh.tile_sum, lin, valid);
+        if (nh.tile_sum) tile_sum_add(nh.tile_sum, lin, valid, c.G);
     }
 }
 
