@@ -46,6 +46,8 @@ struct SphHandle {
     bool prepared = false;
     bool pose_dirty = false;
     int loop_hint[4] = {0, 0, 0, 0};   // iterations the last solve of each device-controlled loop took (sph_steps.hpp device_loop), by reduction slot
+    struct LoopPub *loop_pub = nullptr;   // pinned: residual + flags of a solver loop's batch, published by a kernel (sph_steps.hpp k_publish_loop)
+    unsigned loop_seq = 0;
     int dev_cus = 256;           // compute units of the device (sizing of grids that should be resident at once)
     bool pose_given = false;     // sph_set_rigid_pose was called: pose_h holds library-frame vectors of the CURRENT axis order
     bool rigid_volume_done = false;
@@ -239,6 +241,7 @@ extern "C" void sph_destroy(SphHandle *h) {
     for (auto e : h->ev_pool) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->scal_h) hipHostFree(h->scal_h);
+    if (h->loop_pub) hipHostFree((void *)h->loop_pub);
     if (h->st.list_count_pinned) { hipHostFree((void *)h->st.list_count_pinned); h->st.list_count_pinned = nullptr; }
     if (h->st.list_count_event) { hipEventDestroy(h->st.list_count_event); h->st.list_count_event = nullptr; }
     if (h->st.stream) hipStreamDestroy(h->st.stream);
@@ -355,6 +358,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.cg_parity = 0;
     CHK_CREATE(dalloc(h, &s.scal, 1)); CHK_CREATE(dalloc(h, &s.pose, 1));
     HIP_CREATE(hipHostMalloc((void **)&h->scal_h, sizeof(DevScalars), hipHostMallocDefault));
+    { void *lp = nullptr; HIP_CREATE(hipHostMalloc(&lp, 64, hipHostMallocDefault)); memset(lp, 0, 64); h->loop_pub = (struct LoopPub *)lp; }
     { int *lc = nullptr; HIP_CREATE(hipHostMalloc((void **)&lc, 64, hipHostMallocDefault)); *lc = 0; s.list_count_pinned = lc; }
     HIP_CREATE(hipEventCreateWithFlags(&s.list_count_event, hipEventDisableTiming));
     s.list_count_known = -1;

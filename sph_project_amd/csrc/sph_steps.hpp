@@ -13,6 +13,55 @@ static int read_red(SphHandle *h, int slot, float *out) {
 
 static int implicit_viscosity_non_pressure(SphHandle *h);
 
+// Read-back of a solver loop's batch (round 6).  hipMemcpyAsync D2H + hipStreamSynchronize cost 35-75 us of idle GPU per batch (the copy is a
+// kernel of the runtime, the synchronise sleeps on an interrupt: profiles/r05_gaps_c3_motion.txt) -- two to three per solve, five to six per
+// step of the buckling scene: a fifth of its step.  Instead a one-wave kernel behind the batch stores the residuals and the flags into pinned
+// host memory, the batch number last (system-scope release), and the host spins on that number: the wait ends a few microseconds after the
+// batch's last kernel.  (The same kernel -> pinned memory -> polling host pattern as the slab counts' mirror, sph_halo.hpp.)  Bounded: the host
+// looks at hipStreamQuery every few microseconds and falls back to the copy when the stream is idle or broken.  SPH_NO_LOOP_PUBLISH=1: the copy.
+struct LoopPub { float red[8]; int flags[4]; unsigned seq; unsigned pad[3]; };
+static_assert(sizeof(LoopPub) == 64, "LoopPub layout");
+__global__ void __launch_bounds__(64) k_publish_loop(const DevScalars *scal, LoopPub *pub, unsigned seq) {
+    const int t = threadIdx.x;
+    if (t < 8) __hip_atomic_store(&pub->red[t], scal->red[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (t < 12) __hip_atomic_store(&pub->flags[t - 8], scal->flags[t - 8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&pub->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// brings scal->red[0..8) and scal->flags[0..4) of the stream's current end into h->scal_h
+static int loop_readback(SphHandle *h) {
+    State &s = h->st;
+    static const bool no_publish = getenv("SPH_NO_LOOP_PUBLISH") != nullptr;
+    if (!no_publish && h->loop_pub) {
+        const unsigned want = ++h->loop_seq;
+        volatile LoopPub *pub = h->loop_pub;
+        hipLaunchKernelGGL(k_publish_loop, dim3(1), dim3(64), 0, s.stream, s.scal, h->loop_pub, want);
+        bool got = false;
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) == want) { got = true; break; }
+            if ((spins & 255u) == 255u) {
+                const hipError_t q = hipStreamQuery(s.stream);
+                if (q != hipErrorNotReady) {   // idle (the number should be there: one more look) or broken
+                    if (q == hipSuccess && __atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) == want) got = true;
+                    break;
+                }
+                if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();   // "not yet" is no failure (check_async)
+            }
+            __builtin_ia32_pause();
+        }
+        if (got) {
+            for (int k = 0; k < 8; ++k) h->scal_h->red[k] = pub->red[k];
+            for (int k = 0; k < 4; ++k) h->scal_h->flags[k] = pub->flags[k];
+            return SPH_OK;
+        }
+    }
+    hipError_t e = hipMemcpyAsync(h->scal_h->red, s.scal->red, 8 * sizeof(float) + 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+    if (e != hipSuccess) return fail(h, SPH_ERR_HIP, "solver loop read-back failed: %s", hipGetErrorString(e));
+    return SPH_OK;
+}
+
 // particle_num the reference's residual means divide by (DFSPH.py:212, :293): the whole scene's, not this slab's
 static long long dfsph_particle_num(SphHandle *h) { return h->st.slab_active ? h->comm_n_global : (long long)h->n; }
 
@@ -46,9 +95,8 @@ static int device_loop(SphHandle *h, int max_itr, int slot, int kind, float deno
         for (int k = 0; k < nb; ++k) body();
         if (batch_end) batch_end(s);
         n_launched += nb;
-        hipError_t e = hipMemcpyAsync(h->scal_h->red, s.scal->red, 8 * sizeof(float) + 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
-        if (e != hipSuccess) { rc = fail(h, SPH_ERR_HIP, "solver loop read-back failed: %s", hipGetErrorString(e)); break; }
+        rc = loop_readback(h);
+        if (rc) break;
         if (h->scal_h->flags[0]) break;
         if (predicted) { batch = 2; predicted = false; }
         else if (batch < 8) batch *= 2;
