@@ -48,6 +48,7 @@ struct SphHandle {
     int loop_hint[4] = {0, 0, 0, 0};   // iterations the last solve of each device-controlled loop took (sph_steps.hpp device_loop), by reduction slot
     struct LoopPub *loop_pub = nullptr;   // pinned: residual + flags of a solver loop's batch, published by a kernel (sph_steps.hpp k_publish_loop)
     unsigned loop_seq = 0;
+    bool loop_flags_clean = false;   // scal->flags[0..1] are zero (the publishing kernel of a stopped loop reset them): device_loop needs no memset
     int dev_cus = 256;           // compute units of the device (sizing of grids that should be resident at once)
     bool pose_given = false;     // sph_set_rigid_pose was called: pose_h holds library-frame vectors of the CURRENT axis order
     bool rigid_volume_done = false;

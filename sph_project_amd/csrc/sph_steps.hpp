@@ -21,13 +21,19 @@ static int implicit_viscosity_non_pressure(SphHandle *h);
 // looks at hipStreamQuery every few microseconds and falls back to the copy when the stream is idle or broken.  SPH_NO_LOOP_PUBLISH=1: the copy.
 struct LoopPub { float red[8]; int flags[4]; unsigned seq; unsigned pad[3]; };
 static_assert(sizeof(LoopPub) == 64, "LoopPub layout");
-__global__ void __launch_bounds__(64) k_publish_loop(const DevScalars *scal, LoopPub *pub, unsigned seq) {
+__global__ void __launch_bounds__(64) k_publish_loop(DevScalars *scal, LoopPub *pub, unsigned seq) {
     const int t = threadIdx.x;
+    const int stop = scal->flags[0];
     if (t < 8) __hip_atomic_store(&pub->red[t], scal->red[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else if (t < 12) __hip_atomic_store(&pub->flags[t - 8], scal->flags[t - 8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __threadfence_system();
     __syncthreads();
-    if (t == 0) __hip_atomic_store(&pub->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0) {
+        // a loop that has stopped is over (the host launches nothing more for it): its flags are reset here, so that the next loop needs
+        // no memset in front of it (a fill kernel + a launch boundary per solve)
+        if (stop) { scal->flags[0] = 0; scal->flags[1] = 0; }
+        __hip_atomic_store(&pub->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 // brings scal->red[0..8) and scal->flags[0..4) of the stream's current end into h->scal_h
 static int loop_readback(SphHandle *h) {
@@ -53,8 +59,10 @@ static int loop_readback(SphHandle *h) {
         if (got) {
             for (int k = 0; k < 8; ++k) h->scal_h->red[k] = pub->red[k];
             for (int k = 0; k < 4; ++k) h->scal_h->flags[k] = pub->flags[k];
+            h->loop_flags_clean = h->scal_h->flags[0] != 0;   // (the kernel reset them behind the copy)
             return SPH_OK;
         }
+        h->loop_flags_clean = false;   // (whether the kernel ran is not known here)
     }
     hipError_t e = hipMemcpyAsync(h->scal_h->red, s.scal->red, 8 * sizeof(float) + 4 * sizeof(int), hipMemcpyDeviceToHost, s.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
@@ -81,7 +89,8 @@ template <class F>
 static int device_loop(SphHandle *h, int max_itr, int slot, int kind, float denom, double thr, F body, int *executed,
                        int *launched, float *last_val, void (*batch_end)(State &) = nullptr) {
     State &s = h->st;
-    HIPCHK(h, hipMemsetAsync(&s.scal->flags[0], 0, 2 * sizeof(int), s.stream));
+    if (!h->loop_flags_clean) HIPCHK(h, hipMemsetAsync(&s.scal->flags[0], 0, 2 * sizeof(int), s.stream));
+    h->loop_flags_clean = false;
     s.loop_flag = &s.scal->flags[0];
     s.loop_slot = slot; s.loop_kind = kind; s.loop_denom = denom; s.loop_thr = thr;
     static const bool no_hint = getenv("SPH_NO_LOOP_HINT") != nullptr;
