@@ -684,6 +684,14 @@ static int read_scalars(SphHandle *h) {
     return SPH_OK;
 }
 
+// sph_step / sph_step_end are synchronous on return -- but the statistics (97 KB of striped counters) are only brought over when
+// somebody asks for them (sph_get_stats -> read_scalars): until round 6 every synchronous step copied them
+static int finish_sync(SphHandle *h) {
+    { int rc = slab_settle_if_needed(h); if (rc) return rc; }
+    HIPCHK(h, hipStreamSynchronize(h->st.stream));
+    return SPH_OK;
+}
+
 extern "C" int sph_prepare(SphHandle *h) {
     if (!h) return SPH_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
@@ -803,7 +811,7 @@ extern "C" int sph_step_end(SphHandle *h) {
     refresh_counts(h);
     int rc = step_second_half(h, true); if (rc) return rc;
     rc = check_async(h); if (rc) return rc;
-    return read_scalars(h);
+    return finish_sync(h);
 }
 
 extern "C" int sph_step_async(SphHandle *h, int nsteps) {
@@ -837,7 +845,7 @@ extern "C" int sph_step(SphHandle *h, int nsteps) {
     refresh_counts(h);
     for (int k = 0; k < nsteps; ++k) { int rc = step_once(h, true); if (rc) return rc; }
     int rc = check_async(h); if (rc) return rc;
-    return read_scalars(h);
+    return finish_sync(h);
 }
 
 extern "C" int sph_run_phase(SphHandle *h, int phase) {
