@@ -47,7 +47,7 @@ struct SphHandle {
     bool pose_dirty = false;
     int loop_hint[4] = {0, 0, 0, 0};   // iterations the last solve of each device-controlled loop took (sph_steps.hpp device_loop), by reduction slot
     struct LoopPub *loop_pub = nullptr;   // pinned: residual + flags of a solver loop's batch, published by a kernel (sph_steps.hpp k_publish_loop)
-    unsigned loop_seq = 0;
+    unsigned loop_seq = 0, stats_seq = 0;
     bool loop_flags_clean = false;   // scal->flags[0..1] are zero (the publishing kernel of a stopped loop reset them): device_loop needs no memset
     int dev_cus = 256;           // compute units of the device (sizing of grids that should be resident at once)
     bool pose_given = false;     // sph_set_rigid_pose was called: pose_h holds library-frame vectors of the CURRENT axis order
@@ -359,7 +359,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.cg_parity = 0;
     CHK_CREATE(dalloc(h, &s.scal, 1)); CHK_CREATE(dalloc(h, &s.pose, 1));
     HIP_CREATE(hipHostMalloc((void **)&h->scal_h, sizeof(DevScalars), hipHostMallocDefault));
-    { void *lp = nullptr; HIP_CREATE(hipHostMalloc(&lp, 64, hipHostMallocDefault)); memset(lp, 0, 64); h->loop_pub = (struct LoopPub *)lp; }
+    { void *lp = nullptr; HIP_CREATE(hipHostMalloc(&lp, 128, hipHostMallocDefault)); memset(lp, 0, 128); h->loop_pub = (struct LoopPub *)lp; }   // + StatsPub behind it
     { int *lc = nullptr; HIP_CREATE(hipHostMalloc((void **)&lc, 64, hipHostMallocDefault)); *lc = 0; s.list_count_pinned = lc; }
     HIP_CREATE(hipEventCreateWithFlags(&s.list_count_event, hipEventDisableTiming));
     s.list_count_known = -1;
@@ -670,6 +670,19 @@ static void step_begin(SphHandle *h) {
 
 static int read_scalars(SphHandle *h) {
     { int rc = slab_settle_if_needed(h); if (rc) return rc; }
+    static const bool no_publish = getenv("SPH_NO_LOOP_PUBLISH") != nullptr;
+    if (!no_publish && h->loop_pub) {   // the sums of the last step's bank, added up on the device and published into pinned memory (sph_steps.hpp)
+        StatsPub *pub = (StatsPub *)((char *)h->loop_pub + 64);
+        const unsigned want = ++h->stats_seq;
+        const int bank_d = h->steps > 0 ? (int)((h->steps - 1) & 1) : 0;
+        hipLaunchKernelGGL(k_publish_stats, dim3(1), dim3(256), 0, h->st.stream, h->st.scal, bank_d, pub, want);
+        if (spin_for(h->st, &pub->seq, want)) {
+            h->last.pair_interactions = (int64_t)pub->pairs;
+            h->last.pair_evaluations = (int64_t)pub->evals;
+            h->last.lds_fallback_blocks = (int64_t)pub->fallback;
+            return SPH_OK;
+        }
+    }
     HIPCHK(h, hipMemcpyAsync(h->scal_h, h->st.scal, sizeof(DevScalars), hipMemcpyDeviceToHost, h->st.stream));
     HIPCHK(h, hipStreamSynchronize(h->st.stream));
     unsigned long long pairs = 0, evals = 0, fb = 0;
@@ -684,9 +697,24 @@ static int read_scalars(SphHandle *h) {
     return SPH_OK;
 }
 
-// sph_step / sph_step_end are synchronous on return -- but the statistics (97 KB of striped counters) are only brought over when
-// somebody asks for them (sph_get_stats -> read_scalars): until round 6 every synchronous step copied them
+// Waiting for the stream and reading small results back (round 6; profiles/r06_sync_latency.txt).  What is slow on this runtime is not
+// hipStreamSynchronize but a D2H copy issued on an IDLE stream: the 97 KB statistics copy of sph_get_stats cost ~0.3 ms per call once the same
+// copy at the end of sph_step (issued while the step's kernels were still running, which hid its start-up) was taken away -- a synchronous C5
+// step went 1.39 -> 1.75 ms.  The statistics are therefore added up on the device and published into pinned host memory like the solver
+// loops' residuals (read_scalars -> k_publish_stats; sph_steps.hpp), no copy at all; sph_step / sph_step_end just wait.
+// sph_synchronize -- the fence a caller times asynchronous steps with -- waits by the same publish + spin (ends ~30 us sooner than the
+// interrupt-driven hipStreamSynchronize: C2 in the driver's 3 x 20-step configuration -0.5 %); SPH_SLOW_SYNC=1: plain hipStreamSynchronize.
+static int fast_stream_sync(SphHandle *h) {
+    static const bool slow = getenv("SPH_SLOW_SYNC") != nullptr;
+    if (!slow) return loop_readback(h);          // (returns only when the stream has reached the kernel it appended)
+    HIPCHK(h, hipStreamSynchronize(h->st.stream));
+    return SPH_OK;
+}
+// sph_step / sph_step_end are synchronous on return; the statistics are brought over when somebody asks (sph_get_stats)
+static int read_scalars(SphHandle *h);
 static int finish_sync(SphHandle *h) {
+    static const bool copy_stats = getenv("SPH_STEP_COPIES_STATS") != nullptr;   // A/B: as until round 6
+    if (copy_stats) return read_scalars(h);
     { int rc = slab_settle_if_needed(h); if (rc) return rc; }
     HIPCHK(h, hipStreamSynchronize(h->st.stream));
     return SPH_OK;
@@ -834,8 +862,7 @@ extern "C" int sph_synchronize(SphHandle *h) {
     if (!h) return SPH_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->n_exact) return slab_settle(h);   // drains the stream (bounded) and brings the counts of the asynchronous steps back
-    HIPCHK(h, hipStreamSynchronize(h->st.stream));
-    return SPH_OK;
+    return fast_stream_sync(h);
 }
 
 extern "C" int sph_step(SphHandle *h, int nsteps) {

@@ -35,6 +35,39 @@ __global__ void __launch_bounds__(64) k_publish_loop(DevScalars *scal, LoopPub *
         __hip_atomic_store(&pub->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// host side of a publish: spin until the kernel's number shows up in pinned memory; false: the stream went idle or broke without it
+static bool spin_for(State &s, const volatile unsigned *seq, unsigned want) {
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) return true;
+        if ((spins & 255u) == 255u) {
+            const hipError_t q = hipStreamQuery(s.stream);
+            if (q != hipErrorNotReady) return q == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) == want;   // idle: one more look; or broken
+            if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();   // "not yet" is no failure (check_async)
+        }
+        __builtin_ia32_pause();
+    }
+}
+// The pair statistics of one bank (3 x SPH_STAT_SLOTS striped 64-bit counters) added up on the device and published the same way: a D2H copy of
+// the 97 KB DevScalars issued on an IDLE stream costs ~0.3 ms on this runtime (profiles/r06_sync_latency.txt)
+struct StatsPub { unsigned long long pairs, evals, fallback; unsigned seq; unsigned pad[9]; };
+static_assert(sizeof(StatsPub) == 64, "StatsPub layout");
+__global__ void __launch_bounds__(256) k_publish_stats(const DevScalars *scal, int bank, StatsPub *pub, unsigned seq) {
+    __shared__ unsigned long long s_w[3][4];
+    unsigned long long a = 0, b = 0, c = 0;
+    for (int k = threadIdx.x; k < SPH_STAT_SLOTS; k += 256) { a += scal->pairs[bank][k]; b += scal->evals[bank][k]; c += scal->fallback[bank][k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c += __shfl_down(c, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s_w[0][threadIdx.x >> 6] = a; s_w[1][threadIdx.x >> 6] = b; s_w[2][threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&pub->pairs, s_w[0][0] + s_w[0][1] + s_w[0][2] + s_w[0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&pub->evals, s_w[1][0] + s_w[1][1] + s_w[1][2] + s_w[1][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&pub->fallback, s_w[2][0] + s_w[2][1] + s_w[2][2] + s_w[2][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(&pub->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // brings scal->red[0..8) and scal->flags[0..4) of the stream's current end into h->scal_h
 static int loop_readback(SphHandle *h) {
     State &s = h->st;
@@ -43,23 +76,12 @@ static int loop_readback(SphHandle *h) {
         const unsigned want = ++h->loop_seq;
         volatile LoopPub *pub = h->loop_pub;
         hipLaunchKernelGGL(k_publish_loop, dim3(1), dim3(64), 0, s.stream, s.scal, h->loop_pub, want);
-        bool got = false;
-        for (unsigned spins = 0;; ++spins) {
-            if (__atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) == want) { got = true; break; }
-            if ((spins & 255u) == 255u) {
-                const hipError_t q = hipStreamQuery(s.stream);
-                if (q != hipErrorNotReady) {   // idle (the number should be there: one more look) or broken
-                    if (q == hipSuccess && __atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) == want) got = true;
-                    break;
-                }
-                if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();   // "not yet" is no failure (check_async)
-            }
-            __builtin_ia32_pause();
-        }
+        const bool got = spin_for(s, &pub->seq, want);
         if (got) {
             for (int k = 0; k < 8; ++k) h->scal_h->red[k] = pub->red[k];
             for (int k = 0; k < 4; ++k) h->scal_h->flags[k] = pub->flags[k];
-            h->loop_flags_clean = h->scal_h->flags[0] != 0;   // (the kernel reset them behind the copy)
+            if (h->scal_h->flags[0] != 0) h->loop_flags_clean = true;   // (the kernel reset them behind the copy; else: as they were -- this is
+                                                                        //  also the plain wait of sph_synchronize / sph_step, outside any loop)
             return SPH_OK;
         }
         h->loop_flags_clean = false;   // (whether the kernel ran is not known here)
