@@ -1,6 +1,7 @@
 // sph_steps.hpp -- per-method step orchestration (included by sph_api.hip).
 // Order of operations follows WCSPH.py:27, DFSPH.py:298, PCISPH.py:165 and base_solver.py:692.
 #pragma once
+#include <sched.h>
 
 // reads scal->red[slot] (one small D2H copy + stream sync: the reference's python loops read one
 // scalar per iteration too, DFSPH.py:150, :236; PCISPH.py:122)
@@ -43,6 +44,7 @@ static bool spin_for(State &s, const volatile unsigned *seq, unsigned want) {
             const hipError_t q = hipStreamQuery(s.stream);
             if (q != hipErrorNotReady) return q == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) == want;   // idle: one more look; or broken
             if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();   // "not yet" is no failure (check_async)
+            if (spins > 4096u) sched_yield();   // a long wait (many steps queued): let whoever else wants this core have it; returns at once otherwise
         }
         __builtin_ia32_pause();
     }
