@@ -17,7 +17,9 @@ SPH_COMM_TRANSPORT=shm+ipc / shm lets several ranks share one GPU (test rig).
 
 Timing: W untimed warm-up steps, then 3 repetitions of exactly K steps, each enqueued on the library's HIP stream
 between two (device synchronise + barrier) fences, max over ranks; `ms_per_step` is the MEDIAN repetition
-(`repeat_ms_per_step` lists all three).  `value` = fluid particles advanced per second by the whole job with all state
+(`repeat_ms_per_step` lists all three; from rest the lattice relaxes, so later repetitions are 1-2 % faster).  The
+device synchronise is sph_synchronize: a one-wave kernel behind the queued steps publishes a number into pinned host
+memory and the host spins on it (it returns ~30 us sooner than hipStreamSynchronize's interrupt; SPH_SLOW_SYNC=1).  `value` = fluid particles advanced per second by the whole job with all state
 resident in HBM (scene upload outside the region).  The same scene is then advanced to step 2500 and timed again
 (`in_motion`): the rest lattice holds 29 neighbours per particle, the collapsing column ~39.
 Roofline leg: the dominant kernel (picked by a short all-kernel HIP-event pre-pass) is timed with HIP events on the
