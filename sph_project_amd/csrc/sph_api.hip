@@ -318,7 +318,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.scan_blocks = (int)((G + SPH_NGRAVE + 2047) / 2048);
     if (s.scan_blocks < SPH_STAT_SLOTS / 256) s.scan_blocks = SPH_STAT_SLOTS / 256;   // k_scan_final also clears the statistics slots
     CHK_CREATE(dalloc(h, &s.scan_partial, 2 * ((size_t)s.scan_blocks + 1) * 8));   // two banks of tile sums, SCAN_PARTIAL_STRIDE ints apart (State::scan_bank)
-    s.scan_bank = 0; s.tile_sums_ready = 0; s.skip_residual = 0;
+    s.scan_bank = 0; s.tile_sums_ready = 0; s.skip_residual = 0; s.hist_taken = 0; s.state_error = 0;
     s.cell_count_clean = 1;
     CHK_CREATE(dalloc(h, &s.rho_raw, cap)); CHK_CREATE(dalloc(h, &s.prs, cap)); CHK_CREATE(dalloc(h, &s.ptm, cap));
     CHK_CREATE(dalloc(h, &s.acc, cap));
@@ -618,6 +618,7 @@ extern "C" int sph_measure_copy_rate(SphHandle *h, size_t bytes, int reps, doubl
 
 // ---------------------------------------------------------------------------------- phases
 static int check_async(SphHandle *h) {
+    if (h->st.state_error) { const int se = h->st.state_error; h->st.state_error = 0; return fail(h, SPH_ERR_INVALID, "internal state error %d (a sort was scanned without a histogram of its own)", se); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, SPH_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return SPH_OK;
@@ -818,7 +819,7 @@ static int step_once(SphHandle *h, bool allow_readback) {
     if (!rc) rc = step_second_half(h, allow_readback);
     // a failed step may leave a hash made for a sort that will not come (NextHash: the WCSPH force pass for the next step's sort, the
     // DFSPH position update for this step's): the next sort, whoever asks for it, must hash for itself on a clean histogram
-    if (rc && h->st.prehashed) { h->st.prehashed = 0; h->st.cell_count_clean = 0; }
+    if (rc && h->st.prehashed) { h->st.prehashed = 0; h->st.cell_count_clean = 0; h->st.hist_taken = 0; }
     return rc;
 }
 

@@ -189,6 +189,8 @@ struct State {
     int skip_residual;   // fixed-iteration solves (no stop test, nobody reads the residual): the walks leave their partial sums, k_reduce_partials is not launched
     int tile_sums_ready; // ... and they did (else l_scan launches k_scan_reduce first: SPH_NO_SCAN_FOLD)
     int cell_count_clean;              // cell_count is all zero (the scan clears it behind itself)
+    int hist_taken;                    // the histogram of the coming sort has been taken (by k_hash_count, a NextHash epilogue, the slab kernels) and not yet scanned
+    int state_error;                   // sticky: a launcher met a state it must never see (l_scan without a histogram: ADVICE r05); reported by check_async
     // per-step scratch
     float *rho_raw, *prs, *ptm;
     float4 *acc;

@@ -20,6 +20,7 @@ static void l_halo_classify_pack(State &s, int n) {
         s.cell_count_clean = 0;
         hash = HaloHash{s.cellid, s.rank, s.cell_count, tile_sum_bank(s)};
         s.tile_sums_ready = hash.tile_sum != nullptr;   // (k_halo_unpack2 adds the arrivals' share)
+        s.hist_taken = 1;
         const unsigned seq = ++s.push.rec_seq;
         for (int side = 0; side < 2; ++side)
             if (s.push.peer[side]) dst[side] = (float4 *)inbox_rec(s, s.push.peer[side], 1 - side, seq);   // I am the neighbour's OTHER side

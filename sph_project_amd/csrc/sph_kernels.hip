@@ -45,12 +45,13 @@ void l_hash_count(State &s) {
         s.prehashed = 0;
         s.cell_count_clean = 0;
         s.n_prehashed_sorts++;
-        return;   // (tile_sums_ready was set by l_wcsph_forces)
+        return;   // (tile_sums_ready and hist_taken were set by the pass that hashed)
     }
     if (!s.cell_count_clean) clear_histogram(s);
     s.cell_count_clean = 0;
     int *ts = tile_sum_bank(s);
     s.tile_sums_ready = ts != nullptr;
+    s.hist_taken = 1;
     if (n == 0) return;
     s.n_hash_launches++;
     hipLaunchKernelGGL(k_hash_count, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.cellid,
@@ -58,6 +59,10 @@ void l_hash_count(State &s) {
 }
 
 void l_scan(State &s) {
+    //  the scan must follow a histogram of THIS sort: taken by l_hash_count, by the pass that hashed ahead (NextHash), or by
+    // the slab kernels.  Anything else is a bug in the step orchestration; the sort would file every particle into cell 0.
+    if (!s.hist_taken) s.state_error |= 1;
+    s.hist_taken = 0;
     const int G = s.c.G + (s.slab_active ? SPH_NGRAVE : 0);   // + graveyard cells
     int nb = cdiv(G, SCAN_TILE);                      // <= s.scan_blocks (sized for the global grid)
     if (nb < SPH_STAT_SLOTS / SCAN_TPB) nb = SPH_STAT_SLOTS / SCAN_TPB;   // k_scan_final also clears the statistics slots
@@ -311,7 +316,7 @@ void l_wcsph_forces(State &s) {
         launch_pass(s, p, 2);
     }
     if (s.presend.on) { s.presend.on = 0; s.preclassified = 1; }
-    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; s.tile_sums_ready = nh.tile_sum != nullptr; }
+    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; s.tile_sums_ready = nh.tile_sum != nullptr; s.hist_taken = 1; }
     s.velm.flip();
     s.posv.flip();
     s.masks_valid = 0;  // positions moved

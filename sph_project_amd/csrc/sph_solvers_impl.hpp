@@ -57,7 +57,7 @@ static void l_advect_boundary(State &s) {
     s.masks_valid = 0;  // positions move
     hipLaunchKernelGGL(k_advect_boundary, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(),
                        s.velm.cur(), s.meta.cur(), s.pose, s.c.all_fluid, nh);
-    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; s.tile_sums_ready = nh.tile_sum != nullptr; }
+    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; s.tile_sums_ready = nh.tile_sum != nullptr; s.hist_taken = 1; }
 }
 
 static void l_reduce_sum(State &s, int slot, int nblocks) {
