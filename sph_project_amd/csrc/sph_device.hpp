@@ -925,7 +925,7 @@ k_compact_blocks(const int *__restrict__ flag, int nb, int *__restrict__ list, i
 #define SPH_HEAVY_SB 3   // staging slots per batch of the wide records (32-36 B per slot; all 5 at once spill at 128 VGPRs)
 #endif
 #ifndef SPH_MEDIUM_SB
-#define SPH_MEDIUM_SB 2   // staging slots per batch of a medium functor
+#define SPH_MEDIUM_SB 3   // staging slots per batch of a medium functor (round 6: 3 -- no spills any more; C3 -0.5 % from rest, -1.2 % in motion: profiles/r06_maskpipe_ab.txt)
 #endif
 template <class P> constexpr int pass_slot_bytes() {
     return 16 + (P::HAS_B ? (int)sizeof(typename P::BT) : 0) + (PassC<P>::value ? (int)sizeof(typename PassC<P>::type) : 0);

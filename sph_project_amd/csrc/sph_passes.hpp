@@ -378,7 +378,7 @@ struct WcsphForcePass {
     static constexpr bool COUNT_PAIRS = CNT;     // false: booked by the density pass that stored the masks this pass walks (DensityPass::stat_pairs)
     static constexpr int MAX_WAVES = CNT ? (SPH_FAST ? 4 : 3) : 8;   // (the rarely used counting instantiation takes its class's register budget, never less)
 #ifndef SPH_FORCE_MASK_PIPE
-#define SPH_FORCE_MASK_PIPE 0
+#define SPH_FORCE_MASK_PIPE 1   // round 6: 1 (C2 -1.2 %, in motion -1.0 %: profiles/r06_maskpipe_ab.txt; it spilled when it was last tried, it does not any more)
 #endif
     static constexpr bool MASK_PIPELINE = SPH_FORCE_MASK_PIPE && AF;   // the pair loop holds 111-124 of 128 VGPRs: batches of 3 OR the pipeline
     static constexpr int PAIR_WEIGHT = 3;  // surface tension (:210) + viscosity (:232) + pressure (:136)
