@@ -676,6 +676,18 @@ __device__ __forceinline__ void process_chunk(const Consts &c, const P &p, typen
     }
 }
 
+#ifndef SPH_P2_PAIR2_MEDIUM
+#define SPH_P2_PAIR2_MEDIUM 1
+#endif
+template <class P> constexpr bool pass_is_medium();
+template <class P> constexpr bool pass_pair2() {
+#ifdef SPH_P2_PAIR2
+    return true;
+#else
+    return SPH_P2_PAIR2_MEDIUM && pass_is_medium<P>();
+#endif
+}
+
 // pair() receives the neighbour's sorted index j only where the functor needs it (rigid-body wrench):
 // P::USES_J = false lets the merged loop drop the bookkeeping.
 template <class P, class = void> struct PassUsesJ { static constexpr bool value = true; };
@@ -702,9 +714,11 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
     unsigned ca = a0;
     int cq = q0;
     const unsigned tile = lds_addr(sXY);
-#ifdef SPH_P2_PAIR2
-    // A/B variant (tools/experiments): two accepted neighbours of a run per trip -- all their LDS reads issued before the first
-    // pair is evaluated, half the loop control.  Order of accumulation unchanged (first, then second).
+    if constexpr (pass_pair2<P>()) {
+    // Two accepted neighbours of a run per trip -- all their LDS reads issued before the first pair is evaluated, half the loop control;
+    // order of accumulation unchanged (first, then second).  Pays where runs hold several accepted neighbours and the pair is light: the
+    // 20-28-byte solver walks (pass_is_medium) in motion, C3 -2.7 % at step 1000, +-0 from rest; the WCSPH force pass loses 1.2 % from rest
+    // with it (profiles/r06_pair2_ab.txt).  -DSPH_P2_PAIR2: every pass (A/B); -DSPH_P2_PAIR2_MEDIUM=0: none.
     while (cur) {
         const int t = (sizeof(M) == 8 ? __ffsll((long long)cur) : __ffs((int)cur)) - 1;
         cur &= cur - 1;
@@ -732,7 +746,7 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
         }
         if (cur == 0) { cur = m1; ca = a1; m1 = m2; a1 = a2; m2 = 0; if (UJ) { cq = q1; q1 = q2; } }
     }
-#else
+    } else {
     while (cur) {
         const int t = (sizeof(M) == 8 ? __ffsll((long long)cur) : __ffs((int)cur)) - 1;
         cur &= cur - 1;
@@ -750,7 +764,7 @@ __device__ __forceinline__ void merged_phase2(const Consts &c, const P &p, typen
         pass_pair(p, c, own, dx, dy, dz, r2, make_float4(xy.x, xy.y, zw.x, zw.y), bj, cj, j);
         if (cur == 0) { cur = m1; ca = a1; m1 = m2; a1 = a2; m2 = 0; if (UJ) { cq = q1; q1 = q2; } }
     }
-#endif
+    }
 }
 
 // Per-workgroup data prepared once per sort (k_block_prep), read by every neighbour pass of the sort epoch:
