@@ -684,6 +684,9 @@ template <class P> constexpr bool pass_pair2() {
 #ifdef SPH_P2_PAIR2
     return true;
 #else
+#ifdef SPH_P2_PAIR2_LIGHT
+    if (!P::HAS_B) return true;
+#endif
     return SPH_P2_PAIR2_MEDIUM && pass_is_medium<P>();
 #endif
 }
