@@ -48,6 +48,31 @@ def build_oracle(cfg_dict, jitter=0.0, seed=0, fixed_iterations=0):
     return sim
 
 
+def oracle_from_state(cfg_dict, x, v, ids, fixed_iterations=0):
+    """An oracle holding exactly the given particles of a ONE-fluid-block scene, in the given order (= the product's current order:
+    the stable counting sorts of both sides then keep them aligned), persistent ids in the colour word like build_oracle.  For
+    comparisons that start from a state the PRODUCT has reached (a collapsed column at step 2500), which the oracle could only reach
+    by itself in hours.  The density a particle is ADDED with is the block's rest density -- the reference derives the particle's MASS
+    from it (base_container.py:404-438) and recomputes the current density every step; material / is_dynamic as the block's
+    (base_solver.py:139 / :555 look at is_dynamic of FLUID particles too)."""
+    cfg, geo, batches = scene_particles(cfg_dict)
+    assert len(batches) == 1 and batches[0]["material"][0] == 1
+    b = batches[0]
+    sol = scene.derive_solver_constants(cfg)
+    n = len(ids)
+    sim = oracle_ref.RefSim(scene.params_dict(geo, sol, cfg.get_cfg("simulationMethod"), n, fixed_iterations=fixed_iterations))
+    sim._next_id = n
+    sim._pending = []
+    sim._time = 0.0
+    sim._dt = float(np.float32(sol.dt))
+    color = np.zeros((n, 3), np.int32)
+    color[:, 0] = ids
+    sim.set_object(b["object_id"], int(b["material"][0]), 0)
+    sim.add_particles(b["object_id"], x, v, np.full(n, b["density"][0], np.float32), np.zeros(n, np.float32),
+                      np.full(n, b["material"][0], np.int32), np.full(n, b["is_dynamic"][0], np.int32), color)
+    return sim
+
+
 def oracle_step(sim, n=1):
     """solver.step() of the reference with its host part: _step() inserts the objects that are due in the middle of the
     step (WCSPH.py:41, DFSPH.py:307, PCISPH.py:181), then total_time advances (base_solver.py:694)."""

@@ -223,6 +223,38 @@ def test_c3_full_size_dfsph(gpu):
     np.testing.assert_allclose(rho, rho_r, rtol=5e-5)
 
 
+def test_c3_full_size_dfsph_in_motion(gpu, from_step=1000):
+    """BASELINE configs[2] in the state a DFSPH user spends a run in: the 1.23 M column collapsed (step 1000 of bench.py --config c3,
+    2 + 2 fixed iterations; from rest the solvers have nothing to correct and the walks see the lattice's 29 neighbours).  The oracle is
+    seeded with the product's positions / velocities at that step, in the product's order (H.oracle_from_state; its prepare() recomputes
+    the density and alpha the product's last step_end left, DFSPH.py:321), both advance 3 steps with 2 + 2 iterations."""
+    cfg = P.c2_scene("dfsph")
+    container, solver = H.build_product(cfg, fast_math=1, fixed_iterations=2)
+    solver.prepare()
+    solver.advance(from_step)
+    e = container.engine
+    ids0, x0, v0 = (e.download(f) for f in (L.F_PARTICLE_ID, L.F_POSITION, L.F_VELOCITY))
+    n = len(ids0)
+    assert np.array_equal(np.sort(ids0), np.arange(n)) and np.isfinite(x0).all() and np.isfinite(v0).all()
+    ref = H.oracle_from_state(cfg, x0, v0, ids0, fixed_iterations=2)
+    ref.prepare()
+    solver.advance(3)
+    ref.step(3)
+    ids, oid = e.download(L.F_PARTICLE_ID), H.oracle_ids(ref)
+    assert np.array_equal(np.sort(ids), np.arange(n))
+    x, xr = H.by_id(ids, e.download(L.F_POSITION)), H.by_id(oid, ref.field("particle_positions").copy())
+    d = H.drift(x, xr, container.dh)
+    rho, rho_r = H.by_id(ids, e.download(L.F_DENSITY)), H.by_id(oid, ref.field("particle_densities").copy())
+    st = solver.stats()
+    print("C3 in motion (steps %d..%d): drift max %.3e p99 %.3e, max relative density difference %.3e, pairs/step %d (oracle %+d), "
+          "slots in another order %d" % (from_step, from_step + 3, d.max(), np.percentile(d, 99), np.abs(rho / rho_r - 1).max(),
+                                         st["pair_interactions"], ref.last_pairs - st["pair_interactions"], int((ids != oid).sum())))
+    assert d.max() <= 1e-5
+    assert abs(st["pair_interactions"] - ref.last_pairs) <= 2e-6 * ref.last_pairs, (st["pair_interactions"], ref.last_pairs)
+    np.testing.assert_allclose(rho, rho_r, rtol=5e-5)
+    ref.close()
+
+
 def test_c4_full_size_wcsph_one_gpu(gpu):
     """BASELINE configs[3]'s scene (4,000,000 particles, WCSPH) on ONE GPU, 5 steps in one advance(5) -- the timed path, with the
     force pass hashing for the next sort (its 8-GPU sharding: tests/test_hip_slab.py, 8 ranks on one GPU; real devices: the driver's)."""
