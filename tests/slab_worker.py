@@ -33,6 +33,11 @@ def main():
     if jitter > 0:
         fl = mat == 1
         pos[fl] = H.perturb(pos[fl], jitter, seed)
+    # SPH_WORKER_STATE=<npz with x, v>: the scene's one fluid block is replaced by these particles (a state the undecomposed product reached
+    # by itself, e.g. the collapsed column of step 2500), global id = row of the arrays; slab membership and cuts from THEIR positions
+    state = np.load(os.environ["SPH_WORKER_STATE"]) if os.environ.get("SPH_WORKER_STATE") else None
+    if state is not None:
+        pos, mat = np.ascontiguousarray(state["x"], np.float32), np.ones(len(state["x"]), np.int32)
     nz = int(geo.grid_num[2])
     hist = np.bincount(slab.cell_layer(pos[:, 2], geo.dh, nz), minlength=nz)
     cuts = slab.plan_slabs(hist, nranks)
@@ -41,6 +46,15 @@ def main():
         extra["fixed_iterations"] = int(os.environ["SPH_FIXED_ITERATIONS"])
     container, solver = H.build_product(cfg, slab=dict(rank=rank, nranks=nranks, unique_id=uid, cuts=cuts),
                                         fast_math=int(os.environ.get("SPH_FAST", "0")), **extra)
+    if state is not None:
+        blk = container.fluid_blocks[0]
+        assert len(container.fluid_blocks) == 1 and not container.fluid_bodies and not container.rigid_bodies
+        container.fluid_blocks = []
+        container.fluid_bodies = [dict(objectId=blk["objectId"], entryTime=-1.0, voxelizedPoints=pos, particleNum=len(pos), velocity=[0.0, 0.0, 0.0],
+                                       density=blk["density"], color=blk["color"])]   # (the explicit-points form mesh bodies take: slab selection by these positions)
+        container.insert_object()
+        ids = np.concatenate(container._global_ids)
+        container.engine.upload(L.F_VELOCITY, np.ascontiguousarray(state["v"], np.float32)[ids])
     if jitter > 0:  # same perturbed lattice on every rank: overwrite the positions of the particles kept here
         container.insert_object()
         ids = np.concatenate(container._global_ids)

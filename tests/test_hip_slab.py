@@ -647,3 +647,51 @@ def test_c2_scene_sharded_over_8_ranks_matches_oracle(gpu, tmp_path, transport, 
     cfg["FluidBlocks"][0]["velocity"] = [0.0, -0.5, 1.5]
     moved = _eight_way(cfg, 5, tmp_path, 0.002, 12, exact_pairs=build != "fast", build=build)
     assert moved >= 500, moved
+
+
+@pytest.mark.parametrize("build", ["fast"])
+def test_c2_in_motion_state_sharded_over_8_ranks_matches_oracle(gpu, tmp_path, transport, build, from_step=2500):
+    """What `bench.py --gpus 8` runs through on its way to `in_motion`, checked: the 1.23 M scene in the state of step 2500 (collapsed column,
+    39 neighbours per particle, pile-ups along the floor and the z walls that every slab face cuts through) split over eight ranks.  The
+    undecomposed product produces the state, the ranks are seeded with it (tests/slab_worker.py SPH_WORKER_STATE: slab membership and cuts
+    from these positions), so is the oracle (H.oracle_from_state); 5 asynchronous steps over the push transport; by particle id against
+    the oracle."""
+    if transport != "shm+ipc":
+        pytest.skip("the production data plane; the mailbox rig is covered at small sizes")
+    from sph_project_amd import product as P
+    cfg = P.c2_scene()
+    container, solver = H.build_product(cfg, fast_math=1)
+    solver.prepare()
+    solver.advance(from_step)
+    e = container.engine
+    x0, v0 = e.download(L.F_POSITION), e.download(L.F_VELOCITY)
+    n = len(x0)
+    e.close()
+    tmp_path.mkdir(parents=True, exist_ok=True)
+    np.savez(tmp_path / "state.npz", x=x0, v=v0)
+    steps = 5
+    env = {"SPH_COMM_TIMEOUT_S": "120", "SPH_FAST": "1" if build == "fast" else "0", "SPH_WORKER_STATE": str(tmp_path / "state.npz")}
+    outs, logs = _run_ranks(cfg, 8, steps, tmp_path, advance=True, timeout=600, extra_env=env)
+    ref = H.oracle_from_state(cfg, x0, v0, np.arange(n, dtype=np.int32))
+    ref.prepare()
+    ref.step(steps)
+    oid = H.oracle_ids(ref)
+    x_ref, rho_ref = H.by_id(oid, ref.field("particle_positions").copy()), H.by_id(oid, ref.field("particle_densities").copy())
+    all_ids = np.concatenate([o["ids"] for o in outs])
+    assert len(all_ids) == n and len(np.unique(all_ids)) == n, "every particle owned by exactly one rank"
+    x, rho = np.empty_like(x_ref), np.empty_like(rho_ref)
+    for o in outs:
+        x[o["ids"]] = o["pos"]; rho[o["ids"]] = o["rho"]
+    _, geo, _b = H.scene_particles(cfg)
+    from sph_project_amd import slab
+    cuts = [int(v) for v in outs[0]["cuts"]]
+    nz = int(geo.grid_num[2])
+    moved = int((slab.owner_of(slab.cell_layer(x0[:, 2], geo.dh, nz), cuts) != slab.owner_of(slab.cell_layer(x[:, 2], geo.dh, nz), cuts)).sum())
+    d = H.drift(x, x_ref, geo.dh)
+    got, want = sum(int(o["pairs"]) for o in outs), int(ref.last_pairs)
+    print("8 ranks on one GPU from the state of step %d: cuts %s, owned %s, ghosts %s, changed owner %d, drift max %.3e, pairs %d vs oracle %d" % (
+        from_step, cuts, [len(o["ids"]) for o in outs], [int(o["n_ghost"]) for o in outs], moved, d.max(), got, want))
+    assert d.max() <= 1e-5
+    np.testing.assert_allclose(rho, rho_ref, rtol=2e-5)
+    _pairs_agree(got, want)
+    ref.close()
