@@ -199,6 +199,7 @@ static void fill_consts(SphHandle *h) {
     c.force_global = p.force_global;
     c.stat_bank = 0;
     c.run_grouping = 0;
+    { static const int xc = getenv("SPH_XCD_CHUNK") ? atoi(getenv("SPH_XCD_CHUNK")) : 0; c.xcd_chunk = xc > 0 ? xc : 0; }
     c.ghosts = 0;
 }
 

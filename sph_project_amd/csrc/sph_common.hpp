@@ -60,6 +60,7 @@ struct Consts {
     int   force_global;
     int   ghosts;           // slab sharding: ghost particles present (meta bit 11) even when all_fluid
     int   stat_bank;        // DevScalars bank the running step counts into (step parity)
+    int   xcd_chunk;        // tile order of the neighbour passes (sph_device.hpp xcd_remap): 0 one contiguous eighth per XCD, C > 0 chunks of C tiles dealt round-robin
     int   run_grouping;     // which candidate runs form a staging group of k_nbr_pass (sph_device.hpp run_of): 0 x offsets, 1 outer runs mixed
     // slab sharding, device-resident counts (sph_halo.hpp SlabDyn): when set, the particle count lives in device memory
     // (the halo exchange changes it without the host looking) and `n` above is only the launch bound the grid was sized for

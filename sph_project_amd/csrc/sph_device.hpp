@@ -172,10 +172,20 @@ template <class T> __device__ __forceinline__ T ldg_idx(const T *base, int j) {
 
 // XCD-aware, bijective workgroup remap: consecutive tiles share neighbour runs, so keep them on
 // one XCD's L2 (dispatch places workgroup b on XCD b % 8).
-__device__ __forceinline__ int xcd_remap(int b, int nb) {
+// chunk = 0: every XCD walks ONE contiguous eighth of the tiles (most reuse of candidate runs in its L2; no balance between XCDs: the
+// hardware deals workgroups round-robin, so an XCD whose eighth is cheap idles).  chunk = C > 0: the tiles are dealt in chunks of C
+// consecutive tiles, XCD k takes chunks k, k + 8, ... -- neighbouring tiles still share an L2, and every XCD sees every part of the scene
+// (Consts::xcd_chunk).  Bijective on [0, nb): the ragged end (fewer than 8 C tiles) keeps the dispatch order.
+__device__ __forceinline__ int xcd_remap(int b, int nb, int chunk = 0) {
 #ifdef SPH_NO_XCD_REMAP
     return b;
 #endif
+    if (chunk > 0) {
+        const int full = nb / (8 * chunk) * (8 * chunk);
+        if (b >= full) return b;
+        const int j = b >> 3, m = j / chunk;
+        return (m * 8 + (b & 7)) * chunk + (j - m * chunk);
+    }
     int xcd = b & 7, q = nb >> 3, r = nb & 7;
     int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (b >> 3);
@@ -1084,7 +1094,7 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
 
     const int tid = threadIdx.x;
     NBR_STAMP(0);
-    const int b = blk_list ? b_listed : xcd_remap(blockIdx.x, nblocks);
+    const int b = blk_list ? b_listed : xcd_remap(blockIdx.x, nblocks, c.xcd_chunk);
     const int i0 = b * BLOCK;
     // Second round trip, requested BEFORE a functor's prologue (whose barriers keep later loads behind its own: the CG walk's prologue adds
     // up two arrays of partial sums first): the lane permutation, the header, the skip flag of a slab's interior launch.
