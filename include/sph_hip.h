@@ -134,6 +134,9 @@ typedef struct {
     int64_t prehashed_sorts;     /* sorts since create whose init_grid was done by the force pass of the step before (inside one
                                     sph_step_async(n) call of an unsharded all-fluid WCSPH scene): hash_launches + prehashed_sorts
                                     = sorts.  Lets a test assert which path a timed region really took. */
+    int64_t list_sorts;          /* deterministic sorts since create that ranked the particles from per-cell run lists filed by whoever
+                                    hashed them (reorder_particles, base_container.py:506-515, in two launches: rank + gather with the
+                                    per-tile preparation of the neighbour passes fused in) instead of run records filed after the scan */
 } SphStats;
 
 /* Kernel ids for the HIP-event profiler (sph_profile_*). */

@@ -64,7 +64,7 @@ class SphStats(C.Structure):
         ("iter_pcisph", C.c_int32), ("iter_cg", C.c_int32), ("err_divergence", C.c_float),
         ("err_density", C.c_float), ("err_pcisph", C.c_float), ("err_cg", C.c_float),
         ("lds_fallback_blocks", C.c_int64), ("total_time", C.c_double), ("pair_evaluations", C.c_int64),
-        ("hash_launches", C.c_int64), ("prehashed_sorts", C.c_int64),
+        ("hash_launches", C.c_int64), ("prehashed_sorts", C.c_int64), ("list_sorts", C.c_int64),
     ]
 
 

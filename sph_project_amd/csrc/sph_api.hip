@@ -316,6 +316,8 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     const size_t G = (size_t)s.c.G;
     CHK_CREATE(dalloc(h, &s.cell_count, G + SPH_NGRAVE + 1)); CHK_CREATE(dalloc(h, &s.cell_start, G + SPH_NGRAVE + 1));   // + graveyard cells (slab sharding)
     CHK_CREATE(dalloc(h, &s.cellid, cap)); CHK_CREATE(dalloc(h, &s.rank, cap)); CHK_CREATE(dalloc(h, &s.tmp_idx, 2 * cap));   // (int2 run records of the stable sort)
+    s.run_head = nullptr; s.run_rec = nullptr; s.sort_inv = nullptr; s.sort_epoch = 0u; s.run_lists_filed = 0; s.n_list_sorts = 0;
+    if (!getenv("SPH_NO_RUN_LISTS")) { CHK_CREATE(dalloc(h, &s.run_head, G + 1)); CHK_CREATE(dalloc(h, &s.run_rec, cap + G + 1)); CHK_CREATE(dalloc(h, &s.sort_inv, cap)); }   // deterministic sort by run lists (RunList, sph_common.hpp)
     s.scan_blocks = (int)((G + SPH_NGRAVE + 2047) / 2048);
     if (s.scan_blocks < SPH_STAT_SLOTS / 256) s.scan_blocks = SPH_STAT_SLOTS / 256;   // k_scan_final also clears the statistics slots
     CHK_CREATE(dalloc(h, &s.scan_partial, 2 * ((size_t)s.scan_blocks + 1) * 8));   // two banks of tile sums, SCAN_PARTIAL_STRIDE ints apart (State::scan_bank)
@@ -329,7 +331,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     s.lane_perm = nullptr; s.perm_n = -1;
     s.loop_flag = nullptr; s.loop_slot = 0; s.loop_kind = 0; s.loop_denom = 1.0f; s.loop_thr = 0.0;
     CHK_CREATE(dalloc(h, &s.blk_hdr, (cap + 255) / 256 * (20 + 256)));   // headers of all tiles, then one cell word per particle slot (k_block_prep)
-    s.blk_flag = s.blk_list = s.blk_count = nullptr; s.list_n = -1; s.last_pass_listed = 0; s.list_count_pinned = nullptr; s.list_count_event = nullptr; s.list_count_known = -1; s.nexthash = NextHash{0, nullptr, nullptr, nullptr}; s.prehashed = 0; s.n_hash_launches = s.n_prehashed_sorts = 0;
+    s.blk_flag = s.blk_list = s.blk_count = nullptr; s.list_n = -1; s.last_pass_listed = 0; s.list_count_pinned = nullptr; s.list_count_event = nullptr; s.list_count_known = -1; s.nexthash = NextHash{0, nullptr, nullptr, nullptr, nullptr, RunList{nullptr, nullptr, 0, 0u}}; s.prehashed = 0; s.n_hash_launches = s.n_prehashed_sorts = 0;
     if (!getenv("SPH_NO_BLOCK_LIST")) {
         CHK_CREATE(dalloc(h, &s.blk_flag, (cap + 255) / 256)); CHK_CREATE(dalloc(h, &s.blk_list, (cap + 255) / 256)); CHK_CREATE(dalloc(h, &s.blk_count, 1));
     }
@@ -820,7 +822,7 @@ static int step_once(SphHandle *h, bool allow_readback) {
     if (!rc) rc = step_second_half(h, allow_readback);
     // a failed step may leave a hash made for a sort that will not come (NextHash: the WCSPH force pass for the next step's sort, the
     // DFSPH position update for this step's): the next sort, whoever asks for it, must hash for itself on a clean histogram
-    if (rc && h->st.prehashed) { h->st.prehashed = 0; h->st.cell_count_clean = 0; h->st.hist_taken = 0; }
+    if (rc && h->st.prehashed) { h->st.prehashed = 0; h->st.cell_count_clean = 0; h->st.hist_taken = 0; h->st.run_lists_filed = 0; }
     return rc;
 }
 
@@ -914,6 +916,7 @@ extern "C" int sph_get_stats(SphHandle *h, SphStats *out) {
     h->last.total_time = h->total_time;
     h->last.hash_launches = h->st.n_hash_launches;
     h->last.prehashed_sorts = h->st.n_prehashed_sorts;
+    h->last.list_sorts = h->st.n_list_sorts;
     *out = h->last;
     return SPH_OK;
 }

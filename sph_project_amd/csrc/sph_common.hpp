@@ -150,7 +150,19 @@ struct HaloSend {
 // What the WCSPH force pass needs to be the NEXT step's k_hash_count as well (round 5): it knows every particle's new position when it
 // stores it, so it files the new cell id, takes the histogram atomic (one per run of equal cells among the tile's particles in sorted
 // order, like k_hash_count) and leaves the arrival rank.  on = 0: the next step hashes as usual.
-struct NextHash { int on; int *cellid, *rank, *cell_count, *tile_sum; };
+// Run lists of the deterministic sort (round 6, fourth session).  The lanes of a hashing wave are a few RUNS of particles that share a cell
+// (wave_runs); whoever takes a run's histogram atomic also links the run into a per-cell list: one 64-bit exchange on head[cell] (sort epoch in
+// the high word, so the heads are never reset: a head of another epoch is an empty list) and one record rec[first particle] = (previous head's
+// first particle or -1, run length).  The sort then ranks every particle from its cell's list (k_sort_rank) -- the launch that used to file the
+// records once the scan had said where (k_scatter_index) is gone.  The run that ARRIVES FIRST in its cell (its histogram atomic returned 0:
+// at rest every run, in motion most) takes no second atomic: it leaves (first particle, length) in first[cell] by a plain store -- exactly one
+// run per cell and sort does -- and only later arrivals chain themselves behind head[cell].  first[] needs no epoch: it is read for cells
+// that hold several runs of this sort only, and such a cell has had its first arrival.  head == nullptr: off (slab sharding).
+// ONE array holds both kinds of record -- rec[i] for i < first_off (the particle capacity), first[cell] = rec[first_off + cell] -- so that a
+// hasher's store goes through one base pointer and an index chosen in registers (with two pointers in the kernel arguments the compiler
+// fetched the chosen one by a dependent VECTOR load from the argument segment: one more round trip at the end of every force-pass workgroup).
+struct RunList { unsigned long long *head; int2 *rec; int first_off; unsigned epoch; };
+struct NextHash { int on; int *cellid, *rank, *cell_count, *tile_sum; RunList rl; };
 
 // ... and what the WCSPH density pass needs to store (rho_raw, rho, p, p / rho^2) of its boundary particles straight into the field
 // message of the neighbours' inboxes (the message k_halo_pack2<2> would gather afterwards): out[side] = that message's region, xidx = the
@@ -179,6 +191,14 @@ struct State {
     int *cell_count;     // G+1
     int *cell_start;     // G+1 (exclusive scan, cell_start[G] = n)
     int *cellid, *rank;  // per particle (pre-sort)
+    // deterministic sort by run lists (RunList above; unsharded scenes): list heads per cell (G + 1, never reset), the epoch of the histogram
+    // being taken / last taken, "the hashers of the coming sort filed their runs", and the sort's gather index (dest slot -> source particle)
+    unsigned long long *run_head;
+    int2 *run_rec;       // cap + G + 1 records (RunList::rec)
+    unsigned sort_epoch;
+    int run_lists_filed;
+    int *sort_inv;
+    long long n_list_sorts;   // sorts that went through k_sort_rank + k_gather_prep, since create (SphStats)
     int *tmp_idx;        // stable-sort scratch: int2 (first source index, length) per run, filed at the run's first slot (2 x cap ints)
     // Sums of the histogram over the scan's tiles of SCAN_TILE cells, two banks of scan_blocks + 1 ints.  Round 6: whoever takes the
     // histogram atomics (k_hash_count, the NextHash epilogue of the force pass, the slab kernels) adds its particles to the tile sums of

@@ -253,12 +253,25 @@ __device__ __forceinline__ void tile_sum_add(int *tile_sum, int lin, bool valid,
     }
 }
 
+// Links a run (first particle i_first, `len` particles of cell `lin`) into its cell's list: RunList, sph_common.hpp.  Called by the run's
+// head lane right next to the run's histogram atomic.
+__device__ __forceinline__ void run_list_file(const RunList &rl, int lin, int i_first, int len, int base) {
+    int prev = i_first, at = rl.first_off + lin;   // first arrival of its cell: (first particle, length) into first[cell], no atomic (RunList)
+    if (base != 0) {
+        const unsigned long long mine = ((unsigned long long)rl.epoch << 32) | (unsigned long long)(unsigned)i_first;
+        const unsigned long long old = atomicExch(&rl.head[lin], mine);
+        prev = (unsigned)(old >> 32) == rl.epoch ? (int)(unsigned)(old & 0xffffffffull) : -1;   // a head of another sort: empty list
+        at = i_first;
+    }
+    rl.rec[at] = make_int2(prev, len);
+}
+
 // ------------------------------------------------------------------ grid build
 // base_container.py:496 init_grid: cell id + histogram.  The atomic's return value is the
 // particle's arrival rank inside its cell, which replaces the second atomic pass of :515.
 __global__ void __launch_bounds__(256)
 k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ cellid,
-             int *__restrict__ rank, int *__restrict__ cell_count, const int *__restrict__ meta_dead, int *__restrict__ tile_sum) {
+             int *__restrict__ rank, int *__restrict__ cell_count, const int *__restrict__ meta_dead, int *__restrict__ tile_sum, const RunList rl) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = i < live_n(c);
@@ -278,8 +291,9 @@ k_hash_count(const Consts c, const float4 *__restrict__ posv, int *__restrict__ 
     wave_runs(lin, lane, head, hl, len);
     int base = 0;
     if (head && valid) base = atomicAdd(&cell_count[lin], len);
-    base = __shfl(base, hl, 64);
-    if (valid) rank[i] = base + (lane - hl);
+    const int base_run = __shfl(base, hl, 64);   // (the wait for the atomic's answer sits here, in front of the record's store -- vmcnt counts stores too)
+    if (rl.head && head && valid) run_list_file(rl, lin, i, len, base);
+    if (valid) rank[i] = base_run + (lane - hl);
     if (tile_sum) tile_sum_add(tile_sum, lin, valid, c.G + (meta_dead ? SPH_NGRAVE : 0));
 }
 
@@ -451,6 +465,40 @@ k_scatter(int n, const int *__restrict__ cellid, const int *__restrict__ rank,
     a.rho_out[d] = a.rho_in[i];
     if (a.orig_in) a.orig_out[d] = a.orig_in[i];
     if (a.xidx_in) a.xidx_out[d] = a.xidx_in[i];
+}
+
+// Deterministic sort by run lists, first half (replaces k_scatter_index AND the rank walk of k_scatter<true>): the destination of every
+// particle = cell_start[cell] + stable rank, where the stable rank (serial execution of base_container.py:510-515) = (lengths of the
+// cell's runs whose first particle has a lower source index) + (position inside its own run).  The cell's runs hang on the list the hashers
+// filed (run_list_file); a run that IS its cell (the usual case) has nothing to walk.  Leaves the INVERSE map inv[dest] = source: the second
+// half (k_gather_prep) is organised by destination tile, so that it can prepare the tile for the neighbour passes while it moves it.
+__global__ void __launch_bounds__(256)
+k_sort_rank(int n, const int *__restrict__ cellid, const int *__restrict__ cell_start, const RunList rl, int *__restrict__ inv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < n;
+    const int cell = valid ? cellid[i] : -1 - lane;
+    bool head; int hl, len;
+    wave_runs(cell, lane, head, hl, len);   // the same runs the hasher saw: same thread -> particle map
+    int d0 = 0;
+    if (valid && head) {
+        const int s = cell_start[cell], e = cell_start[cell + 1];
+        int r0 = 0;
+        if (e - s != len) {   // other runs share the cell
+            const int2 f = rl.rec[rl.first_off + cell];                            // the cell's first arrival (of this sort: the cell holds several runs)
+            r0 = f.x < i ? f.y : 0;
+            const unsigned long long hd = rl.head[cell];              // ... and the later ones, newest first
+            int p = (unsigned)(hd >> 32) == rl.epoch ? (int)(unsigned)(hd & 0xffffffffull) : -1;
+            for (int hops = 0; p >= 0 && hops < e - s; ++hops) {      // a cell has at most as many runs as particles
+                const int2 rec = rl.rec[p];
+                r0 += p < i ? rec.y : 0;
+                p = rec.x;
+            }
+        }
+        d0 = s + r0;
+    }
+    d0 = __shfl(d0, hl, 64);
+    if (valid) inv[d0 + (lane - hl)] = i;
 }
 
 // ------------------------------------------------------------------ generic neighbour pass
@@ -797,52 +845,20 @@ struct TilePlanOut { int *list_b, *list_i, *cnt; unsigned char *cls; int lo_laye
 // neighbours for particles in the low-x and the high-x part of a cell; putting like with like makes the 64 lanes
 // of a wave agree on their trip counts per group.  Any permutation is correct (every lane still walks its own
 // particle's neighbours in reference order); this one is only faster.  perm[b * 256 + lane] = particle of the lane.
-__global__ void __launch_bounds__(256)
-k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restrict__ meta,
-             const int *__restrict__ cell_start, int *__restrict__ blk_hdr, unsigned char *__restrict__ perm,
-             int *__restrict__ blk_flag, const int *__restrict__ xidx, BlockPrepTables tabs, TilePlanOut plan, unsigned *__restrict__ cellw) {
-    __shared__ int s_cnt[4][64];
-    __shared__ int s_c[2];
+// The per-tile part (header, cell words, lane permutation, fluid flag) of tile blockIdx.x, given every thread's particle: `p` / `meta_i` are
+// the position and meta word of particle blockIdx.x * 256 + threadIdx.x (anything where that is >= n).  Shared by k_block_prep (which reads
+// them from the sorted arrays) and k_gather_prep (which has just moved them there).  All 256 threads of the workgroup must call it.
+__device__ __forceinline__ void block_prep_tile(const Consts &c, int n, const float4 p, int meta_i, const int *__restrict__ cell_start,
+                                                int *__restrict__ blk_hdr, unsigned char *__restrict__ perm, int *__restrict__ blk_flag,
+                                                unsigned *__restrict__ cellw, int (*s_cnt)[64], int *s_c) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i0 = blockIdx.x * 256;
     const int i = i0 + tid;
-    const int n = live_n(c);
-    if (plan.list_b && tid == 64 && i0 < n) {
-        // which set does this tile belong to?  Interior = entirely inside the particle range [r1, r2) of the layers that are neither
-        // ghost layers nor within two layers of a face; everything else (and every tile of a slab too thin to have such layers) = boundary.
-        const int layer = c.ny * c.nz;
-        const int r1 = plan.lo_layers > 0 ? cell_start[(plan.lo_layers < c.nx ? plan.lo_layers : c.nx) * layer] : 0;
-        const int r2 = plan.hi_layers > 0 ? cell_start[(c.nx - plan.hi_layers > 0 ? c.nx - plan.hi_layers : 0) * layer] : n;
-        const int nt = (n + 255) >> 8;
-        int t1 = (r1 + 255) >> 8, t2 = r2 >> 8;          // interior tiles: [t1, t2)
-        if (t2 > nt) t2 = nt;
-        if (t2 < t1) t2 = t1 = nt;                         // none
-        const int t = (int)blockIdx.x, ni = t2 - t1;
-        if (t < t1) plan.list_b[t] = t;
-        else if (t >= t2) plan.list_b[t1 + (t - t2)] = t;
-        else plan.list_i[t - t1] = t1 + xcd_remap(t - t1, ni);   // slot k holds the k-th tile of an XCD-aware order (bijective)
-        plan.cls[t] = (t < t1 || t >= t2) ? 1 : 0;
-        if (t == 0) {
-            plan.cnt[0] = nt - ni; plan.cnt[1] = ni;
-            if (nt - ni > plan.bound_b && plan.status) atomicOr(plan.status, SLAB_ST_BOUND);   // boundary launches of this sort epoch would miss tiles
-            if (plan.mirror_nb) *plan.mirror_nb = nt - ni;
-        }
-    }
-    if (i0 >= n) {   // launch bound of an asynchronous slab step: no such tile
-        if (blk_flag && tid == 0) blk_flag[blockIdx.x] = 0;
-        return;
-    }
     const int nvalid = (n - i0) < 256 ? (n - i0) : 256;
     int key = 63;  // slots past the end go last
     int my_lin = 0, my_dz0 = 0, my_dz = 0;   // this particle's cell, z0 - cz and z1 - z0 (for its cell word, below)
     unsigned my_dom = 0u;
     if (i < n) {
-        if (xidx) {   // slab sharding, push transport: the halo slot tables of this sort (sph_halo.hpp k_halo_tables) ride along
-            const int x = xidx[i];
-            const int kind = (int)(((unsigned)x) >> 28);
-            if (kind >= 1 && kind <= 8) tabs.tab[kind - 1][x & 0x0fffffff] = i;
-        }
-        const float4 p = posv[i];
         const int cxg = cell_coord(p.x, c.grid_size, c.nx_glob);   // (the key is the position inside the cell: global layer)
         const int k = (int)((p.x / c.grid_size - (float)cxg) * 62.0f);
         const int cx = cell_coord_x(c, p.x);
@@ -863,7 +879,7 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
     }
     (&s_cnt[0][0])[tid] = 0;
     if (blk_flag) {   // does this workgroup hold any fluid particle? (k_compact_blocks lists those that do)
-        const int anyf = __syncthreads_or((i < n && META_ACTIVE_FLUID(meta[i])) ? 1 : 0);
+        const int anyf = __syncthreads_or((i < n && META_ACTIVE_FLUID(meta_i)) ? 1 : 0);
         if (tid == 0) blk_flag[blockIdx.x] = anyf ? 1 : 0;
     }
     unsigned long long peers = ~0ull;   // lanes of this wave holding the same key
@@ -909,6 +925,82 @@ k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restr
         for (int k = 0; k < w; ++k) dest += s_cnt[k][key];
         perm[i0 + dest] = (unsigned char)tid;
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_block_prep(const Consts c, const float4 *__restrict__ posv, const int *__restrict__ meta,
+             const int *__restrict__ cell_start, int *__restrict__ blk_hdr, unsigned char *__restrict__ perm,
+             int *__restrict__ blk_flag, const int *__restrict__ xidx, BlockPrepTables tabs, TilePlanOut plan, unsigned *__restrict__ cellw) {
+    __shared__ int s_cnt[4][64];
+    __shared__ int s_c[2];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * 256;
+    const int i = i0 + tid;
+    const int n = live_n(c);
+    if (plan.list_b && tid == 64 && i0 < n) {
+        // which set does this tile belong to?  Interior = entirely inside the particle range [r1, r2) of the layers that are neither
+        // ghost layers nor within two layers of a face; everything else (and every tile of a slab too thin to have such layers) = boundary.
+        const int layer = c.ny * c.nz;
+        const int r1 = plan.lo_layers > 0 ? cell_start[(plan.lo_layers < c.nx ? plan.lo_layers : c.nx) * layer] : 0;
+        const int r2 = plan.hi_layers > 0 ? cell_start[(c.nx - plan.hi_layers > 0 ? c.nx - plan.hi_layers : 0) * layer] : n;
+        const int nt = (n + 255) >> 8;
+        int t1 = (r1 + 255) >> 8, t2 = r2 >> 8;          // interior tiles: [t1, t2)
+        if (t2 > nt) t2 = nt;
+        if (t2 < t1) t2 = t1 = nt;                         // none
+        const int t = (int)blockIdx.x, ni = t2 - t1;
+        if (t < t1) plan.list_b[t] = t;
+        else if (t >= t2) plan.list_b[t1 + (t - t2)] = t;
+        else plan.list_i[t - t1] = t1 + xcd_remap(t - t1, ni);   // slot k holds the k-th tile of an XCD-aware order (bijective)
+        plan.cls[t] = (t < t1 || t >= t2) ? 1 : 0;
+        if (t == 0) {
+            plan.cnt[0] = nt - ni; plan.cnt[1] = ni;
+            if (nt - ni > plan.bound_b && plan.status) atomicOr(plan.status, SLAB_ST_BOUND);   // boundary launches of this sort epoch would miss tiles
+            if (plan.mirror_nb) *plan.mirror_nb = nt - ni;
+        }
+    }
+    if (i0 >= n) {   // launch bound of an asynchronous slab step: no such tile
+        if (blk_flag && tid == 0) blk_flag[blockIdx.x] = 0;
+        return;
+    }
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    int meta_i = 0;
+    if (i < n) {
+        if (xidx) {   // slab sharding, push transport: the halo slot tables of this sort (sph_halo.hpp k_halo_tables) ride along
+            const int x = xidx[i];
+            const int kind = (int)(((unsigned)x) >> 28);
+            if (kind >= 1 && kind <= 8) tabs.tab[kind - 1][x & 0x0fffffff] = i;
+        }
+        p = posv[i];
+        if (blk_flag) meta_i = meta[i];
+    }
+    block_prep_tile(c, n, p, meta_i, cell_start, blk_hdr, perm, blk_flag, cellw, s_cnt, s_c);
+}
+
+// Deterministic sort by run lists, second half: base_container.py:506 reorder_particles as a GATHER by destination tile (inv from
+// k_sort_rank) with k_block_prep's work fused in -- the workgroup that fills the 256 slots of a tile holds their positions in registers, so
+// it writes the tile's header, cell words and lane permutation as well: the sort is scan + rank + this (3 launches; 4 with k_scatter_index
+// / k_scatter / k_block_prep), and nobody reads the 16 B positions a second time.  Unsharded scenes only (n is exact, no slot tables).
+__global__ void __launch_bounds__(256)
+k_gather_prep(const Consts c, int n, const int *__restrict__ inv, SortArrays a, const int *__restrict__ cell_start,
+              int *__restrict__ blk_hdr, unsigned char *__restrict__ perm, int *__restrict__ blk_flag, unsigned *__restrict__ cellw) {
+    __shared__ int s_cnt[4][64];
+    __shared__ int s_c[2];
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    int meta_i = 0;
+    if (d < n) {
+        const int i = inv[d];
+        p = a.posv_in[i];
+        meta_i = a.meta_in[i];
+        a.posv_out[d] = p;
+        a.velm_out[d] = a.velm_in[i];
+        a.meta_out[d] = meta_i;
+        a.pid_out[d] = a.pid_in[i];
+        a.color_out[d] = a.color_in[i];
+        a.rho_out[d] = a.rho_in[i];
+        if (a.orig_in) a.orig_out[d] = a.orig_in[i];
+    }
+    block_prep_tile(c, n, p, meta_i, cell_start, blk_hdr, perm, blk_flag, cellw, s_cnt, s_c);
 }
 
 // ascending list of the workgroups whose flag is set (one workgroup, fixed order: the list is deterministic).  Every thread owns a
@@ -1525,8 +1617,9 @@ k_nbr_pass(const Consts c, const int *__restrict__ cell_start, const P p, DevSca
             wave_runs(lin, lane, head, hl, len);
             int base = 0;
             if (head && v2) base = atomicAdd(&p.nh.cell_count[lin], len);
-            base = __shfl(base, hl, 64);
-            if (v2) { p.nh.cellid[i0 + tid] = lin; p.nh.rank[i0 + tid] = base + (lane - hl); }
+            const int base_run = __shfl(base, hl, 64);   // (the wait for the atomic's answer sits here, in front of the record's store -- vmcnt counts stores too)
+            if (p.nh.rl.head && head && v2) run_list_file(p.nh.rl, lin, i0 + tid, len, base);
+            if (v2) { p.nh.cellid[i0 + tid] = lin; p.nh.rank[i0 + tid] = base_run + (lane - hl); }
             if (p.nh.tile_sum) tile_sum_add(p.nh.tile_sum, lin, v2, c.G);   // (unsharded only: no graveyard cells)
         }
     }

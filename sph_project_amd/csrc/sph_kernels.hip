@@ -39,6 +39,15 @@ static void clear_histogram(State &s) {
     hipMemsetAsync(s.scan_partial + (size_t)s.scan_bank * (s.scan_blocks + 1) * SCAN_PARTIAL_STRIDE, 0, sizeof(int) * (size_t)(s.scan_blocks + 1) * SCAN_PARTIAL_STRIDE, s.stream);
 }
 
+// Run lists of the deterministic sort (RunList, sph_common.hpp): what a hasher of the COMING sort files its runs with, or an off list.
+// Unsharded scenes only (a slab's arrivals take their slots one by one, in kernels of their own); SPH_NO_RUN_LISTS=1: never allocated.
+// open_epoch: a new histogram begins (the lists of every earlier one die with their epoch).
+static RunList run_list_of(State &s, bool open_epoch) {
+    if (!s.run_head || s.slab_active) { s.run_lists_filed = 0; return RunList{nullptr, nullptr, 0, 0u}; }
+    if (open_epoch) { if (++s.sort_epoch == 0u) s.sort_epoch = 1u; }
+    return RunList{s.run_head, s.run_rec, s.cap, s.sort_epoch};
+}
+
 void l_hash_count(State &s) {
     const int n = s.c.n;
     if (s.prehashed) {   // the last step's force pass has hashed for this sort (NextHash): cell ids, histogram and ranks are in place
@@ -52,10 +61,13 @@ void l_hash_count(State &s) {
     int *ts = tile_sum_bank(s);
     s.tile_sums_ready = ts != nullptr;
     s.hist_taken = 1;
+    s.run_lists_filed = 0;
     if (n == 0) return;
     s.n_hash_launches++;
+    const RunList rl = run_list_of(s, true);
     hipLaunchKernelGGL(k_hash_count, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.cellid,
-                       s.rank, s.cell_count, s.slab_active ? s.meta.cur() : nullptr, ts);
+                       s.rank, s.cell_count, s.slab_active ? s.meta.cur() : nullptr, ts, rl);
+    s.run_lists_filed = rl.head != nullptr;
 }
 
 void l_scan(State &s) {
@@ -78,7 +90,8 @@ void l_scan(State &s) {
 }
 
 // per-workgroup header + lane permutation of the neighbour passes (k_block_prep); valid until the order changes
-void l_block_prep(State &s) {
+// launch = false: k_gather_prep has done the kernel's work for this sort (l_scatter_impl); the bookkeeping behind it is the same
+void l_block_prep(State &s, bool launch = true) {
     const int n = s.c.n;
     if (n == 0) return;
     const bool lst = !s.c.all_fluid && s.blk_list;
@@ -99,6 +112,7 @@ void l_block_prep(State &s) {
                            s.dyn_cur ? &s.dyn_cur->status : nullptr, s.push.mirror ? &((volatile SlabDyn *)s.push.mirror)->n_btiles : nullptr};
         s.tile_plan_n = n;
     }
+    if (launch)
     hipLaunchKernelGGL(k_block_prep, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(), s.meta.cur(), s.cell_start,
                        s.blk_hdr, s.lane_perm, lst ? s.blk_flag : nullptr, xi, tabs, plan,
                        reinterpret_cast<unsigned *>(s.blk_hdr + (size_t)((s.cap + 255) / 256) * BLK_HDR_INTS));   // cell words behind the headers
@@ -124,7 +138,19 @@ void l_scatter_impl(State &s, bool stable) {
     a.rho_in = s.rho.cur(); a.rho_out = s.rho.alt();
     a.orig_in = s.orig.cur(); a.orig_out = s.orig.alt();
     a.xidx_in = s.slab_active ? s.xidx[s.xcur] : nullptr; a.xidx_out = s.slab_active ? s.xidx[1 - s.xcur] : nullptr;
-    if (stable) {
+    // deterministic sort of an unsharded scene whose hashers filed their runs into per-cell lists: rank from the lists, then a gather by
+    // destination tile that prepares the tile for the neighbour passes as it goes -- 2 launches instead of 3 (k_scatter_index, k_scatter, k_block_prep)
+    const bool by_lists = stable && s.run_lists_filed && s.run_head && s.sort_inv && !s.slab_active;
+    s.run_lists_filed = 0;
+    if (by_lists) {
+        hipLaunchKernelGGL(k_sort_rank, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.cell_start,
+                           RunList{s.run_head, s.run_rec, s.cap, s.sort_epoch}, s.sort_inv);
+        const bool lst = !s.c.all_fluid && s.blk_list;
+        hipLaunchKernelGGL(k_gather_prep, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, s.c, n, s.sort_inv, a, s.cell_start,
+                           s.blk_hdr, s.lane_perm, lst ? s.blk_flag : nullptr,
+                           reinterpret_cast<unsigned *>(s.blk_hdr + (size_t)((s.cap + 255) / 256) * BLK_HDR_INTS));
+        s.n_list_sorts++;
+    } else if (stable) {
         hipLaunchKernelGGL(k_scatter_index, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
                            s.cell_start, (int2 *)s.tmp_idx, s.c.n_dev);
         hipLaunchKernelGGL(k_scatter<true>, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.rank,
@@ -135,7 +161,7 @@ void l_scatter_impl(State &s, bool stable) {
     }
     s.posv.flip(); s.velm.flip(); s.meta.flip(); s.pid.flip(); s.color.flip(); s.rho.flip();
     s.masks_valid = 0;  // new order, new candidate runs
-    if (!s.slab_active) l_block_prep(s);
+    if (!s.slab_active) l_block_prep(s, !by_lists);
     else s.perm_n = s.list_n = -1;   // slab sharding: rebuilt once the dead particles behind the live ones are dropped (launch_pass)
     if (s.orig.cur()) s.orig.flip();
     if (s.slab_active) s.xcur = 1 - s.xcur;
@@ -290,9 +316,10 @@ void l_pressure_integrate(State &s) {
 void l_wcsph_forces(State &s) {
     // this pass as the next step's k_hash_count (NextHash): only where the histogram is clean (the scan cleared it behind itself) and
     // every particle is an active fluid particle of an unsharded scene (wcsph_step decides whether another step follows untouched)
-    NextHash nh{0, s.cellid, s.rank, s.cell_count, tile_sum_bank(s)};
+    NextHash nh{0, s.cellid, s.rank, s.cell_count, tile_sum_bank(s), RunList{nullptr, nullptr, 0, 0u}};
     if (s.nexthash.on && s.c.all_fluid && !s.slab_active && s.cell_count_clean && s.density_books_forces && s.c.n > 0) nh.on = 1;
     s.nexthash.on = 0;
+    if (nh.on) nh.rl = run_list_of(s, true);
     if (!s.density_books_forces) {   // launched outside wcsph_step's density + forces pair: nobody has booked this walk's pairs
         if (s.c.all_fluid) {
             WcsphForcePass<true, false, true> p{s.posv.cur(), s.velm.cur(), s.meta.cur(), s.rho_raw, s.ptm, s.prs, s.rho.cur(), s.velm.alt(), s.acc, s.posv.alt(), s.scal, s.pose, s.c.rho0, s.presend, nh};
@@ -316,7 +343,7 @@ void l_wcsph_forces(State &s) {
         launch_pass(s, p, 2);
     }
     if (s.presend.on) { s.presend.on = 0; s.preclassified = 1; }
-    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; s.tile_sums_ready = nh.tile_sum != nullptr; s.hist_taken = 1; }
+    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; s.tile_sums_ready = nh.tile_sum != nullptr; s.hist_taken = 1; s.run_lists_filed = nh.rl.head != nullptr; }
     s.velm.flip();
     s.posv.flip();
     s.masks_valid = 0;  // positions moved

@@ -43,21 +43,23 @@ k_advect_boundary(const Consts c, float4 *posv, float4 *velm, int *meta, const R
         wave_runs(lin, lane, head, hl, len);
         int base = 0;
         if (head && valid) base = atomicAdd(&nh.cell_count[lin], len);
-        base = __shfl(base, hl, 64);
-        if (valid) nh.rank[i] = base + (lane - hl);
+        const int base_run = __shfl(base, hl, 64);
+        if (nh.rl.head && head && valid) run_list_file(nh.rl, lin, i, len, base);
+        if (valid) nh.rank[i] = base_run + (lane - hl);
         if (nh.tile_sum) tile_sum_add(nh.tile_sum, lin, valid, c.G);
     }
 }
 
 static void l_advect_boundary(State &s) {
-    NextHash nh{0, s.cellid, s.rank, s.cell_count, tile_sum_bank(s)};
+    NextHash nh{0, s.cellid, s.rank, s.cell_count, tile_sum_bank(s), RunList{nullptr, nullptr, 0, 0u}};
     if (s.nexthash.on && s.c.all_fluid && !s.slab_active && s.cell_count_clean && s.c.n > 0) nh.on = 1;
     s.nexthash.on = 0;
     if (s.c.n == 0) return;
+    if (nh.on) nh.rl = run_list_of(s, true);
     s.masks_valid = 0;  // positions move
     hipLaunchKernelGGL(k_advect_boundary, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c, s.posv.cur(),
                        s.velm.cur(), s.meta.cur(), s.pose, s.c.all_fluid, nh);
-    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; s.tile_sums_ready = nh.tile_sum != nullptr; s.hist_taken = 1; }
+    if (nh.on) { s.prehashed = 1; s.cell_count_clean = 0; s.tile_sums_ready = nh.tile_sum != nullptr; s.hist_taken = 1; s.run_lists_filed = nh.rl.head != nullptr; }
 }
 
 static void l_reduce_sum(State &s, int slot, int nblocks) {

@@ -272,13 +272,14 @@ def test_c2_full_size_20_steps(gpu):
     solver.prepare()
     ref = H.build_oracle(cfg)
     ref.prepare()
-    h0, p0 = solver.stats()["hash_launches"], solver.stats()["prehashed_sorts"]
+    h0, p0, l0 = solver.stats()["hash_launches"], solver.stats()["prehashed_sorts"], solver.stats()["list_sorts"]
     solver.advance(20)
     ref.step(20)
     e = container.engine
     st = solver.stats()
     assert st["steps"] == 20
     assert st["prehashed_sorts"] - p0 == 19 and st["hash_launches"] - h0 == 1, (st["hash_launches"], st["prehashed_sorts"])
+    assert st["list_sorts"] - l0 == 20, st   # ... and every sort ranked the particles from the run lists those hashers filed (k_sort_rank + k_gather_prep)
     ids = e.download(L.F_PARTICLE_ID)
     assert np.array_equal(np.sort(ids), np.arange(1231200))
     x_sorted, v_sorted = e.download(L.F_POSITION), e.download(L.F_VELOCITY)
@@ -386,6 +387,60 @@ def test_next_hash_changes_nothing(gpu, fast_math):
         for u, v in zip(a[:4], b[:4]):
             assert np.array_equal(u, v)
         assert a[4] == b[4]
+
+
+@pytest.mark.parametrize("fast_math", [0, 1])
+def test_list_sort_equals_record_sort(gpu, fast_math, monkeypatch):
+    """The deterministic sort by per-cell RUN LISTS (filed by whoever hashes: k_hash_count / the force pass; then k_sort_rank +
+    k_gather_prep, which also prepares the tiles for the neighbour passes) against the sort by run records (k_scatter_index +
+    k_scatter<true> + k_block_prep; SPH_NO_RUN_LISTS=1): a perturbed, collapsing block whose cells change population every step,
+    advanced in calls of several lengths -- ids, positions, velocities, densities and pair counts array_equal after every call
+    (= same order, same tile headers / cell words / lane permutation as far as any result depends on them), and the counters say
+    which sort ran.  reorder_particles: base_container.py:506-515."""
+    cfg = H.dam_break_scene(end=(0.3, 0.4, 0.3), velocity=(0.4, -1.5, 0.3))
+    out = []
+    for lists in (True, False):
+        if not lists:
+            monkeypatch.setenv("SPH_NO_RUN_LISTS", "1")
+        container, solver = H.build_product(cfg, fast_math=fast_math, jitter=0.003, seed=11)
+        e = container.engine
+        solver.prepare()
+        snaps = []
+        for n in (1, 7, 2, 30):
+            e.step_async(n)
+            st = solver.stats()
+            snaps.append((e.download(L.F_PARTICLE_ID), e.download(L.F_POSITION), e.download(L.F_VELOCITY), e.download(L.F_DENSITY),
+                          st["pair_interactions"]))
+        st = solver.stats()
+        sorts = st["hash_launches"] + st["prehashed_sorts"]
+        assert st["list_sorts"] == (sorts if lists else 0), st
+        out.append(snaps)
+    for a, b in zip(*out):
+        for u, v in zip(a[:4], b[:4]):
+            assert np.array_equal(u, v)
+        assert a[4] == b[4]
+
+
+def test_list_sort_with_boundary_particles_and_emitter(gpu, monkeypatch):
+    """The same A/B where the scene is not all fluid (sampled domain box: the gather also flags the tiles that hold fluid, and
+    k_hash_count -- not the force pass -- files the runs every step)."""
+    cfg = H.dam_break_scene(domain_end=(0.6, 0.6, 0.6), end=(0.2, 0.2, 0.2), translation=(0.06, 0.06, 0.06),
+                            add_domain_box=True)
+    out = []
+    for lists in (True, False):
+        if not lists:
+            monkeypatch.setenv("SPH_NO_RUN_LISTS", "1")
+        container, solver = H.build_product(cfg)
+        solver.prepare()
+        for _ in range(10):
+            solver.step()
+        solver.advance(5)
+        st = solver.stats()
+        assert (st["list_sorts"] > 0) == lists, st
+        out.append((_state(container), st))
+    for k in ("x", "v", "rho", "p", "a", "V"):
+        np.testing.assert_array_equal(out[0][0][k], out[1][0][k])
+    assert out[0][1]["pair_interactions"] == out[1][1]["pair_interactions"]
 
 
 def test_fluid_workgroup_list_changes_nothing(gpu, monkeypatch):

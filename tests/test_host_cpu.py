@@ -318,3 +318,60 @@ def test_run_record_stable_rank_model():
         want = np.empty(n, np.int64)
         want[np.argsort(cell, kind="stable")] = np.arange(n)
         np.testing.assert_array_equal(dest, want)
+
+
+def test_run_list_stable_rank_model():
+    """The deterministic sort by per-cell RUN LISTS (round 6: csrc/sph_device.hpp run_list_file / k_sort_rank / k_gather_prep) as a numpy
+    model, against a stable argsort.  Whoever hashes a run (consecutive source particles of a wave with the same cell) takes one histogram
+    "atomic" for it -- served in any order -- and links it into its cell's list: the run whose atomic returned 0 (the cell's first arrival)
+    stores (first particle, length) into first[cell] without another atomic, every later arrival exchanges head[cell] = (epoch, first
+    particle) and keeps what it found (if of this epoch) as its `next`.  Stale heads and stale first[] entries of earlier sorts must not
+    matter.  k_sort_rank: dest = cell_start + (lengths of the cell's runs that start at a lower source index) + (position inside the
+    run), written as the inverse map the gather reads."""
+    rng = np.random.default_rng(6)
+    n_cells = 48
+    head = np.zeros(n_cells, np.int64)          # (epoch << 32) | first particle; never reset
+    first = np.full((n_cells, 2), -7, np.int64)  # never reset either
+    epoch = 0
+    for trial in range(60):
+        epoch += 1
+        n = int(rng.integers(1, 700))
+        cell = np.sort(rng.integers(0, n_cells, n))
+        move = rng.random(n) < (0.0 if trial % 5 == 0 else 0.2)    # every fifth trial: a rest lattice (every run is its cell, up to wave seams)
+        cell[move] = np.clip(cell[move] + rng.integers(-2, 3, move.sum()), 0, n_cells - 1)
+        wave = np.arange(n) // 64
+        is_head = np.ones(n, bool)
+        is_head[1:] = (cell[1:] != cell[:-1]) | (wave[1:] != wave[:-1])
+        heads = np.nonzero(is_head)[0]
+        lens = np.diff(np.concatenate([heads, [n]]))
+        count = np.zeros(n_cells, np.int64)
+        rec = {}
+        for k in rng.permutation(len(heads)):                 # the order the atomics are served in
+            h, L, c = int(heads[k]), int(lens[k]), int(cell[heads[k]])
+            base = count[c]; count[c] += L
+            if base == 0:
+                first[c] = (h, L)
+            else:
+                old = head[c]; head[c] = (epoch << 32) | h
+                rec[h] = (int(old & 0xffffffff) if (old >> 32) == epoch else -1, L)
+        start = np.concatenate([[0], np.cumsum(count)])
+        inv = np.full(n, -1, np.int64)
+        for h, L in zip(heads, lens):
+            c = cell[h]
+            r0 = 0
+            if start[c + 1] - start[c] != L:
+                f0, fl = first[c]
+                r0 = fl if f0 < h else 0
+                p = int(head[c] & 0xffffffff) if (head[c] >> 32) == epoch else -1
+                hops = 0
+                while p >= 0:
+                    nxt, length = rec[p]
+                    if p < h:
+                        r0 += length
+                    p = nxt
+                    hops += 1
+                    assert hops <= start[c + 1] - start[c]
+            d = start[c] + r0 + np.arange(L)
+            assert (inv[d] == -1).all()
+            inv[d] = h + np.arange(L)
+        np.testing.assert_array_equal(inv, np.argsort(cell, kind="stable"))
