@@ -317,7 +317,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     CHK_CREATE(dalloc(h, &s.cell_count, G + SPH_NGRAVE + 1)); CHK_CREATE(dalloc(h, &s.cell_start, G + SPH_NGRAVE + 1));   // + graveyard cells (slab sharding)
     CHK_CREATE(dalloc(h, &s.cellid, cap)); CHK_CREATE(dalloc(h, &s.rank, cap)); CHK_CREATE(dalloc(h, &s.tmp_idx, 2 * cap));   // (int2 run records of the stable sort)
     s.run_head = nullptr; s.run_rec = nullptr; s.sort_inv = nullptr; s.sort_epoch = 0u; s.run_lists_filed = 0; s.n_list_sorts = 0;
-    if (!getenv("SPH_NO_RUN_LISTS")) { CHK_CREATE(dalloc(h, &s.run_head, G + 1)); CHK_CREATE(dalloc(h, &s.run_rec, cap + G + 1)); CHK_CREATE(dalloc(h, &s.sort_inv, cap)); }   // deterministic sort by run lists (RunList, sph_common.hpp)
+    if (h->prm.deterministic && !getenv("SPH_NO_RUN_LISTS")) { CHK_CREATE(dalloc(h, &s.run_head, G + 1)); CHK_CREATE(dalloc(h, &s.run_rec, cap + G + 1)); CHK_CREATE(dalloc(h, &s.sort_inv, cap)); }   // deterministic sort by run lists (RunList, sph_common.hpp)
     s.scan_blocks = (int)((G + SPH_NGRAVE + 2047) / 2048);
     if (s.scan_blocks < SPH_STAT_SLOTS / 256) s.scan_blocks = SPH_STAT_SLOTS / 256;   // k_scan_final also clears the statistics slots
     CHK_CREATE(dalloc(h, &s.scan_partial, 2 * ((size_t)s.scan_blocks + 1) * 8));   // two banks of tile sums, SCAN_PARTIAL_STRIDE ints apart (State::scan_bank)
