@@ -421,7 +421,7 @@ def test_list_sort_equals_record_sort(gpu, fast_math, monkeypatch):
         assert a[4] == b[4]
 
 
-def test_list_sort_with_boundary_particles_and_emitter(gpu, monkeypatch):
+def test_list_sort_with_boundary_particles(gpu, monkeypatch):
     """The same A/B where the scene is not all fluid (sampled domain box: the gather also flags the tiles that hold fluid, and
     k_hash_count -- not the force pass -- files the runs every step)."""
     cfg = H.dam_break_scene(domain_end=(0.6, 0.6, 0.6), end=(0.2, 0.2, 0.2), translation=(0.06, 0.06, 0.06),
