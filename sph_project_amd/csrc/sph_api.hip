@@ -317,7 +317,8 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     CHK_CREATE(dalloc(h, &s.cell_count, G + SPH_NGRAVE + 1)); CHK_CREATE(dalloc(h, &s.cell_start, G + SPH_NGRAVE + 1));   // + graveyard cells (slab sharding)
     CHK_CREATE(dalloc(h, &s.cellid, cap)); CHK_CREATE(dalloc(h, &s.rank, cap)); CHK_CREATE(dalloc(h, &s.tmp_idx, 2 * cap));   // (int2 run records of the stable sort)
     s.run_head = nullptr; s.run_rec = nullptr; s.sort_inv = nullptr; s.sort_epoch = 0u; s.run_lists_filed = 0; s.n_list_sorts = 0;
-    if (h->prm.deterministic && !getenv("SPH_NO_RUN_LISTS")) { CHK_CREATE(dalloc(h, &s.run_head, G + 1)); CHK_CREATE(dalloc(h, &s.run_rec, cap + G + 1)); CHK_CREATE(dalloc(h, &s.sort_inv, cap)); }   // deterministic sort by run lists (RunList, sph_common.hpp)
+    s.sort_skip_rho = 0; s.color_home = nullptr; s.color_home_ok = 0; s.color_stale = 0;
+    if (h->prm.deterministic && !getenv("SPH_NO_RUN_LISTS")) { CHK_CREATE(dalloc(h, &s.run_head, G + 1)); CHK_CREATE(dalloc(h, &s.run_rec, cap + G + 1)); CHK_CREATE(dalloc(h, &s.sort_inv, cap)); CHK_CREATE(dalloc(h, &s.color_home, cap)); s.color_home_ok = 1; }   // deterministic sort by run lists (RunList, sph_common.hpp)
     s.scan_blocks = (int)((G + SPH_NGRAVE + 2047) / 2048);
     if (s.scan_blocks < SPH_STAT_SLOTS / 256) s.scan_blocks = SPH_STAT_SLOTS / 256;   // k_scan_final also clears the statistics slots
     CHK_CREATE(dalloc(h, &s.scan_partial, 2 * ((size_t)s.scan_blocks + 1) * 8));   // two banks of tile sums, SCAN_PARTIAL_STRIDE ints apart (State::scan_bank)
@@ -443,6 +444,7 @@ extern "C" int sph_append_particles(SphHandle *h, int object_id, int n, const fl
     HIPCHK(h, hipMemcpy(s.meta.cur() + off, hm.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(s.pid.cur() + off, hid.data(), sizeof(int) * n, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(s.color.cur() + off, hc.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice));
+    if (s.color_home) HIPCHK(h, hipMemcpy(s.color_home + off, hc.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice));   // (particle id = append index: hid above)
     HIPCHK(h, hipMemcpy(s.rho.cur() + off, hr.data(), sizeof(float) * n, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(s.prs + off, hpr.data(), sizeof(float) * n, hipMemcpyHostToDevice));
     if (s.orig.cur()) HIPCHK(h, hipMemcpy(s.orig.cur() + off, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
@@ -464,6 +466,7 @@ extern "C" int sph_set_appended_ids(SphHandle *h, int n, const int32_t *ids) {
     if (!h || !ids || n < 0 || n > h->n) return fail(h, SPH_ERR_INVALID, "set_appended_ids: bad arguments");
     if (n == 0) return SPH_OK;
     HIPCHK(h, hipSetDevice(h->device));
+    h->L->ensure_color(h->st); h->st.color_home_ok = 0;   // ids from outside: the colours travel with the particles from now on
     HIPCHK(h, hipStreamSynchronize(h->st.stream));
     HIPCHK(h, hipMemcpy(h->st.pid.cur() + (size_t)(h->n - n), ids, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
     return SPH_OK;
@@ -1003,6 +1006,7 @@ extern "C" int sph_download(SphHandle *h, int field, void *dst, size_t bytes) {
     }
     if (field == SPH_F_COLOR) {
         if (bytes != n * 12) return fail(h, SPH_ERR_INVALID, "download: size mismatch");
+        h->L->ensure_color(s); HIPCHK(h, hipStreamSynchronize(s.stream));
         std::vector<unsigned> tmp(n);
         HIPCHK(h, hipMemcpy(tmp.data(), s.color.cur(), n * 4, hipMemcpyDeviceToHost));
         int32_t *d = (int32_t *)dst;
@@ -1062,6 +1066,7 @@ extern "C" int sph_upload(SphHandle *h, int field, const void *src, size_t bytes
     }
     if (field == SPH_F_PARTICLE_ID) {  // global ids when a scene is split over ranks
         if (bytes != n * 4) return fail(h, SPH_ERR_INVALID, "upload: size mismatch");
+        h->L->ensure_color(s); s.color_home_ok = 0; HIPCHK(h, hipStreamSynchronize(s.stream));
         HIPCHK(h, hipMemcpy(s.pid.cur(), src, n * 4, hipMemcpyHostToDevice));
         return SPH_OK;
     }

@@ -244,6 +244,7 @@ extern "C" int sph_comm_set_slab(SphHandle *h, int z_lo, int z_hi) {
         h->comm.rebalance_every = rb ? atoi(rb) : 64;
         h->comm.slab_ready = 1;
     }
+    h->L->ensure_color(s); s.color_home_ok = 0;   // sharded: global ids, the colours travel in the halo records
     s.slab_active = 1;
     s.z_lo = z_lo; s.z_hi = z_hi;
     // the cell lists cover the own layers plus one ghost layer per interior side only: G, and with it the histogram, the

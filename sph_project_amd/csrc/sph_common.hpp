@@ -199,6 +199,15 @@ struct State {
     int run_lists_filed;
     int *sort_inv;
     long long n_list_sorts;   // sorts that went through k_sort_rank + k_gather_prep, since create (SphStats)
+    // Bytes the sort's gather does not have to move (k_gather_prep, unsharded list sorts only):
+    //  * sort_skip_rho: set by a step whose next kernel recomputes every particle's density (WCSPH step of an all-fluid scene: the density
+    //    pass writes rho for all particles straight after the sort) -- consumed by the next sort;
+    //  * colours stay AT HOME: color_home[particle id] is written when a particle is appended and never moves, while the ids are the append
+    //    order (color_home_ok; ids set from outside or slab sharding end that).  color_stale: the sorted copy (State::color) is out of date --
+    //    whoever needs it (download, a sort by run records, slab activation) calls Launch::ensure_color first.
+    int sort_skip_rho;
+    unsigned *color_home;
+    int color_home_ok, color_stale;
     int *tmp_idx;        // stable-sort scratch: int2 (first source index, length) per run, filed at the run's first slot (2 x cap ints)
     // Sums of the histogram over the scan's tiles of SCAN_TILE cells, two banks of scan_blocks + 1 ints.  Round 6: whoever takes the
     // histogram atomics (k_hash_count, the NextHash epilogue of the force pass, the slab kernels) adds its particles to the tile sums of
@@ -313,6 +322,7 @@ struct State {
 
 // Function table implemented twice (strict / fast math), see sph_kernels.hip.
 struct Launch {
+    void (*ensure_color)(State &);   // materialise State::color in sorted order from color_home (no-op unless color_stale)
     void (*hash_count)(State &);
     void (*scan)(State &);
     void (*scatter)(State &);

@@ -996,11 +996,18 @@ k_gather_prep(const Consts c, int n, const int *__restrict__ inv, SortArrays a, 
         a.velm_out[d] = a.velm_in[i];
         a.meta_out[d] = meta_i;
         a.pid_out[d] = a.pid_in[i];
-        a.color_out[d] = a.color_in[i];
-        a.rho_out[d] = a.rho_in[i];
+        if (a.color_in) a.color_out[d] = a.color_in[i];   // (null: the colours stay at home, State::color_home)
+        if (a.rho_in) a.rho_out[d] = a.rho_in[i];         // (null: the next kernel recomputes every density, State::sort_skip_rho)
         if (a.orig_in) a.orig_out[d] = a.orig_in[i];
     }
     block_prep_tile(c, n, p, meta_i, cell_start, blk_hdr, perm, blk_flag, cellw, s_cnt, s_c);
+}
+
+// State::color in sorted order from the colours at home (color_home[particle id]; ids = append order)
+__global__ void __launch_bounds__(256)
+k_color_from_home(int n, const int *__restrict__ pid, const unsigned *__restrict__ home, unsigned *__restrict__ color) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) color[i] = home[pid[i]];
 }
 
 // ascending list of the workgroups whose flag is set (one workgroup, fixed order: the list is deterministic).  Every thread owns a

@@ -125,9 +125,15 @@ void l_block_prep(State &s, bool launch = true) {
     s.perm_n = n;
 }
 
+void l_ensure_color(State &s) {
+    if (!s.color_stale) return;
+    s.color_stale = 0;
+    if (s.c.n > 0) hipLaunchKernelGGL(k_color_from_home, dim3(cdiv(s.c.n, 256)), dim3(256), 0, s.stream, s.c.n, s.pid.cur(), s.color_home, s.color.cur());
+}
+
 void l_scatter_impl(State &s, bool stable) {
     const int n = s.c.n;
-    if (n == 0) return;
+    if (n == 0) { s.sort_skip_rho = 0; return; }
     SortArrays a;
     a.G = s.c.G;
     a.posv_in = s.posv.cur(); a.posv_out = s.posv.alt();
@@ -141,8 +147,16 @@ void l_scatter_impl(State &s, bool stable) {
     // deterministic sort of an unsharded scene whose hashers filed their runs into per-cell lists: rank from the lists, then a gather by
     // destination tile that prepares the tile for the neighbour passes as it goes -- 2 launches instead of 3 (k_scatter_index, k_scatter, k_block_prep)
     const bool by_lists = stable && s.run_lists_filed && s.run_head && s.sort_inv && !s.slab_active;
+    if (!by_lists) l_ensure_color(s);   // (k_scatter moves State::color)
     s.run_lists_filed = 0;
+    const bool skip_rho = by_lists && s.sort_skip_rho && s.c.all_fluid;
+    s.sort_skip_rho = 0;
     if (by_lists) {
+        // bytes that need not move: the colours (at home, keyed by the particle id, while the ids are the append order) and a density that
+        // the next kernel recomputes for every particle
+        static const bool move_all = getenv("SPH_SORT_MOVE_ALL") != nullptr;   // A/B
+        if (s.color_home && s.color_home_ok && !move_all) { a.color_in = nullptr; s.color_stale = 1; }
+        if (skip_rho && !move_all) a.rho_in = nullptr;
         hipLaunchKernelGGL(k_sort_rank, dim3(cdiv(n, 256)), dim3(256), 0, s.stream, n, s.cellid, s.cell_start,
                            RunList{s.run_head, s.run_rec, s.cap, s.sort_epoch}, s.sort_inv);
         const bool lst = !s.c.all_fluid && s.blk_list;
@@ -443,6 +457,7 @@ const Launch *SPH_LAUNCH_FN() {
     static Launch L;
     static bool init = false;
     if (!init) {
+        L.ensure_color = l_ensure_color;
         L.hash_count = l_hash_count;
         L.scan = l_scan;
         L.scatter = l_scatter;

@@ -159,7 +159,7 @@ static int wcsph_step(SphHandle *h) {
     // (slab_neighbor_search_push, "async"): implicit viscosity and the unfused force passes launch exact grids instead
     const bool fused = !h->prm.viscosity_implicit && !getenv("SPH_NO_FUSED_FORCES");
     if (s.slab_active) { int rc = slab_neighbor_search(h, fused); if (rc) return rc; }
-    else ph_neighbor_search(h);                                               // WCSPH.py:28
+    else { s.sort_skip_rho = s.c.all_fluid; ph_neighbor_search(h); }          // WCSPH.py:28 (the density pass below rewrites every rho: the sort need not move it)
     ph_rigid_volume(h);                                                       // base_solver.py:696 (see ph_rigid_volume)
     s.density_books_forces = (fused && !getenv("SPH_FORCES_COUNT_OWN")) ? 1 : 0;   // (switch: the force pass counts its own pairs -- the counting instantiation any other caller of l_wcsph_forces gets)
     struct Unbook { State &s; ~Unbook() { s.density_books_forces = 0; } } unbook{s};

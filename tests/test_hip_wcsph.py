@@ -421,6 +421,48 @@ def test_list_sort_equals_record_sort(gpu, fast_math, monkeypatch):
         assert a[4] == b[4]
 
 
+def test_list_sort_leaves_colours_at_home_and_densities_to_the_next_pass(gpu):
+    """What the sort's gather does NOT move (k_gather_prep: the colours stay keyed by the particle id while the ids are the append
+    order; an all-fluid WCSPH step does not carry the density its next pass recomputes): two blocks of different colour thrown at
+    each other plus one that enters late, advanced through list sorts -- every particle still has the colour it was appended
+    with (downloaded in sorted order, looked up by id), the density download is the pass's own (finite, ~rho0), and the colours
+    keep travelling with the particles once ids set from outside have ended the shortcut."""
+    cfg = H.dam_break_scene(end=(0.2, 0.3, 0.3), translation=(0.1, 0.1, 0.1), velocity=(1.0, 0.0, 0.0))
+    cfg["FluidBlocks"][0]["color"] = [10, 20, 30]
+    cfg["FluidBlocks"].append({"objectId": 1, "start": [0.0, 0.0, 0.0], "end": [0.2, 0.3, 0.3], "translation": [0.5, 0.1, 0.1],
+                               "scale": [1, 1, 1], "velocity": [-1.0, 0.0, 0.0], "density": 1000.0, "color": [200, 100, 50],
+                               "entryTime": -1.0})
+    cfg["FluidBlocks"].append({"objectId": 2, "start": [0.0, 0.0, 0.0], "end": [0.1, 0.1, 0.1], "translation": [0.35, 0.6, 0.2],
+                               "scale": [1, 1, 1], "velocity": [0.0, -1.0, 0.0], "density": 1000.0, "color": [7, 8, 9],
+                               "entryTime": 20.5 * 4e-4})
+    container, solver = H.build_product(cfg, fast_math=1)
+    solver.prepare()
+    e = container.engine
+    ids0, col0 = e.download(L.F_PARTICLE_ID), e.download(L.F_COLOR)
+    home = np.zeros((container.particle_max_num, 3), np.int32)
+    home[ids0] = col0
+    n0 = len(ids0)
+    for _ in range(30):
+        solver.step()
+    solver.advance(30)
+    st = solver.stats()
+    assert st["list_sorts"] >= 60, st
+    ids, col, rho = e.download(L.F_PARTICLE_ID), e.download(L.F_COLOR), e.download(L.F_DENSITY)
+    assert len(ids) > n0 and np.array_equal(np.sort(ids), np.arange(len(ids)))      # the late block came in
+    late = ids >= n0
+    assert (col[late] == np.array([7, 8, 9])).all()
+    assert np.array_equal(col[~late], home[ids[~late]])
+    assert set(map(tuple, col0)) == {(10, 20, 30), (200, 100, 50)}
+    assert np.isfinite(rho).all() and rho.min() >= 999.0 and rho.max() < 2000.0
+    # ids from outside end the shortcut: the colours are materialised and travel with the particles again
+    e.upload(L.F_PARTICLE_ID, (ids + 1000000).astype(np.int32))
+    solver.advance(5)
+    ids2, col2 = e.download(L.F_PARTICLE_ID), e.download(L.F_COLOR)
+    lut = np.zeros((len(ids), 3), np.int32)
+    lut[ids] = col
+    assert np.array_equal(col2, lut[ids2 - 1000000])
+
+
 def test_list_sort_with_boundary_particles(gpu, monkeypatch):
     """The same A/B where the scene is not all fluid (sampled domain box: the gather also flags the tiles that hold fluid, and
     k_hash_count -- not the force pass -- files the runs every step)."""
