@@ -14,11 +14,13 @@ k_advect_boundary(const Consts c, float4 *posv, float4 *velm, int *meta, const R
     if (valid) {
         p = posv[i];
         float4 v = velm[i];
+        const float4 v_in = v;
         const int m = all_fluid ? META_PACK(0, 1, 1) : meta[i];
         if (META_MAT(m) == 1) {
             p.x += c.dt * v.x; p.y += c.dt * v.y; p.z += c.dt * v.z;
             if (META_DYN(m)) enforce_boundary(c, p.x, p.y, p.z, v.x, v.y, v.z);
-            posv[i] = p; velm[i] = v;
+            posv[i] = p;
+            if (__float_as_int(v.x) != __float_as_int(v_in.x) || __float_as_int(v.y) != __float_as_int(v_in.y) || __float_as_int(v.z) != __float_as_int(v_in.z)) velm[i] = v;   // (only a particle that hit a wall: 16 B per particle not written)
         } else if (up_coord(c, p) > c.g_upper) {  // emitter branch :660-666
             const int obj = META_OBJ(m);
             if (obj >= 0 && pose->material[obj] == 1) {

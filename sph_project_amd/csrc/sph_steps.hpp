@@ -343,7 +343,7 @@ static int dfsph_step_begin(SphHandle *h, bool allow_readback) {
 static int dfsph_step_end(SphHandle *h, bool allow_readback) {
     State &s = h->st;
     if (s.slab_active) { int rc = slab_neighbor_search(h); if (rc) return rc; }   // + migration / ghost exchange
-    else ph_neighbor_search(h);                                               // :316
+    else { s.sort_skip_rho = s.c.all_fluid; ph_neighbor_search(h); }          // :316 (the density pass below rewrites every rho: the sort need not move it)
     ph_rigid_volume(h);
     static const bool unfused = getenv("SPH_NO_DFSPH_FUSED_DIV") != nullptr;   // A/B switch
     if (unfused) { ProfScope p(h, SPH_K_DFSPH_DENSITY_ALPHA); h->L->dfsph_density_alpha(s); } // :317-318
@@ -395,7 +395,7 @@ static int pcisph_refine(SphHandle *h, bool allow_readback) {
 static int pcisph_step(SphHandle *h, bool allow_readback) {
     State &s = h->st;
     if (s.slab_active) { int rc = slab_neighbor_search(h); if (rc) return rc; }   // + migration / ghost exchange
-    else ph_neighbor_search(h);                                               // PCISPH.py:166
+    else { s.sort_skip_rho = s.c.all_fluid; ph_neighbor_search(h); }          // PCISPH.py:166 (:167 below rewrites every rho)
     ph_rigid_volume(h);
     { ProfScope p(h, SPH_K_DENSITY); h->L->density(s, 0); }                   // :167
     if (s.slab_active) { int rc = slab_exchange_scalar(h, s.rho.cur()); if (rc) return rc; }   // ghost densities (viscosity)
