@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the three-way form: needs tools/experiments/r06_gather_rank_prep.patch applied -- in the tree "lists" IS rank kernel + plain gather and SPH_SORT_RANK_KERNEL does nothing)
 # deterministic sort by run lists against the sort by run records (SPH_NO_RUN_LISTS=1), and the two forms of the list sort:
 #   lists   = k_scan_final + k_gather_rank_prep (2 launches; the gathering workgroup finds its slots' cells and source particles itself)
 #   rankk   = SPH_SORT_RANK_KERNEL=1: k_scan_final + k_sort_rank + k_gather_prep (3 launches, inverse map in between)

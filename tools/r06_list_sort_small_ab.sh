@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the three-way form: needs tools/experiments/r06_gather_rank_prep.patch applied -- in the tree "lists" IS rank kernel + plain gather and SPH_SORT_RANK_KERNEL does nothing)
 # the three sorts (tools/r06_list_sort_ab.sh) where launches count most: C5 (2.17 M particles, ~106 k of them fluid) and unsharded blocks the size of a rank's share
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/r06_list_sort
