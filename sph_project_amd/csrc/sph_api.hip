@@ -321,6 +321,7 @@ extern "C" int sph_create(const SphParams *params, SphHandle **out) {
     if (h->prm.deterministic && !getenv("SPH_NO_RUN_LISTS")) { CHK_CREATE(dalloc(h, &s.run_head, G + 1)); CHK_CREATE(dalloc(h, &s.run_rec, cap + G + 1)); CHK_CREATE(dalloc(h, &s.sort_inv, cap)); CHK_CREATE(dalloc(h, &s.color_home, cap)); s.color_home_ok = 1; }   // deterministic sort by run lists (RunList, sph_common.hpp)
     s.scan_blocks = (int)((G + SPH_NGRAVE + 2047) / 2048);
     if (s.scan_blocks < SPH_STAT_SLOTS / 256) s.scan_blocks = SPH_STAT_SLOTS / 256;   // k_scan_final also clears the statistics slots
+    s.scan_tile_state = nullptr; if (!getenv("SPH_SCAN_ALL_TILES")) CHK_CREATE(dalloc(h, &s.scan_tile_state, (size_t)s.scan_blocks + 1));
     CHK_CREATE(dalloc(h, &s.scan_partial, 2 * ((size_t)s.scan_blocks + 1) * 8));   // two banks of tile sums, SCAN_PARTIAL_STRIDE ints apart (State::scan_bank)
     s.scan_bank = 0; s.tile_sums_ready = 0; s.skip_residual = 0; s.hist_taken = 0; s.state_error = 0;
     s.cell_count_clean = 1;

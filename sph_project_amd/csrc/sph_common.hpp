@@ -215,6 +215,7 @@ struct State {
     // k_scan_final reads that bank and clears the other one for the next histogram (like cell_count, which it clears behind itself).
     int *scan_partial;
     int scan_blocks;
+    int *scan_tile_state;   // per scan tile: (particles before it) + 1 if its cells hold that constant because it was EMPTY at the last scan, else 0 (k_scan_final)
     int scan_bank;       // bank the hashers of the coming sort add to / the coming scan reads
     int skip_residual;   // fixed-iteration solves (no stop test, nobody reads the residual): the walks leave their partial sums, k_reduce_partials is not launched
     int tile_sums_ready; // ... and they did (else l_scan launches k_scan_reduce first: SPH_NO_SCAN_FOLD)

@@ -347,7 +347,8 @@ k_scan_reduce(const int *__restrict__ in, int n, int *__restrict__ partial) {
 
 __global__ void __launch_bounds__(SCAN_TPB)
 k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *__restrict__ out,
-             int total_particles, DevScalars *__restrict__ scal, int clear_bank, const int *__restrict__ total_dev, int *__restrict__ partial_next) {
+             int total_particles, DevScalars *__restrict__ scal, int clear_bank, const int *__restrict__ total_dev, int *__restrict__ partial_next,
+             int *__restrict__ tile_state) {
     // side jobs of the kernel that runs every step: clears cell_count behind itself (the next histogram starts from
     // zero without a memset) and clears the statistics bank of the next step
     __shared__ int s_w[SCAN_TPB / 64];
@@ -364,7 +365,24 @@ k_scan_final(int *__restrict__ in, int n, const int *__restrict__ partial, int *
     int before = 0;
     for (int k = threadIdx.x; k < (int)blockIdx.x; k += SCAN_TPB) before += partial[k * SCAN_PARTIAL_STRIDE];
     int tot0, tot1, btot;
+    // EMPTY tiles (most of them: the fluid fills a corner of the domain -- 930 of C2's 1041 tiles hold no particle) need no histogram and no
+    // zeroing, only cell_start = (particles before the tile) in all their cells; and not even that when the tile was empty with the same
+    // count before it at the last scan (tile_state[t] = that count + 1, 0 = cells hold a real scan).  The tile's own sum comes from whoever
+    // took the histogram (or k_scan_reduce); the last tile's is never counted (tile_sum_add), block 0 also files cell_start[n].  The loads
+    // above are issued regardless: skipping them would put a dependent round trip in front of every tile that does hold particles.
+    const bool maybe_empty = tile_state && blockIdx.x > 0 && (int)blockIdx.x < ((n - 1) >> SCAN_TILE_SHIFT);
+    const int own_sum = maybe_empty ? partial[blockIdx.x * SCAN_PARTIAL_STRIDE] : 1;
+    const int was = maybe_empty ? tile_state[blockIdx.x] : 0;
     block_excl_scan_256(before, s_w, btot);
+    if (own_sum == 0) {   // (workgroup-uniform)
+        if (was == btot + 1) return;
+        const int4 o = make_int4(btot, btot, btot, btot);
+        *reinterpret_cast<int4 *>(out + base) = o;                   // (not the last tile: every index is inside the grid)
+        *reinterpret_cast<int4 *>(out + base + SCAN_TILE / 2) = o;
+        if (threadIdx.x == 0) tile_state[blockIdx.x] = btot + 1;
+        return;
+    }
+    if (tile_state && threadIdx.x == 0 && (int)blockIdx.x <= ((n - 1) >> SCAN_TILE_SHIFT)) tile_state[blockIdx.x] = 0;
     const int sa = (a.x + a.y) + (a.z + a.w), sb = (b.x + b.y) + (b.z + b.w);
     int ea = block_excl_scan_256(sa, s_w, tot0) + btot;
     int eb = block_excl_scan_256(sb, s_w, tot1) + btot + tot0;

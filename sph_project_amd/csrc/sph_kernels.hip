@@ -83,7 +83,8 @@ void l_scan(State &s) {
     // the tile sums: left by whoever took the histogram (one launch less per sort, round 6), else by k_scan_reduce
     if (!s.tile_sums_ready) hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, part);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_TPB), 0, s.stream, s.cell_count, G, part,
-                       s.cell_start, s.c.n, s.scal, 1 - s.c.stat_bank, s.c.n_dev, part_next);
+                       s.cell_start, s.c.n, s.scal, 1 - s.c.stat_bank, s.c.n_dev, part_next,
+                       (s.scan_tile_state && !s.slab_active) ? s.scan_tile_state : nullptr);   // (a slab's grid moves with its cuts: every tile scanned)
     s.cell_count_clean = 1;   // ... and so is the bank of tile sums the next histogram adds to
     s.scan_bank = 1 - s.scan_bank;
     s.tile_sums_ready = 0;
